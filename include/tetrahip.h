@@ -1,0 +1,156 @@
+/*
+ * tetrahip.h -- C-ABI of libtetrahip.so: MI355X (gfx950) TETRA IQ -> symbol front end.
+ *
+ * This is the drop-in boundary for ONE path of syrex1013/TetraEar:
+ *     tetraear/signal/processor.py  SignalProcessor  (processor.py:18-273)
+ * The reference has no FFI of its own (it is pure Python over numpy/scipy); the
+ * boundary a maintainer binds is this header via ctypes (see INTEGRATION.md and
+ * tetraear_amd/signal/processor.py, which keeps the SignalProcessor interface).
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the ABI; every call returns 0 (TDM_OK) or a negative
+ *     tdm_status; tdm_last_error() gives the text for the calling thread.
+ *   - the caller owns every buffer it passes; a plan owns its device scratch.
+ *   - a plan is not thread-safe (one caller at a time, like the reference instance,
+ *     ui/modern.py:1857); the library is.
+ *   - complex data: interleaved (re, im).  "c128" = two doubles per sample.
+ *   - there is NO CPU fallback: without a gfx950 device every compute call fails with
+ *     TDM_ERR_NO_DEVICE.
+ */
+#ifndef TETRAHIP_H
+#define TETRAHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDM_VERSION 100 /* 0.1.0 */
+
+typedef enum tdm_status {
+    TDM_OK = 0,
+    TDM_ERR_INVALID = -1,    /* bad argument */
+    TDM_ERR_NO_DEVICE = -2,  /* no usable gfx950 device / HIP runtime failure at init */
+    TDM_ERR_HIP = -3,        /* a HIP call failed (text in tdm_last_error) */
+    TDM_ERR_NOMEM = -4,
+    TDM_ERR_UNSUPPORTED = -5
+} tdm_status;
+
+/* IQ sample formats accepted on the wire (signal/capture.py:143-158 hands over complex128
+ * made by pyrtlsdr from cu8; cu8 is the RTL-SDR native format). */
+typedef enum tdm_fmt {
+    TDM_CU8 = 0,  /* uint8 I,Q;  value = u/127.5 - 1   (pyrtlsdr convention) */
+    TDM_CS8 = 1,  /* int8  I,Q;  value = s/128.0 */
+    TDM_CF32 = 2, /* float I,Q */
+    TDM_CF64 = 3  /* double I,Q  (numpy complex128, the reference's own dtype) */
+} tdm_fmt;
+
+typedef enum tdm_mode {
+    TDM_MODE_REFERENCE = 0, /* reproduces processor.py:221-273 (parity mode) */
+    TDM_MODE_TETRA = 1      /* RRC + Gardner/Farrow pi/4-DQPSK receiver (no reference oracle) */
+} tdm_mode;
+
+typedef struct tdm_plan tdm_plan;
+
+/* Derived constants of a plan (processor.py:245-255, :74-75, :183, :194). */
+typedef struct tdm_plan_info {
+    double sample_rate;
+    double rate_dec;      /* rate after the decimator (== sample_rate if not decimated) */
+    int64_t n_samples;    /* samples per carrier per call */
+    int64_t n_dec;        /* samples per carrier after the decimator */
+    int32_t n_carriers;
+    int32_t q;            /* decimation factor actually applied (1 = none) */
+    int32_t sps;          /* int(rate_dec / 18000) */
+    int32_t phase_step;   /* max(1, sps // 8) */
+    int32_t max_soft;     /* capacity per carrier of the soft-symbol output */
+    int32_t lpf_applied;  /* 0 when n_dec <= 15 (reference falls back to unfiltered) */
+    int32_t in_fmt;
+    int32_t mode;
+    int32_t device;
+    int32_t reserved;
+} tdm_plan_info;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int tdm_version(void);
+/* number of HIP devices, or a negative tdm_status */
+int tdm_device_count(void);
+/* copies the calling thread's last error text (NUL-terminated) into buf; returns its length */
+int tdm_last_error(char *buf, size_t buflen);
+
+/* ---- plan: one (sample_rate, n_samples, n_carriers, format) configuration ----------------
+ * replaces SignalProcessor.__init__ (processor.py:21-33) + the per-call filter design
+ * (processor.py:78, :254).  n_carriers independent streams are processed per call.         */
+int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, int32_t in_fmt,
+                    int32_t mode, int32_t device, tdm_plan **out);
+int tdm_plan_destroy(tdm_plan *plan);
+int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
+
+/* ---- SignalProcessor.process (processor.py:221-273), batched over carriers ----------------
+ *  iq            [n_carriers] streams of n_samples in the plan's format; carrier c starts at
+ *                iq + c * carrier_stride_samples samples (0 = all carriers share one stream)
+ *  pre_shift_hz  per carrier, or NULL: frequency_shift(x, f) at the INPUT rate before process()
+ *                (processor.py:85-100; the composition SURVEY.md 8(d) C3 uses to channelise)
+ *  freq_offset_hz per carrier, or NULL: process()'s freq_offset (applied after the decimator)
+ *  hard          [n_carriers][max_soft] uint8 symbols 0..3   (n_hard = max(n_soft-1, 0))
+ *  soft          [n_carriers][max_soft] c128, = SignalProcessor.symbols (processor.py:268)
+ *  n_soft        [n_carriers]
+ *  best_phase    [n_carriers] timing phase chosen (processor.py:196-210), may be NULL
+ *  min_margin    [n_carriers] min |phase - threshold| over the decisions (rad), may be NULL
+ * tdm_process:        all pointers are HOST memory; blocking.
+ * tdm_process_device: all pointers are DEVICE memory (pre_shift/freq_offset too); enqueues on
+ *                     `stream` (a hipStream_t, NULL = default) and returns; tdm_plan_sync waits. */
+int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples,
+                const double *pre_shift_hz, const double *freq_offset_hz, uint8_t *hard, double *soft,
+                int32_t *n_soft, int32_t *best_phase, double *min_margin);
+int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples,
+                       const double *pre_shift_hz, const double *freq_offset_hz, uint8_t *hard,
+                       double *soft, int32_t *n_soft, int32_t *best_phase, double *min_margin,
+                       void *stream);
+int tdm_plan_sync(tdm_plan *plan);
+
+/* ---- the other public methods of SignalProcessor, one call each (host pointers, blocking) ---
+ * All take/return c128 host arrays.                                                          */
+/* filter_signal (processor.py:51-83). *applied = 0 when the reference's except-branch would
+ * return the input unchanged (n <= 15). */
+int tdm_filter_signal(const double *x, int64_t n, double bandwidth, double fs, double *y,
+                      int32_t *applied, int32_t device);
+/* frequency_shift (processor.py:85-100) */
+int tdm_frequency_shift(const double *x, int64_t n, double freq_offset, double fs, double *y,
+                        int32_t device);
+/* extract_symbols (processor.py:168-219): y has room for n samples */
+int tdm_extract_symbols(const double *x, int64_t n, double fs, double symbol_rate, double *y,
+                        int64_t *n_out, int32_t *best_phase, int32_t device);
+/* demodulate_dqpsk (processor.py:102-166): out has room for n-1 symbols */
+int tdm_demodulate_dqpsk(const double *x, int64_t n, uint8_t *out, int64_t *n_out, double *min_margin,
+                         int32_t device);
+/* scipy.signal.decimate(x, q) as called at processor.py:254 (y has room for ceil(n/q));
+ * returns TDM_ERR_INVALID when n <= 27 (scipy raises there). */
+int tdm_decimate(const double *x, int64_t n, int32_t q, double *y, int64_t *n_out, int32_t device);
+/* resample (processor.py:35-49): scipy.signal.resample (FFT method) to `num` points */
+int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t device);
+
+/* ---- device memory helpers for callers without a HIP binding (bench, tests) ---------------- */
+int tdm_dev_alloc(int32_t device, size_t bytes, void **ptr);
+int tdm_dev_free(int32_t device, void *ptr);
+int tdm_dev_upload(int32_t device, void *dst_dev, const void *src_host, size_t bytes);
+int tdm_dev_download(int32_t device, void *dst_host, const void *src_dev, size_t bytes);
+int tdm_dev_sync(int32_t device);
+/* event timing on the library's own stream for a plan: elapsed milliseconds between two marks */
+int tdm_plan_time_begin(tdm_plan *plan);
+int tdm_plan_time_end(tdm_plan *plan, float *elapsed_ms);
+/* per-stage kernel time (ms) accumulated between time_begin/time_end; names[i] static strings */
+int tdm_plan_stage_times(tdm_plan *plan, int32_t max_stages, const char **names, float *ms,
+                         int32_t *n_stages);
+
+/* ---- introspection used by the CPU tests (no device needed) -------------------------------- */
+/* filter design the plan would use: sos[4][6], soszi[4][2] (zeros if q == 1), b[5], a[5], zi[4] */
+int tdm_design_dump(double sample_rate, int64_t n_samples, double *sos, double *soszi, double *b,
+                    double *a, double *zi, int32_t *q, double *rate_dec);
+int tdm_design_butter(double bandwidth, double fs, double *b, double *a, double *zi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TETRAHIP_H */

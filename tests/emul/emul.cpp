@@ -1,0 +1,210 @@
+// TEST INFRASTRUCTURE ONLY -- CPU lock-step emulation of the HIP kernels.
+//
+// Compiles the kernel bodies of tetraear_amd/csrc/zp_kernels.hpp with g++ and runs each
+// "workgroup" as a set of std::threads that exchange data through barriers where the GPU uses
+// wavefront shuffles / LDS reductions.  It exists so that the table/index logic of the device
+// code can be validated against the oracle in the CPU test tier (no GPU in the build container).
+// It is NOT part of the product: tetraear_amd never loads it and libtetrahip.so has no CPU path.
+#include <barrier>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "../../tetraear_amd/csrc/ref_pipeline.hpp"
+
+using namespace tdm;
+
+namespace {
+
+struct Group {
+    int nt;
+    std::barrier<> bar;
+    std::vector<double> slots;
+    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16) {}
+};
+
+struct EmuWaveComm {
+    Group *g;
+    int lane;
+    template <int K>
+    void xchg(const double *a, const double *b, double *oa, double *ob, int src)
+    {
+        double *mine = &g->slots[(size_t)lane * 16];
+        for (int k = 0; k < K; ++k) { mine[k] = a[k]; mine[8 + k] = b[k]; }
+        g->bar.arrive_and_wait();
+        const int s = (src >= 0 && src < g->nt) ? src : lane;
+        const double *from = &g->slots[(size_t)s * 16];
+        for (int k = 0; k < K; ++k) { oa[k] = from[k]; ob[k] = from[8 + k]; }
+        g->bar.arrive_and_wait();
+    }
+    template <int K>
+    void shfl_up2(const double *a, const double *b, double *oa, double *ob, int d) { xchg<K>(a, b, oa, ob, lane - d); }
+    template <int K>
+    void shfl_down2(const double *a, const double *b, double *oa, double *ob, int d) { xchg<K>(a, b, oa, ob, lane + d); }
+};
+
+struct EmuBlockComm {
+    Group *g;
+    int t;
+    int tid() const { return t; }
+    int nthreads() const { return g->nt; }
+    void sync() { g->bar.arrive_and_wait(); }
+    template <class F>
+    double reduce(double v, F f)
+    {
+        g->slots[t] = v;
+        g->bar.arrive_and_wait();
+        double r = g->slots[0];
+        for (int i = 1; i < g->nt; ++i) r = f(r, g->slots[i]);
+        g->bar.arrive_and_wait();
+        return r;
+    }
+    double reduce_sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
+    double reduce_max(double v) { return reduce(v, [](double a, double b) { return std::fmax(a, b); }); }
+    double reduce_min(double v) { return reduce(v, [](double a, double b) { return std::fmin(a, b); }); }
+};
+
+template <class F>
+void run_group(int nt, F fn)
+{
+    Group g(nt);
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(t, &g); });
+    for (auto &x : th) x.join();
+}
+
+struct EmuBackend {
+    template <int K, int NSEC, int L, int EDGE, class Loader>
+    void zp_block(const ZpParams *P, Loader ld, int nb, int rows)
+    {
+        for (int row = 0; row < rows; ++row)
+            for (int b = 0; b < nb; ++b)
+                run_group(kWave, [&](int lane, Group *g) {
+                    EmuWaveComm cm{g, lane};
+                    zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, lane, b, row);
+                });
+    }
+    template <int K, int NSEC>
+    void zp_carry(const ZpParams *P, int nb, int rows)
+    {
+        for (int row = 0; row < rows; ++row)
+            for (int b = 0; b < nb; ++b)
+                for (int ch = 0; ch < 2; ++ch) zp_carry_fwd_body<K, NSEC>(P, row, b, ch);
+        for (int row = 0; row < rows; ++row)
+            for (int b = 0; b < nb; ++b)
+                for (int ch = 0; ch < 2; ++ch) zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
+    }
+    template <int D>
+    void zp_fixup(const ZpParams *P, int rows, int64_t n_out, double *out, int64_t out_row_stride,
+                  const double *freq_offset, double fs_out)
+    {
+        for (int row = 0; row < rows; ++row)
+            for (int64_t j = 0; j < n_out; ++j)
+                zp_fixup_body<D>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
+    }
+    template <int FMT>
+    void convert(RawLoader<FMT> ld, int rows, int64_t n, double *out, const double *freq_offset, double fs)
+    {
+        for (int row = 0; row < rows; ++row)
+            for (int64_t j = 0; j < n; ++j) convert_body<FMT>(ld, row, j, out + (int64_t)row * n * 2, freq_offset, fs);
+    }
+    void finish(const FinishArgs &fa, int rows)
+    {
+        for (int row = 0; row < rows; ++row)
+            run_group(64, [&](int t, Group *g) {
+                EmuBlockComm cm{g, t};
+                finish_body(fa, cm, row);
+            });
+    }
+};
+
+struct HostZp {
+    ZpHostTables t;
+    std::vector<double> y0, Ef, Eb, flast, Gf, Hb;
+    void bind(int rows)
+    {
+        ZpParams &p = t.p;
+        const int D = p.nsec * p.K;
+        p.Mpow = t.blob.data() + t.off_Mpow;
+        p.csec = t.blob.data() + t.off_csec;
+        p.cfull = t.blob.data() + t.off_cfull;
+        p.T1_reg = t.blob.data() + t.off_T1reg;
+        p.T1_last = t.blob.data() + t.off_T1last;
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        y0.assign((size_t)rows * p.n_out * 2 + 2, nan);
+        Ef.assign((size_t)rows * p.nb * D * 2, nan);
+        Eb.assign((size_t)rows * p.nb * D * 2, nan);
+        Gf.assign((size_t)rows * p.nb * D * 2, nan);
+        Hb.assign((size_t)rows * p.nb * D * 2, nan);
+        flast.assign((size_t)rows * 2, nan);
+        p.y0 = y0.data(); p.Ef = Ef.data(); p.Eb = Eb.data();
+        p.Gf = Gf.data(); p.Hb = Hb.data(); p.flast = flast.data();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// whole pipeline == tdm_process with host pointers
+int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq, int64_t stride,
+                const double *pre_shift, const double *freq_offset, uint8_t *hard, double *soft,
+                int32_t *n_soft, int32_t *best_phase, double *min_margin, int32_t *max_soft_out)
+{
+    RefPlanHost h = build_ref_plan(sample_rate, n);
+    if (max_soft_out) *max_soft_out = (int32_t)h.max_soft;
+    if (!iq) return 0;  // query only
+    HostZp dec, lpf;
+    RefBuffers B;
+    if (h.decimated) { dec.t = h.dec; dec.bind(rows); B.dec_params = &dec.t.p; }
+    if (h.lpf) { lpf.t = h.lpf_t; lpf.bind(rows); B.lpf_params = &lpf.t.p; }
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    std::vector<double> y((size_t)rows * h.n_dec * 2 + 2, nan), z((size_t)rows * h.n_dec * 2 + 2, nan);
+    B.y = y.data();
+    B.z = z.data();
+    RefIO io{iq, stride, pre_shift, freq_offset, hard, soft, n_soft, best_phase, min_margin};
+    EmuBackend be;
+    run_ref(be, h, rows, fmt, B, io);
+    return 0;
+}
+
+// one zero-phase stage on c128 data: kind 0 = decimator sos (q), kind 1 = butter tf (bandwidth, fs)
+int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, double fs, double *y)
+{
+    EmuBackend be;
+    HostZp hz;
+    RawLoader<FMT_CF64> ld{x, n, nullptr, fs};
+    if (kind == 0) {
+        if (n <= kEdgeSos) return -1;
+        Sos4 s = design_cheby1_8(0.05, 0.8 / q);
+        int64_t n_out = (n + q - 1) / q;
+        hz.t = build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, n_out, q);
+        hz.bind(1);
+        be.zp_block<2, 4, kLDec, kEdgeSos>(&hz.t.p, ld, hz.t.p.nb, 1);
+        be.zp_carry<2, 4>(&hz.t.p, hz.t.p.nb, 1);
+        be.zp_fixup<8>(&hz.t.p, 1, n_out, y, n_out, nullptr, fs);
+    } else {
+        if (n <= kEdgeTf) return -1;
+        Tf4 t = design_butter4(butter_cutoff(bandwidth, fs));
+        hz.t = build_zp_tables(desc_from_tf(t), n, kEdgeTf, kLLpf, n, 1);
+        hz.bind(1);
+        be.zp_block<4, 1, kLLpf, kEdgeTf>(&hz.t.p, ld, hz.t.p.nb, 1);
+        be.zp_carry<4, 1>(&hz.t.p, hz.t.p.nb, 1);
+        be.zp_fixup<4>(&hz.t.p, 1, n, y, n, nullptr, fs);
+    }
+    return 0;
+}
+
+int emu_carry_terms(double sample_rate, int64_t n, int32_t *dec_terms, int32_t *lpf_terms, int32_t *nb_dec)
+{
+    RefPlanHost h = build_ref_plan(sample_rate, n);
+    *dec_terms = h.decimated ? h.dec.p.carry_terms : 0;
+    *lpf_terms = h.lpf ? h.lpf_t.p.carry_terms : 0;
+    *nb_dec = h.decimated ? h.dec.p.nb : 0;
+    return 0;
+}
+}

@@ -1,0 +1,56 @@
+"""TEST INFRASTRUCTURE: ctypes face of tests/emul/libtdm_emul.so (CPU lock-step emulation of
+the HIP kernel bodies).  Never imported by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+        _LIB = C.CDLL(os.path.join(_HERE, "libtdm_emul.so"))
+    return _LIB
+
+
+FMT = {"cu8": 0, "cs8": 1, "cf32": 2, "cf64": 3}
+
+
+def process(sample_rate, iq, fmt, n, rows=1, stride=None, pre_shift=None, freq_offset=None):
+    L = lib()
+    ms = C.c_int32()
+    L.emu_process(C.c_double(sample_rate), C.c_int64(n), rows, FMT[fmt], None, C.c_int64(0), None, None,
+                  None, None, None, None, None, C.byref(ms))
+    ms = ms.value
+    hard = np.zeros((rows, ms), dtype=np.uint8)
+    soft = np.zeros((rows, ms), dtype=np.complex128)
+    n_soft = np.zeros(rows, dtype=np.int32)
+    bp = np.zeros(rows, dtype=np.int32)
+    mm = np.zeros(rows, dtype=np.float64)
+    iq = np.ascontiguousarray(iq)
+    ps = None if pre_shift is None else np.ascontiguousarray(pre_shift, dtype=np.float64)
+    fo = None if freq_offset is None else np.ascontiguousarray(freq_offset, dtype=np.float64)
+    if stride is None:
+        stride = n
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    L.emu_process(C.c_double(sample_rate), C.c_int64(n), rows, FMT[fmt], vp(iq), C.c_int64(stride), vp(ps),
+                  vp(fo), vp(hard), vp(soft), vp(n_soft), vp(bp), vp(mm), None)
+    return hard, soft, n_soft, bp, mm
+
+
+def zp_stage(kind, x, q=10, bandwidth=25000.0, fs=240000.0):
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    n = len(x)
+    n_out = (n + q - 1) // q if kind == 0 else n
+    y = np.zeros(n_out, dtype=np.complex128)
+    rc = L.emu_zp_stage(kind, x.ctypes.data_as(C.c_void_p), C.c_int64(n), q, C.c_double(bandwidth),
+                        C.c_double(fs), y.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError("input too short")
+    return y

@@ -1,0 +1,104 @@
+// Launch sequence of the reference-parity pipeline (SignalProcessor.process, processor.py:221-273),
+// written against a Backend so that the gfx950 build (tdm_hip.hip) and the CPU lock-step test
+// harness (tests/emul) run the SAME sequence of the SAME kernel bodies.
+//
+// Backend concept (all calls enqueue asynchronously on the backend's stream):
+//   template<int K,int NSEC,int L,int EDGE,class Loader> void zp_block(const ZpParams* dev, Loader, int nb, int rows);
+//   template<int K,int NSEC> void zp_carry(const ZpParams* dev, int nb, int rows);
+//   template<int D> void zp_fixup(const ZpParams* dev, int rows, int64_t n_out, double* out,
+//                                 int64_t out_row_stride, const double* freq_offset, double fs_out);
+//   template<int FMT> void convert(RawLoader<FMT>, int rows, int64_t n, double* out,
+//                                  const double* freq_offset, double fs);
+//   void finish(const FinishArgs&, int rows);
+#pragma once
+#include "ref_plan.hpp"
+#include "zp_kernels.hpp"
+
+namespace tdm {
+
+struct RefBuffers {
+    const ZpParams *dec_params = nullptr;  // backend-visible copies of h.dec.p / h.lpf_t.p
+    const ZpParams *lpf_params = nullptr;
+    double *y = nullptr;  // [rows][n_dec] c128: decimated (+freq_offset) signal
+    double *z = nullptr;  // [rows][n_dec] c128: channel-filtered signal
+};
+
+struct RefIO {
+    const void *iq;
+    int64_t carrier_stride;
+    const double *pre_shift;
+    const double *freq_offset;
+    uint8_t *hard;
+    double *soft;
+    int32_t *n_soft;
+    int32_t *best_phase;
+    double *min_margin;
+};
+
+template <class BE, int FMT>
+void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, const RefIO &io)
+{
+    RawLoader<FMT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
+    if (h.decimated) {
+        // scipy.signal.decimate(samples, q)  (processor.py:254)
+        be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
+        be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
+        // + frequency_shift(samples, freq_offset, current_rate)  (processor.py:260-261)
+        be.template zp_fixup<8>(B.dec_params, rows, h.n_dec, B.y, h.n_dec, io.freq_offset, h.rate_dec);
+    } else {
+        be.template convert<FMT>(ld, rows, h.n, B.y, io.freq_offset, h.sample_rate);
+    }
+    const double *zin = B.y;
+    if (h.lpf) {
+        // filter_signal(samples, 25000, current_rate)  (processor.py:264)
+        RawLoader<FMT_CF64> l2{B.y, h.n_dec, nullptr, h.rate_dec};
+        be.template zp_block<4, 1, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
+        be.template zp_carry<4, 1>(B.lpf_params, h.lpf_t.p.nb, rows);
+        be.template zp_fixup<4>(B.lpf_params, rows, h.n_dec, B.z, h.n_dec, nullptr, h.rate_dec);
+        zin = B.z;
+    }
+    // extract_symbols + demodulate_dqpsk  (processor.py:267-271)
+    FinishArgs fa{};
+    fa.z = zin;
+    fa.n = h.n_dec;
+    fa.row_stride = h.n_dec;
+    fa.sps = h.sps;
+    fa.do_extract = 1;
+    fa.do_demod = 1;
+    fa.max_soft = (int32_t)h.max_soft;
+    fa.soft = io.soft;
+    fa.hard = io.hard;
+    fa.n_soft = io.n_soft;
+    fa.best_phase = io.best_phase;
+    fa.min_margin = io.min_margin;
+    be.finish(fa, rows);
+}
+
+template <class BE>
+void run_ref(BE &be, const RefPlanHost &h, int rows, int fmt, const RefBuffers &B, const RefIO &io)
+{
+    switch (fmt) {
+    case FMT_CU8: run_ref_fmt<BE, FMT_CU8>(be, h, rows, B, io); break;
+    case FMT_CS8: run_ref_fmt<BE, FMT_CS8>(be, h, rows, B, io); break;
+    case FMT_CF32: run_ref_fmt<BE, FMT_CF32>(be, h, rows, B, io); break;
+    default: run_ref_fmt<BE, FMT_CF64>(be, h, rows, B, io); break;
+    }
+}
+
+// convert body: raw sample (+ input-rate pre-shift) then process()'s freq_offset at rate fs
+template <int FMT>
+TDM_HD void convert_body(const RawLoader<FMT> &ld, int row, int64_t j, double *out_row,
+                         const double *freq_offset, double fs)
+{
+    double re, im;
+    const double f0 = ld.pre_shift ? ld.pre_shift[row] : 0.0;
+    ld.sample(ld.row_ptr(row), j, f0, re, im);
+    if (freq_offset) {
+        const double f = freq_offset[row];
+        if (f != 0.0) nco_rotate(re, im, j, f, fs);
+    }
+    out_row[j * 2] = re;
+    out_row[j * 2 + 1] = im;
+}
+
+}  // namespace tdm

@@ -1,0 +1,81 @@
+// Host-side plan of the reference-parity pipeline: the decisions SignalProcessor.process makes
+// per call (processor.py:239-273) turned into a static description for one
+// (sample_rate, n_samples) pair, plus the filter tables for the two zero-phase stages.
+#pragma once
+#include <cstdint>
+
+#include "design.hpp"
+#include "zp_tables.hpp"
+
+namespace tdm {
+
+constexpr int kLDec = 32;  // samples per lane, decimator stage (4 biquads)
+constexpr int kLLpf = 32;  // samples per lane, channel-filter stage (order-4 tf)
+constexpr int kEdgeSos = 27;  // sosfiltfilt pad for 4 sections: 3*(2*4+1)
+constexpr int kEdgeTf = 15;   // filtfilt pad for order 4: 3*5
+constexpr double kSymbolRate = 18000.0;
+
+struct RefPlanHost {
+    double sample_rate = 0;
+    int64_t n = 0;
+    int q = 1;              // factor the reference would use (processor.py:248-250)
+    bool decimated = false; // false also when decimate raises (n <= 27, processor.py:253-257)
+    double rate_dec = 0;    // current_rate after the decimation step
+    int64_t n_dec = 0;
+    bool lpf = false;       // false when filtfilt raises (n_dec <= 15, processor.py:81-83)
+    int sps = 0;            // int(rate_dec / 18000)
+    int phase_step = 1;
+    int64_t max_soft = 0;
+    Sos4 sos{};
+    Tf4 tf{};
+    ZpHostTables dec;       // valid if decimated
+    ZpHostTables lpf_t;     // valid if lpf
+};
+
+inline ZpFilterDesc desc_from_sos(const Sos4 &s)
+{
+    ZpFilterDesc f{};
+    f.nsec = 4;
+    f.K = 2;
+    for (int i = 0; i < 4; ++i) {
+        for (int k = 0; k < 3; ++k) { f.b[i][k] = s.sos[i][k]; f.a[i][k] = s.sos[i][3 + k]; }
+        f.zi[i][0] = s.zi[i][0];
+        f.zi[i][1] = s.zi[i][1];
+    }
+    return f;
+}
+
+inline ZpFilterDesc desc_from_tf(const Tf4 &t)
+{
+    ZpFilterDesc f{};
+    f.nsec = 1;
+    f.K = 4;
+    for (int k = 0; k < 5; ++k) { f.b[0][k] = t.b[k]; f.a[0][k] = t.a[k]; }
+    for (int k = 0; k < 4; ++k) f.zi[0][k] = t.zi[k];
+    return f;
+}
+
+inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidth = 25000.0)
+{
+    RefPlanHost h;
+    h.sample_rate = sample_rate;
+    h.n = n;
+    h.q = decimation_factor(sample_rate);
+    h.decimated = (h.q > 1 && n > kEdgeSos);
+    h.rate_dec = h.decimated ? sample_rate / h.q : sample_rate;
+    h.n_dec = h.decimated ? (n + h.q - 1) / h.q : n;
+    h.lpf = h.n_dec > kEdgeTf;
+    h.sps = (int)(h.rate_dec / kSymbolRate);
+    h.phase_step = h.sps / 8 > 1 ? h.sps / 8 : 1;
+    h.max_soft = h.sps > 1 ? h.n_dec / h.sps + 1 : h.n_dec;
+    if (h.max_soft < 1) h.max_soft = 1;
+    if (h.q > 1) h.sos = design_cheby1_8(0.05, 0.8 / h.q);
+    h.tf = design_butter4(butter_cutoff(bandwidth, h.rate_dec));
+    if (h.decimated)
+        h.dec = build_zp_tables(desc_from_sos(h.sos), n, kEdgeSos, kLDec, h.n_dec, h.q);
+    if (h.lpf)
+        h.lpf_t = build_zp_tables(desc_from_tf(h.tf), h.n_dec, kEdgeTf, kLLpf, h.n_dec, 1);
+    return h;
+}
+
+}  // namespace tdm

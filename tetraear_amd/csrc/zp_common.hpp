@@ -1,0 +1,92 @@
+// Shared definitions for the zero-phase IIR block engine (host table builder + device kernels).
+//
+// The engine evaluates scipy's sosfiltfilt / filtfilt (as called by the reference at
+// processor.py:254 via signal.decimate, and processor.py:79) WITHOUT running one long sequential
+// recurrence: the padded, odd-extended signal is cut into blocks of 64 segments x L samples; a
+// 64-lane wavefront filters one block with every lane starting from zero state, and linearity is
+// used twice to restore the exact result:
+//   in-block : per section, a wavefront prefix scan over the lanes' end states (K x K transition
+//              matrices A^(L*2^j)) gives each lane its true start state; the zero-input response
+//              of that state (table csec) is added to the lane's samples;
+//   x-block  : each block exports its end states (forward Ef, backward Eb); a tiny carry kernel
+//              runs the D-dimensional recurrences across blocks (tables Mf, Mb, U) and the
+//              consumer adds the two carry responses (tables T1, T2) to the block-local outputs.
+// In-block nothing is truncated.  Across blocks the carry recurrence is evaluated as a series in
+// Mf = A^(64 L) cut where max|Mf^t| < 1e-30 (or complete, t = nb), far below fp64 rounding, so the
+// result equals the sequential recurrence to rounding for any filter memory and any length.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TDM_HD __host__ __device__ __forceinline__
+#else
+#define TDM_HD inline
+#endif
+
+namespace tdm {
+
+constexpr int kWave = 64;        // lanes per block (one wavefront)
+constexpr int kMaxSec = 4;       // sections per cascade
+constexpr int kMaxOrd = 4;       // order of one section
+constexpr int kMaxD = 8;         // total state dimension
+constexpr int kScanSteps = 6;    // log2(kWave)
+
+// One zero-phase stage over a batch of independent rows (carriers).
+struct ZpParams {
+    // ---- filter: cascade of nsec DF2T sections of order K (a[.][0] == 1)
+    int32_t nsec, K;
+    double b[kMaxSec][kMaxOrd + 1];
+    double a[kMaxSec][kMaxOrd + 1];
+    double zi[kMaxSec][kMaxOrd];  // steady-state start per unit input (sosfilt_zi / lfilter_zi)
+    // ---- geometry (padded extended domain: index = P0 + ext index)
+    int64_t n;         // signal samples per row
+    int32_t edge;      // odd-extension length each side (27 cheby sos, 15 butter tf)
+    int32_t L;         // samples per lane
+    int32_t P0;        // lead pad: (P0 + edge) % L == 0, so signal sample 0 sits on a lane boundary
+    int32_t k0L;       // P0 + edge
+    int64_t Ne;        // P0 + n + 2*edge
+    int32_t nb;        // blocks per row = ceil(Ne / (64 L))
+    int32_t len_last;  // valid length of the last block
+    int64_t n_out;     // outputs per row
+    int32_t out_stride;  // q for the decimator, 1 otherwise
+    int32_t carry_terms; // series length of the cross-block carries (see zp_kernels.hpp)
+    // ---- tables (pointers valid where the kernels run)
+    const double *Mpow;     // [nsec][6][K*K]   A_s^(L*2^j), row-major
+    const double *csec;     // [nsec][L][K]     zero-input response of section s at step i
+    const double *cfull;    // [64L][D]         zero-input response of the whole cascade
+    const double *T1_reg;   // [64L][D]         fwd carry-in -> block-local fwd->bwd output
+    const double *T1_last;  // [len_last][D]
+    double Mf[kMaxD * kMaxD];       // A^(64L)
+    double Mb_last[kMaxD * kMaxD];  // A^(len_last)
+    double U_reg[kMaxD * kMaxD];    // fwd carry-in -> bwd end state of the block
+    double U_last[kMaxD * kMaxD];
+    // ---- per-row work buffers
+    double *y0;     // [rows][n_out] c128, block-local outputs
+    double *Ef;     // [rows][nb][D] c128, block-local forward end states
+    double *Eb;     // [rows][nb][D] c128, block-local backward end states
+    double *flast;  // [rows] c128, block-local forward output at the last extended sample
+    double *Gf;     // [rows][nb][D] c128, resolved forward carry into each block
+    double *Hb;     // [rows][nb][D] c128, resolved backward carry into each block
+};
+
+// One DF2T section step, the operation order of scipy's sosfilt (K == 2,
+// scipy/signal/_sosfilt.pyx) and lfilter (K == 4, scipy/signal/_lfilter.c.in).
+template <int K, typename T>
+TDM_HD T df2t_step(const T *b, const T *a, T x, T *z)
+{
+    if (K == 2) {
+        T y = b[0] * x + z[0];
+        z[0] = (b[1] * x - a[1] * y) + z[1];
+        z[1] = b[2] * x - a[2] * y;
+        return y;
+    } else {
+        T y = z[0] + b[0] * x;
+#pragma unroll
+        for (int k = 1; k < K; ++k) z[k - 1] = (z[k] + b[k] * x) - a[k] * y;
+        z[K - 1] = b[K] * x - a[K] * y;
+        return y;
+    }
+}
+
+}  // namespace tdm

@@ -1,0 +1,600 @@
+// Kernel bodies of the reference-parity path, written once and compiled twice:
+//   * by hipcc for gfx950 (tdm_hip.hip wraps each body in a __global__ kernel; Comm = wavefront
+//     shuffles / LDS reductions), and
+//   * by g++ for the CPU test harness tests/emul (Comm = std::barrier lock-step emulation), so
+//     the index/table logic can be checked against the oracle without a GPU.  The CPU build is
+//     test infrastructure only; the product library has no CPU path.
+//
+// Reference functions restated here (tetraear/signal/processor.py):
+//   zp_block_body / zp_carry_body / zp_fixup_body : scipy sosfiltfilt+[::q] (processor.py:254)
+//                                                    and filtfilt (processor.py:79)
+//   nco_rotate                                     : frequency_shift (processor.py:85-100)
+//   finish_body                                    : extract_symbols (processor.py:168-219) +
+//                                                    demodulate_dqpsk (processor.py:102-166)
+#pragma once
+#include <math.h>
+
+#include "zp_common.hpp"
+
+namespace tdm {
+
+// ------------------------------------------------------------------------------------------
+// exact-rounding helpers (no FMA contraction) for the few places where the reference's own
+// rounding sequence defines the data (cu8 -> float conversion, slicer products)
+// ------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+TDM_HD double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+TDM_HD double add_rn(double a, double b) { return __dadd_rn(a, b); }
+TDM_HD double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+#else
+// host builds of this header use -ffp-contract=off
+TDM_HD double mul_rn(double a, double b) { return a * b; }
+TDM_HD double add_rn(double a, double b) { return a + b; }
+TDM_HD double sub_rn(double a, double b) { return a - b; }
+#endif
+
+#if defined(__HIPCC__)
+#define TDM_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define TDM_NOINLINE __attribute__((noinline))
+#endif
+
+struct alignas(16) u32x4 {
+    uint32_t x, y, z, w;
+};
+struct alignas(16) f64x2 {
+    double x, y;
+};
+
+// frequency_shift (processor.py:98-99): t = n/fs; shift = exp(-1j*2*pi*f*t)
+// Python evaluates ((-1j*2)*pi)*f -> (0, -(2*pi)*f) and multiplies by t[n].
+TDM_NOINLINE void nco_rotate(double &re, double &im, int64_t k, double f, double fs)
+{
+    const double ci = -(2.0 * M_PI) * f;
+    const double t = (double)k / fs;
+    const double th = ci * t;
+    double s, c;
+    sincos(th, &s, &c);
+    const double a = re, b = im;
+    re = a * c - b * s;
+    im = a * s + b * c;
+}
+
+// ------------------------------------------------------------------------------------------
+// Loaders: give a lane its L consecutive samples of the padded, odd-extended signal.
+// ------------------------------------------------------------------------------------------
+enum { FMT_CU8 = 0, FMT_CS8 = 1, FMT_CF32 = 2, FMT_CF64 = 3 };
+
+template <int FMT>
+TDM_HD void convert_one(const void *rowp, int64_t k, double &re, double &im)
+{
+    if (FMT == FMT_CU8) {
+        // pyrtlsdr: iq = bytes.astype(float64).view(complex128); iq /= 127.5; iq -= (1+1j)
+        // numpy's complex/real division multiplies by fl(1/127.5): two roundings, no FMA.
+        const uint8_t *p = (const uint8_t *)rowp + 2 * k;
+        const double c = 1.0 / 127.5;
+        re = sub_rn(mul_rn((double)p[0], c), 1.0);
+        im = sub_rn(mul_rn((double)p[1], c), 1.0);
+    } else if (FMT == FMT_CS8) {
+        const int8_t *p = (const int8_t *)rowp + 2 * k;
+        re = (double)p[0] * (1.0 / 128.0);
+        im = (double)p[1] * (1.0 / 128.0);
+    } else if (FMT == FMT_CF32) {
+        const float *p = (const float *)rowp + 2 * k;
+        re = (double)p[0];
+        im = (double)p[1];
+    } else {
+        const double *p = (const double *)rowp + 2 * k;
+        re = p[0];
+        im = p[1];
+    }
+}
+
+template <int FMT>
+struct RawLoader {
+    const void *iq;            // first sample of row 0
+    int64_t row_stride;        // samples between rows (0 = shared stream)
+    const double *pre_shift;   // per row [Hz] or null
+    double fs;
+
+    static constexpr int kBytes = (FMT == FMT_CU8 || FMT == FMT_CS8) ? 2 : (FMT == FMT_CF32 ? 8 : 16);
+
+    TDM_HD const void *row_ptr(int row) const
+    {
+        return (const char *)iq + (int64_t)row * row_stride * kBytes;
+    }
+    TDM_HD void sample(const void *rowp, int64_t k, double f, double &re, double &im) const
+    {
+        convert_one<FMT>(rowp, k, re, im);
+        if (f != 0.0) nco_rotate(re, im, k, f, fs);
+    }
+
+    template <int L>
+    TDM_HD void fast(const void *rowp, int64_t k, double f, double *xr, double *xi) const
+    {
+        const char *p = (const char *)rowp + k * kBytes;
+        const bool aligned = (((uintptr_t)p) & 15) == 0;
+        if ((FMT == FMT_CU8 || FMT == FMT_CS8) && aligned) {
+            const u32x4 *v = (const u32x4 *)p;
+#pragma unroll
+            for (int c = 0; c < L / 8; ++c) {
+                const u32x4 w = v[c];
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t s = ww[d] >> (16 * h);
+                        const int idx = c * 8 + d * 2 + h;
+                        if (FMT == FMT_CU8) {
+                            const double cc = 1.0 / 127.5;
+                            xr[idx] = sub_rn(mul_rn((double)(s & 255u), cc), 1.0);
+                            xi[idx] = sub_rn(mul_rn((double)((s >> 8) & 255u), cc), 1.0);
+                        } else {
+                            xr[idx] = (double)(int8_t)(s & 255u) * (1.0 / 128.0);
+                            xi[idx] = (double)(int8_t)((s >> 8) & 255u) * (1.0 / 128.0);
+                        }
+                    }
+            }
+        } else if (FMT == FMT_CF64 && aligned) {
+            const f64x2 *v = (const f64x2 *)p;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const f64x2 w = v[i];
+                xr[i] = w.x;
+                xi[i] = w.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < L; ++i) convert_one<FMT>(rowp, k + i, xr[i], xi[i]);
+        }
+        if (f != 0.0) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) nco_rotate(xr[i], xi[i], k + i, f, fs);
+        }
+    }
+
+    // x[i] = padded-ext sample seg+i (zero outside [P0, Ne))
+    template <int L>
+    TDM_HD void load(int row, int64_t seg, const ZpParams *P, double *xr, double *xi) const
+    {
+        const void *rowp = row_ptr(row);
+        const double f = pre_shift ? pre_shift[row] : 0.0;
+        const int64_t n = P->n;
+        const int edge = P->edge;
+        const int64_t e0 = seg - P->P0;  // ext index of x[0]
+        if (e0 >= edge && e0 + L <= edge + n) {
+            fast<L>(rowp, e0 - edge, f, xr, xi);
+            return;
+        }
+        double x0r = 0, x0i = 0, x1r = 0, x1i = 0;
+        if (n > 0) {
+            sample(rowp, 0, f, x0r, x0i);
+            sample(rowp, n - 1, f, x1r, x1i);
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int64_t e = e0 + i;
+            double re = 0, im = 0;
+            if (e >= 0 && e < n + 2 * (int64_t)edge) {
+                if (e < edge) {  // 2*x[0] - x[edge - e]
+                    sample(rowp, edge - e, f, re, im);
+                    re = 2 * x0r - re;
+                    im = 2 * x0i - im;
+                } else if (e < edge + n) {
+                    sample(rowp, e - edge, f, re, im);
+                } else {  // 2*x[n-1] - x[n-2-(e-edge-n)]
+                    sample(rowp, n - 2 - (e - edge - n), f, re, im);
+                    re = 2 * x1r - re;
+                    im = 2 * x1i - im;
+                }
+            }
+            xr[i] = re;
+            xi[i] = im;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Block kernel body: one wavefront filters one block forward then backward.
+//   Comm: shfl_up2<K>(a, b, outa, outb, d) / shfl_down2<K>: out[lane] = in[lane -/+ d] for two
+//   K-vectors of doubles across the 64 lanes (own value where the source lane does not exist).
+// ------------------------------------------------------------------------------------------
+template <int K, int NSEC, int L, int EDGE, class Loader, class Comm>
+TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm &cm, int lane, int blk,
+                          int row)
+{
+    constexpr int D = K * NSEC;
+    constexpr int Bn = kWave * L;
+    double xr[L], xi[L];
+    const int64_t seg = (int64_t)blk * Bn + (int64_t)lane * L;
+    ld.template load<L>(row, seg, P, xr, xi);
+
+    constexpr int P0 = (L - EDGE % L) % L;  // == P->P0
+    const bool inject = (blk == 0 && lane == 0);
+    const double e0r = xr[P0], e0i = xi[P0];
+
+    const int64_t nbD = (int64_t)P->nb * D;
+    double *Ef = P->Ef + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
+    double *Eb = P->Eb + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
+
+    // ---------------- forward: sections in cascade order ----------------
+#pragma unroll
+    for (int s = 0; s < NSEC; ++s) {
+        double b[K + 1], a[K + 1];
+#pragma unroll
+        for (int k = 0; k <= K; ++k) { b[k] = P->b[s][k]; a[k] = P->a[s][k]; }
+        double zr[K], zq[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { zr[k] = 0; zq[k] = 0; }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            if (i == P0 && inject) {  // scipy: zi * ext[0] is the state before the first sample
+#pragma unroll
+                for (int k = 0; k < K; ++k) { zr[k] = P->zi[s][k] * e0r; zq[k] = P->zi[s][k] * e0i; }
+            }
+            xr[i] = df2t_step<K, double>(b, a, xr[i], zr);
+            xi[i] = df2t_step<K, double>(b, a, xi[i], zq);
+        }
+        // inclusive scan of end states: I_p = sum_{j<=p} M^(p-j) e_j
+#pragma unroll
+        for (int j = 0; j < kScanSteps; ++j) {
+            const int d = 1 << j;
+            const double *M = P->Mpow + ((size_t)s * kScanSteps + j) * K * K;
+            double jr[K], jq[K];
+            cm.template shfl_up2<K>(zr, zq, jr, jq, d);
+            if (lane >= d) {
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    double ar = zr[r], aq = zq[r];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { ar += M[r * K + k] * jr[k]; aq += M[r * K + k] * jq[k]; }
+                    zr[r] = ar;
+                    zq[r] = aq;
+                }
+            }
+        }
+        if (lane == kWave - 1) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) { Ef[(s * K + k) * 2] = zr[k]; Ef[(s * K + k) * 2 + 1] = zq[k]; }
+        }
+        // start state of this lane = inclusive value of lane-1
+        double sr[K], sq[K];
+        cm.template shfl_up2<K>(zr, zq, sr, sq, 1);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (lane == 0) { sr[k] = 0; sq[k] = 0; }
+        const double *cs = P->csec + (size_t)s * L * K;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            double ar = xr[i], aq = xi[i];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { ar += cs[i * K + k] * sr[k]; aq += cs[i * K + k] * sq[k]; }
+            xr[i] = ar;
+            xi[i] = aq;
+        }
+    }
+    // positions past the end of the extended signal must not feed the backward pass
+    if (blk == P->nb - 1) {
+        const int64_t last = P->Ne - 1;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int64_t g = seg + i;
+            if (g == last) { P->flast[(int64_t)row * 2] = xr[i]; P->flast[(int64_t)row * 2 + 1] = xi[i]; }
+            if (g > last) { xr[i] = 0; xi[i] = 0; }
+        }
+    }
+    // ---------------- backward: same cascade, time reversed ----------------
+#pragma unroll
+    for (int s = 0; s < NSEC; ++s) {
+        double b[K + 1], a[K + 1];
+#pragma unroll
+        for (int k = 0; k <= K; ++k) { b[k] = P->b[s][k]; a[k] = P->a[s][k]; }
+        double zr[K], zq[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { zr[k] = 0; zq[k] = 0; }
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            xr[i] = df2t_step<K, double>(b, a, xr[i], zr);
+            xi[i] = df2t_step<K, double>(b, a, xi[i], zq);
+        }
+#pragma unroll
+        for (int j = 0; j < kScanSteps; ++j) {
+            const int d = 1 << j;
+            const double *M = P->Mpow + ((size_t)s * kScanSteps + j) * K * K;
+            double jr[K], jq[K];
+            cm.template shfl_down2<K>(zr, zq, jr, jq, d);
+            if (lane + d < kWave) {
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    double ar = zr[r], aq = zq[r];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { ar += M[r * K + k] * jr[k]; aq += M[r * K + k] * jq[k]; }
+                    zr[r] = ar;
+                    zq[r] = aq;
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) { Eb[(s * K + k) * 2] = zr[k]; Eb[(s * K + k) * 2 + 1] = zq[k]; }
+        }
+        double sr[K], sq[K];
+        cm.template shfl_down2<K>(zr, zq, sr, sq, 1);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (lane == kWave - 1) { sr[k] = 0; sq[k] = 0; }
+        const double *cs = P->csec + (size_t)s * L * K;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            double ar = xr[i], aq = xi[i];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                ar += cs[(L - 1 - i) * K + k] * sr[k];
+                aq += cs[(L - 1 - i) * K + k] * sq[k];
+            }
+            xr[i] = ar;
+            xi[i] = aq;
+        }
+    }
+    // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------
+    {
+        const int64_t rel0 = seg - P->k0L;
+        const int q = P->out_stride;
+        int64_t j = rel0 <= 0 ? 0 : (rel0 + q - 1) / q;
+        int64_t next = j * q - rel0;  // position inside this segment
+        double *y0 = P->y0 + (int64_t)row * P->n_out * 2;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            if (i == next) {
+                if (j < P->n_out) { y0[j * 2] = xr[i]; y0[j * 2 + 1] = xi[i]; }
+                ++j;
+                next += q;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Carry bodies.  The true state entering block b is the D-dimensional recurrence
+//     Gf[b] = Mf Gf[b-1] + Ef[b-1],                      Gf[0] = 0 (the start state zi*ext[0]
+//                                                         is injected inside block 0 itself)
+//     Hb[b-1] = Mb(b) Hb[b] + Eb[b] + U(b) Gf[b],        Hb[nb-1] = zi * f[last]
+// (scipy sosfiltfilt `zi * y_0`, _signaltools.py:4823-4824).  Mf = A^(64 L) is a contraction, so
+// each carry is evaluated independently per block as the Horner form of its series, cut after
+// P->carry_terms terms; the host picks carry_terms so that max|Mf^terms| < 1e-24 (or = nb, in
+// which case the series is complete).  One thread per (row, block, component).
+// ------------------------------------------------------------------------------------------
+template <int D>
+TDM_HD void matvec_acc(const double *M, const double *v, double *out)
+{
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        double a = out[r];
+#pragma unroll
+        for (int k = 0; k < D; ++k) a += M[r * D + k] * v[k];
+        out[r] = a;
+    }
+}
+
+template <int K, int NSEC>
+TDM_HD void zp_carry_fwd_body(const ZpParams *__restrict__ P, int row, int b, int ch)
+{
+    constexpr int D = K * NSEC;
+    const int nb = P->nb;
+    const int64_t base = (int64_t)row * nb * D * 2 + ch;
+    const double *Ef = P->Ef + base;
+    double *Gf = P->Gf + base;
+    double G[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) G[k] = 0;
+    int first = b - P->carry_terms;
+    if (first < 0) first = 0;
+    for (int bb = first; bb < b; ++bb) {  // G <- Mf G + Ef[bb]
+        double Gn[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) Gn[k] = Ef[((int64_t)bb * D + k) * 2];
+        matvec_acc<D>(P->Mf, G, Gn);
+#pragma unroll
+        for (int k = 0; k < D; ++k) G[k] = Gn[k];
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) Gf[((int64_t)b * D + k) * 2] = G[k];
+    if (b == nb - 1) {
+        // true forward output at the last extended sample -> start state of the backward pass
+        double fl = P->flast[(int64_t)row * 2 + ch];
+        const double *c = P->cfull + (size_t)(P->len_last - 1) * D;
+#pragma unroll
+        for (int k = 0; k < D; ++k) fl += c[k] * G[k];
+        double *Hb = P->Hb + base;
+#pragma unroll
+        for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) Hb[((int64_t)b * D + s * K + k) * 2] = P->zi[s][k] * fl;
+    }
+}
+
+// for b < nb-1 (Hb[nb-1] was written by zp_carry_fwd_body)
+template <int K, int NSEC>
+TDM_HD void zp_carry_bwd_body(const ZpParams *__restrict__ P, int row, int b, int ch)
+{
+    constexpr int D = K * NSEC;
+    const int nb = P->nb;
+    if (b >= nb - 1) return;
+    const int64_t base = (int64_t)row * nb * D * 2 + ch;
+    const double *Eb = P->Eb + base;
+    const double *Gf = P->Gf + base;
+    double *Hb = P->Hb + base;
+    double H[D];
+    int far = b + P->carry_terms;  // farthest block whose contribution is kept
+    if (far >= nb - 1) {
+        far = nb - 1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) H[k] = Hb[((int64_t)(nb - 1) * D + k) * 2];
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) H[k] = 0;
+    }
+    for (int bb = far; bb > b; --bb) {  // H <- Mb(bb) H + Eb[bb] + U(bb) Gf[bb]
+        const bool last = (bb == nb - 1);
+        double Hn[D], Gb[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            Hn[k] = Eb[((int64_t)bb * D + k) * 2];
+            Gb[k] = Gf[((int64_t)bb * D + k) * 2];
+        }
+        matvec_acc<D>(last ? P->Mb_last : P->Mf, H, Hn);
+        matvec_acc<D>(last ? P->U_last : P->U_reg, Gb, Hn);
+#pragma unroll
+        for (int k = 0; k < D; ++k) H[k] = Hn[k];
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) Hb[((int64_t)b * D + k) * 2] = H[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// Fix-up body: out[j] = y0[j] + T1[m].Gf_b + T2[m].Hb_b, then (optionally) process()'s
+// freq_offset NCO at the output rate (processor.py:260-261).  One thread per output sample.
+// ------------------------------------------------------------------------------------------
+template <int D>
+TDM_HD void zp_fixup_body(const ZpParams *__restrict__ P, int row, int64_t j, double *out /* row base */,
+                          const double *freq_offset /* per row or null */, double fs_out)
+{
+    const int Bn = kWave * P->L;
+    const int64_t pos = P->k0L + j * P->out_stride;
+    const int b = (int)(pos / Bn);
+    const int m = (int)(pos - (int64_t)b * Bn);
+    const bool last = (b == P->nb - 1);
+    const int len = last ? P->len_last : Bn;
+    const double *T1 = (last ? P->T1_last : P->T1_reg) + (size_t)m * D;
+    const double *T2 = P->cfull + (size_t)(len - 1 - m) * D;
+    const int64_t cb = ((int64_t)row * P->nb + b) * D * 2;
+    const double *Gf = P->Gf + cb;
+    const double *Hb = P->Hb + cb;
+    const double *y0 = P->y0 + ((int64_t)row * P->n_out + j) * 2;
+    double re = y0[0], im = y0[1];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        re += T1[k] * Gf[k * 2] + T2[k] * Hb[k * 2];
+        im += T1[k] * Gf[k * 2 + 1] + T2[k] * Hb[k * 2 + 1];
+    }
+    if (freq_offset) {
+        const double f = freq_offset[row];
+        if (f != 0.0) nco_rotate(re, im, j, f, fs_out);
+    }
+    out[j * 2] = re;
+    out[j * 2 + 1] = im;
+}
+
+// ------------------------------------------------------------------------------------------
+// Finish body: timing-phase pick + symbol gather (extract_symbols) and the differential slicer
+// (demodulate_dqpsk).  One workgroup per row.
+//   Comm: tid(), nthreads(), sync(), reduce_sum/max/min(double) -> value on every thread.
+// ------------------------------------------------------------------------------------------
+struct FinishArgs {
+    const double *z;      // [rows][n] c128 input at rate fs
+    int64_t n;
+    int64_t row_stride;   // samples between rows
+    int32_t sps;          // int(fs / symbol_rate)
+    int32_t do_extract;   // 0: the input already is the symbol stream
+    int32_t do_demod;     // 0: stop after the gather
+    int32_t max_soft;     // capacity per row of soft / hard
+    double *soft;         // [rows][max_soft] c128
+    uint8_t *hard;        // [rows][max_soft]
+    int32_t *n_soft;      // [rows]
+    int32_t *best_phase;  // [rows] or null
+    double *min_margin;   // [rows] or null
+};
+
+TDM_HD uint8_t dqpsk_decide(double cr, double ci, double pr, double pi_, double &margin)
+{
+    // diff = sample * conj(prev), numpy scalar complex product: two roundings per component
+    const double br = pr, bi = -pi_;
+    const double dr = sub_rn(mul_rn(cr, br), mul_rn(ci, bi));
+    const double di = add_rn(mul_rn(cr, bi), mul_rn(ci, br));
+    const double ph = atan2(di, dr);
+    const double t0 = -5 * M_PI / 8, t1 = -3 * M_PI / 8, t2 = 3 * M_PI / 8, t3 = 5 * M_PI / 8;
+    uint8_t sym;
+    if (ph < t0) sym = 3;
+    else if (ph < t1) sym = 2;
+    else if (ph < t2) sym = 0;
+    else if (ph < t3) sym = 1;
+    else sym = 3;
+    double m = fabs(ph - t0);
+    m = fmin(m, fabs(ph - t1));
+    m = fmin(m, fabs(ph - t2));
+    m = fmin(m, fabs(ph - t3));
+    margin = m;
+    return sym;
+}
+
+template <class Comm>
+TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
+{
+    const int tid = cm.tid(), nt = cm.nthreads();
+    const double *z = A.z + (int64_t)row * A.row_stride * 2;
+    double *soft = A.soft + (int64_t)row * A.max_soft * 2;
+    uint8_t *hard = A.hard ? A.hard + (int64_t)row * A.max_soft : nullptr;
+    const int64_t n = A.n;
+    int64_t best = 0;
+    int64_t ns = n;
+    const int64_t sps = A.sps;
+    if (A.do_extract && n > 0 && sps > 1) {
+        const int64_t step = sps / 8 > 1 ? sps / 8 : 1;
+        double maxp = -1.0;
+        for (int64_t ph = 0; ph < sps; ph += step) {
+            const int64_t np_ = (n - ph) / sps;
+            if (n - ph <= 0 || np_ <= 0) continue;
+            double acc = 0;
+            for (int64_t k = tid; k < np_; k += nt) {
+                const double *s = z + (ph + k * sps) * 2;
+                const double m = hypot(s[0], s[1]);
+                acc += m * m;
+            }
+            const double power = cm.reduce_sum(acc) / (double)np_;
+            if (power > maxp) { maxp = power; best = ph; }  // identical on every thread
+        }
+        ns = (n - best) / sps;
+    }
+    if (ns > A.max_soft) ns = A.max_soft;
+    if (ns < 0) ns = 0;
+    const int64_t stride = (A.do_extract && sps > 1) ? sps : 1;
+    double mx = 0;
+    for (int64_t k = tid; k < ns; k += nt) {
+        const double *s = z + (best + k * stride) * 2;
+        soft[k * 2] = s[0];
+        soft[k * 2 + 1] = s[1];
+        mx = fmax(mx, hypot(s[0], s[1]));
+    }
+    if (tid == 0) {
+        A.n_soft[row] = (int32_t)ns;
+        if (A.best_phase) A.best_phase[row] = (int32_t)best;
+    }
+    if (!A.do_demod) return;
+    mx = cm.reduce_max(mx);
+    double margin = INFINITY;
+    if (ns >= 2) {
+        const double scl = mx > 0 ? 1.0 / mx : 1.0;  // samples / max_power == samples * fl(1/max)
+        for (int64_t k = 1 + tid; k < ns; k += nt) {
+            const double *c = z + (best + k * stride) * 2;
+            const double *p = z + (best + (k - 1) * stride) * 2;
+            double mg;
+            hard[k - 1] = dqpsk_decide(mul_rn(c[0], scl), mul_rn(c[1], scl), mul_rn(p[0], scl),
+                                       mul_rn(p[1], scl), mg);
+            margin = fmin(margin, mg);
+        }
+    }
+    margin = cm.reduce_min(margin);
+    if (tid == 0 && A.min_margin) A.min_margin[row] = margin;
+}
+
+// frequency_shift as a stand-alone elementwise op (public method, processor.py:85-100)
+TDM_HD void shift_body(const double *x, double *y, int64_t k, double f, double fs)
+{
+    double re = x[k * 2], im = x[k * 2 + 1];
+    nco_rotate(re, im, k, f, fs);  // the reference multiplies even when f == 0 (exp(0) == 1)
+    y[k * 2] = re;
+    y[k * 2 + 1] = im;
+}
+
+}  // namespace tdm

@@ -1,0 +1,152 @@
+// Host-side construction of the linear-response tables the block engine needs (zp_common.hpp).
+// Every table is obtained by simulating the same DF2T recurrences on unit states in long double
+// and rounding once to double.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "zp_common.hpp"
+
+namespace tdm {
+
+struct ZpFilterDesc {
+    int nsec, K;
+    double b[kMaxSec][kMaxOrd + 1];
+    double a[kMaxSec][kMaxOrd + 1];
+    double zi[kMaxSec][kMaxOrd];
+};
+
+struct ZpHostTables {
+    ZpParams p;                // table/work pointers are null until patched by the owner
+    std::vector<double> blob;  // all tables, concatenated
+    size_t off_Mpow, off_csec, off_cfull, off_T1reg, off_T1last;
+};
+
+namespace detail {
+template <int K>
+inline long double cascade_step(const ZpFilterDesc &f, long double x, long double *Z)
+{
+    long double y = x;
+    for (int s = 0; s < f.nsec; ++s) {
+        long double b[kMaxOrd + 1], a[kMaxOrd + 1];
+        for (int k = 0; k <= K; ++k) { b[k] = f.b[s][k]; a[k] = f.a[s][k]; }
+        y = df2t_step<K, long double>(b, a, y, Z + s * K);
+    }
+    return y;
+}
+
+template <int K>
+inline void build(const ZpFilterDesc &f, ZpHostTables &t)
+{
+    ZpParams &p = t.p;
+    const int L = p.L, Bn = kWave * L, D = f.nsec * K;
+    const int len_last = p.len_last;
+    std::vector<double> &blob = t.blob;
+    auto reserve = [&](size_t n) { size_t o = blob.size(); blob.resize(o + n, 0.0); return o; };
+    t.off_Mpow = reserve((size_t)f.nsec * kScanSteps * K * K);
+    t.off_csec = reserve((size_t)f.nsec * L * K);
+    t.off_cfull = reserve((size_t)Bn * D);
+    t.off_T1reg = reserve((size_t)Bn * D);
+    t.off_T1last = reserve((size_t)len_last * D);
+
+    // ---- per-section tables: csec[s][i][k], Mpow[s][j] = A_s^(L*2^j)
+    for (int s = 0; s < f.nsec; ++s) {
+        long double b[kMaxOrd + 1], a[kMaxOrd + 1];
+        for (int k = 0; k <= K; ++k) { b[k] = f.b[s][k]; a[k] = f.a[s][k]; }
+        for (int k = 0; k < K; ++k) {
+            long double z[kMaxOrd] = {0, 0, 0, 0};
+            z[k] = 1.0L;
+            int step = 0;
+            for (int j = 0; j < kScanSteps; ++j) {
+                const int target = L << j;
+                for (; step < target; ++step) {
+                    long double y = df2t_step<K, long double>(b, a, 0.0L, z);
+                    if (step < L) blob[t.off_csec + ((size_t)s * L + step) * K + k] = (double)y;
+                }
+                for (int r = 0; r < K; ++r)
+                    blob[t.off_Mpow + (((size_t)s * kScanSteps + j) * K + r) * K + k] = (double)z[r];
+            }
+        }
+    }
+    // ---- whole-cascade tables
+    std::vector<long double> zir((size_t)Bn);
+    for (int k = 0; k < D; ++k) {
+        long double Z[kMaxD] = {0};
+        Z[k] = 1.0L;
+        for (int i = 0; i < Bn; ++i) {
+            long double y = cascade_step<K>(f, 0.0L, Z);
+            zir[i] = y;
+            blob[t.off_cfull + (size_t)i * D + k] = (double)y;
+            if (i + 1 == len_last)
+                for (int r = 0; r < D; ++r) p.Mb_last[r * D + k] = (double)Z[r];
+        }
+        for (int r = 0; r < D; ++r) p.Mf[r * D + k] = (double)Z[r];
+        // backward run over the forward zero-input response, regular and last-block lengths
+        for (int v = 0; v < 2; ++v) {
+            const int len = v ? len_last : Bn;
+            long double W[kMaxD] = {0};
+            const size_t off = v ? t.off_T1last : t.off_T1reg;
+            for (int i = len - 1; i >= 0; --i) {
+                long double y = cascade_step<K>(f, zir[i], W);
+                blob[off + (size_t)i * D + k] = (double)y;
+            }
+            double *U = v ? p.U_last : p.U_reg;
+            for (int r = 0; r < D; ++r) U[r * D + k] = (double)W[r];
+        }
+    }
+}
+}  // namespace detail
+
+// n: signal length per row; edge: odd-extension length; L: samples per lane;
+// n_out/out_stride: outputs are padded-ext positions k0L + j*out_stride, j < n_out.
+inline ZpHostTables build_zp_tables(const ZpFilterDesc &f, int64_t n, int edge, int L, int64_t n_out,
+                                    int out_stride)
+{
+    ZpHostTables t;
+    std::memset(&t.p, 0, sizeof(t.p));
+    ZpParams &p = t.p;
+    p.nsec = f.nsec;
+    p.K = f.K;
+    std::memcpy(p.b, f.b, sizeof(p.b));
+    std::memcpy(p.a, f.a, sizeof(p.a));
+    std::memcpy(p.zi, f.zi, sizeof(p.zi));
+    p.n = n;
+    p.edge = edge;
+    p.L = L;
+    p.P0 = (L - edge % L) % L;
+    p.k0L = p.P0 + edge;
+    p.Ne = p.P0 + n + 2 * (int64_t)edge;
+    const int64_t Bn = (int64_t)kWave * L;
+    p.nb = (int32_t)((p.Ne + Bn - 1) / Bn);
+    p.len_last = (int32_t)(p.Ne - (int64_t)(p.nb - 1) * Bn);
+    p.n_out = n_out;
+    p.out_stride = out_stride;
+    if (f.K == 2)
+        detail::build<2>(f, t);
+    else
+        detail::build<4>(f, t);
+    // carry series length: smallest t with max|Mf^t| < 1e-30, capped at nb (complete series)
+    {
+        const int D = f.nsec * f.K;
+        std::vector<long double> Pw((size_t)D * D), Nx((size_t)D * D);
+        for (int i = 0; i < D * D; ++i) Pw[i] = p.Mf[i];
+        int terms = 1;
+        for (; terms < p.nb; ++terms) {
+            long double mx = 0;
+            for (int i = 0; i < D * D; ++i) mx = std::fmax(mx, std::fabs(Pw[i]));
+            if (mx < 1e-30L) break;
+            for (int r = 0; r < D; ++r)
+                for (int c = 0; c < D; ++c) {
+                    long double acc = 0;
+                    for (int k = 0; k < D; ++k) acc += Pw[r * D + k] * (long double)p.Mf[k * D + c];
+                    Nx[r * D + c] = acc;
+                }
+            Pw = Nx;
+        }
+        p.carry_terms = terms;
+    }
+    return t;
+}
+
+}  // namespace tdm
