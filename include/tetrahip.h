@@ -29,6 +29,12 @@ extern "C" {
 
 #define TDM_VERSION 100 /* 0.1.0 */
 
+#if defined(__GNUC__)
+#define TDM_API __attribute__((visibility("default")))
+#else
+#define TDM_API
+#endif
+
 typedef enum tdm_status {
     TDM_OK = 0,
     TDM_ERR_INVALID = -1,    /* bad argument */
@@ -73,19 +79,19 @@ typedef struct tdm_plan_info {
 } tdm_plan_info;
 
 /* ---- library ---------------------------------------------------------------------------- */
-int tdm_version(void);
+TDM_API int tdm_version(void);
 /* number of HIP devices, or a negative tdm_status */
-int tdm_device_count(void);
+TDM_API int tdm_device_count(void);
 /* copies the calling thread's last error text (NUL-terminated) into buf; returns its length */
-int tdm_last_error(char *buf, size_t buflen);
+TDM_API int tdm_last_error(char *buf, size_t buflen);
 
 /* ---- plan: one (sample_rate, n_samples, n_carriers, format) configuration ----------------
  * replaces SignalProcessor.__init__ (processor.py:21-33) + the per-call filter design
  * (processor.py:78, :254).  n_carriers independent streams are processed per call.         */
-int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, int32_t in_fmt,
+TDM_API int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, int32_t in_fmt,
                     int32_t mode, int32_t device, tdm_plan **out);
-int tdm_plan_destroy(tdm_plan *plan);
-int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
+TDM_API int tdm_plan_destroy(tdm_plan *plan);
+TDM_API int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
 
 /* ---- SignalProcessor.process (processor.py:221-273), batched over carriers ----------------
  *  iq            [n_carriers] streams of n_samples in the plan's format; carrier c starts at
@@ -101,54 +107,54 @@ int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
  * tdm_process:        all pointers are HOST memory; blocking.
  * tdm_process_device: all pointers are DEVICE memory (pre_shift/freq_offset too); enqueues on
  *                     `stream` (a hipStream_t, NULL = default) and returns; tdm_plan_sync waits. */
-int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples,
+TDM_API int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples,
                 const double *pre_shift_hz, const double *freq_offset_hz, uint8_t *hard, double *soft,
                 int32_t *n_soft, int32_t *best_phase, double *min_margin);
-int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples,
+TDM_API int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples,
                        const double *pre_shift_hz, const double *freq_offset_hz, uint8_t *hard,
                        double *soft, int32_t *n_soft, int32_t *best_phase, double *min_margin,
                        void *stream);
-int tdm_plan_sync(tdm_plan *plan);
+TDM_API int tdm_plan_sync(tdm_plan *plan);
 
 /* ---- the other public methods of SignalProcessor, one call each (host pointers, blocking) ---
  * All take/return c128 host arrays.                                                          */
 /* filter_signal (processor.py:51-83). *applied = 0 when the reference's except-branch would
  * return the input unchanged (n <= 15). */
-int tdm_filter_signal(const double *x, int64_t n, double bandwidth, double fs, double *y,
+TDM_API int tdm_filter_signal(const double *x, int64_t n, double bandwidth, double fs, double *y,
                       int32_t *applied, int32_t device);
 /* frequency_shift (processor.py:85-100) */
-int tdm_frequency_shift(const double *x, int64_t n, double freq_offset, double fs, double *y,
+TDM_API int tdm_frequency_shift(const double *x, int64_t n, double freq_offset, double fs, double *y,
                         int32_t device);
 /* extract_symbols (processor.py:168-219): y has room for n samples */
-int tdm_extract_symbols(const double *x, int64_t n, double fs, double symbol_rate, double *y,
+TDM_API int tdm_extract_symbols(const double *x, int64_t n, double fs, double symbol_rate, double *y,
                         int64_t *n_out, int32_t *best_phase, int32_t device);
 /* demodulate_dqpsk (processor.py:102-166): out has room for n-1 symbols */
-int tdm_demodulate_dqpsk(const double *x, int64_t n, uint8_t *out, int64_t *n_out, double *min_margin,
+TDM_API int tdm_demodulate_dqpsk(const double *x, int64_t n, uint8_t *out, int64_t *n_out, double *min_margin,
                          int32_t device);
 /* scipy.signal.decimate(x, q) as called at processor.py:254 (y has room for ceil(n/q));
  * returns TDM_ERR_INVALID when n <= 27 (scipy raises there). */
-int tdm_decimate(const double *x, int64_t n, int32_t q, double *y, int64_t *n_out, int32_t device);
+TDM_API int tdm_decimate(const double *x, int64_t n, int32_t q, double *y, int64_t *n_out, int32_t device);
 /* resample (processor.py:35-49): scipy.signal.resample (FFT method) to `num` points */
-int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t device);
+TDM_API int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t device);
 
 /* ---- device memory helpers for callers without a HIP binding (bench, tests) ---------------- */
-int tdm_dev_alloc(int32_t device, size_t bytes, void **ptr);
-int tdm_dev_free(int32_t device, void *ptr);
-int tdm_dev_upload(int32_t device, void *dst_dev, const void *src_host, size_t bytes);
-int tdm_dev_download(int32_t device, void *dst_host, const void *src_dev, size_t bytes);
-int tdm_dev_sync(int32_t device);
+TDM_API int tdm_dev_alloc(int32_t device, size_t bytes, void **ptr);
+TDM_API int tdm_dev_free(int32_t device, void *ptr);
+TDM_API int tdm_dev_upload(int32_t device, void *dst_dev, const void *src_host, size_t bytes);
+TDM_API int tdm_dev_download(int32_t device, void *dst_host, const void *src_dev, size_t bytes);
+TDM_API int tdm_dev_sync(int32_t device);
 /* event timing on the library's own stream for a plan: elapsed milliseconds between two marks */
-int tdm_plan_time_begin(tdm_plan *plan);
-int tdm_plan_time_end(tdm_plan *plan, float *elapsed_ms);
+TDM_API int tdm_plan_time_begin(tdm_plan *plan);
+TDM_API int tdm_plan_time_end(tdm_plan *plan, float *elapsed_ms);
 /* per-stage kernel time (ms) accumulated between time_begin/time_end; names[i] static strings */
-int tdm_plan_stage_times(tdm_plan *plan, int32_t max_stages, const char **names, float *ms,
+TDM_API int tdm_plan_stage_times(tdm_plan *plan, int32_t max_stages, const char **names, float *ms,
                          int32_t *n_stages);
 
 /* ---- introspection used by the CPU tests (no device needed) -------------------------------- */
 /* filter design the plan would use: sos[4][6], soszi[4][2] (zeros if q == 1), b[5], a[5], zi[4] */
-int tdm_design_dump(double sample_rate, int64_t n_samples, double *sos, double *soszi, double *b,
+TDM_API int tdm_design_dump(double sample_rate, int64_t n_samples, double *sos, double *soszi, double *b,
                     double *a, double *zi, int32_t *q, double *rate_dec);
-int tdm_design_butter(double bandwidth, double fs, double *b, double *a, double *zi);
+TDM_API int tdm_design_butter(double bandwidth, double fs, double *b, double *a, double *zi);
 
 #ifdef __cplusplus
 }

@@ -79,7 +79,7 @@ void run_group(int nt, F fn)
 
 struct EmuBackend {
     template <int K, int NSEC, int L, int EDGE, class Loader>
-    void zp_block(const ZpParams *P, Loader ld, int nb, int rows)
+    void zp_block(const ZpParams &P, Loader ld, int nb, int rows)
     {
         for (int row = 0; row < rows; ++row)
             for (int b = 0; b < nb; ++b)
@@ -89,7 +89,7 @@ struct EmuBackend {
                 });
     }
     template <int K, int NSEC>
-    void zp_carry(const ZpParams *P, int nb, int rows)
+    void zp_carry(const ZpParams &P, int nb, int rows)
     {
         for (int row = 0; row < rows; ++row)
             for (int b = 0; b < nb; ++b)
@@ -99,18 +99,18 @@ struct EmuBackend {
                 for (int ch = 0; ch < 2; ++ch) zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
     }
     template <int D>
-    void zp_fixup(const ZpParams *P, int rows, int64_t n_out, double *out, int64_t out_row_stride,
+    void zp_fixup(const ZpParams &P, int rows, int64_t n_out, double *out, int64_t out_row_stride,
                   const double *freq_offset, double fs_out)
     {
         for (int row = 0; row < rows; ++row)
             for (int64_t j = 0; j < n_out; ++j)
                 zp_fixup_body<D>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
     }
-    template <int FMT>
-    void convert(RawLoader<FMT> ld, int rows, int64_t n, double *out, const double *freq_offset, double fs)
+    template <class Loader>
+    void convert(Loader ld, int rows, int64_t n, double *out, const double *freq_offset, double fs)
     {
         for (int row = 0; row < rows; ++row)
-            for (int64_t j = 0; j < n; ++j) convert_body<FMT>(ld, row, j, out + (int64_t)row * n * 2, freq_offset, fs);
+            for (int64_t j = 0; j < n; ++j) convert_body(ld, row, j, out + (int64_t)row * n * 2, freq_offset, fs);
     }
     void finish(const FinishArgs &fa, int rows)
     {
@@ -129,11 +129,7 @@ struct HostZp {
     {
         ZpParams &p = t.p;
         const int D = p.nsec * p.K;
-        p.Mpow = t.blob.data() + t.off_Mpow;
-        p.csec = t.blob.data() + t.off_csec;
-        p.cfull = t.blob.data() + t.off_cfull;
-        p.T1_reg = t.blob.data() + t.off_T1reg;
-        p.T1_last = t.blob.data() + t.off_T1last;
+        t.bind(p, t.blob.data());
         const double nan = std::numeric_limits<double>::quiet_NaN();
         y0.assign((size_t)rows * p.n_out * 2 + 2, nan);
         Ef.assign((size_t)rows * p.nb * D * 2, nan);
@@ -160,8 +156,8 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
     if (!iq) return 0;  // query only
     HostZp dec, lpf;
     RefBuffers B;
-    if (h.decimated) { dec.t = h.dec; dec.bind(rows); B.dec_params = &dec.t.p; }
-    if (h.lpf) { lpf.t = h.lpf_t; lpf.bind(rows); B.lpf_params = &lpf.t.p; }
+    if (h.decimated) { dec.t = h.dec; dec.bind(rows); B.dec_params = dec.t.p; }
+    if (h.lpf) { lpf.t = h.lpf_t; lpf.bind(rows); B.lpf_params = lpf.t.p; }
     const double nan = std::numeric_limits<double>::quiet_NaN();
     std::vector<double> y((size_t)rows * h.n_dec * 2 + 2, nan), z((size_t)rows * h.n_dec * 2 + 2, nan);
     B.y = y.data();
@@ -177,24 +173,24 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
 {
     EmuBackend be;
     HostZp hz;
-    RawLoader<FMT_CF64> ld{x, n, nullptr, fs};
+    RawLoader<FMT_CF64, false> ld{x, n, nullptr, fs};
     if (kind == 0) {
         if (n <= kEdgeSos) return -1;
         Sos4 s = design_cheby1_8(0.05, 0.8 / q);
         int64_t n_out = (n + q - 1) / q;
         hz.t = build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, n_out, q);
         hz.bind(1);
-        be.zp_block<2, 4, kLDec, kEdgeSos>(&hz.t.p, ld, hz.t.p.nb, 1);
-        be.zp_carry<2, 4>(&hz.t.p, hz.t.p.nb, 1);
-        be.zp_fixup<8>(&hz.t.p, 1, n_out, y, n_out, nullptr, fs);
+        be.zp_block<2, 4, kLDec, kEdgeSos>(hz.t.p, ld, hz.t.p.nb, 1);
+        be.zp_carry<2, 4>(hz.t.p, hz.t.p.nb, 1);
+        be.zp_fixup<8>(hz.t.p, 1, n_out, y, n_out, nullptr, fs);
     } else {
         if (n <= kEdgeTf) return -1;
         Tf4 t = design_butter4(butter_cutoff(bandwidth, fs));
         hz.t = build_zp_tables(desc_from_tf(t), n, kEdgeTf, kLLpf, n, 1);
         hz.bind(1);
-        be.zp_block<4, 1, kLLpf, kEdgeTf>(&hz.t.p, ld, hz.t.p.nb, 1);
-        be.zp_carry<4, 1>(&hz.t.p, hz.t.p.nb, 1);
-        be.zp_fixup<4>(&hz.t.p, 1, n, y, n, nullptr, fs);
+        be.zp_block<4, 1, kLLpf, kEdgeTf>(hz.t.p, ld, hz.t.p.nb, 1);
+        be.zp_carry<4, 1>(hz.t.p, hz.t.p.nb, 1);
+        be.zp_fixup<4>(hz.t.p, 1, n, y, n, nullptr, fs);
     }
     return 0;
 }

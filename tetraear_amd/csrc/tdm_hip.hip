@@ -1,0 +1,740 @@
+// libtetrahip.so -- gfx950 build of the C-ABI in include/tetrahip.h.
+//
+// __global__ wrappers around the kernel bodies of zp_kernels.hpp, the HIP backend of
+// ref_pipeline.hpp, plans, and the extern "C" entry points.  There is no CPU compute path in
+// this library: every compute entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tetrahip.h"
+#include "ref_pipeline.hpp"
+
+using namespace tdm;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(TDM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+static int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(TDM_ERR_NO_DEVICE, std::string("no HIP device available (") +
+                                           (e == hipSuccess ? "count=0" : hipGetErrorString(e)) +
+                                           "); libtetrahip has no CPU path");
+    if (device < 0 || device >= n) return fail(TDM_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    return TDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device-side communication objects
+// ------------------------------------------------------------------------------------------
+struct WaveComm {
+    template <int K>
+    __device__ __forceinline__ void shfl_up2(const double *a, const double *b, double *oa, double *ob, int d)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { oa[k] = __shfl_up(a[k], d, 64); ob[k] = __shfl_up(b[k], d, 64); }
+    }
+    template <int K>
+    __device__ __forceinline__ void shfl_down2(const double *a, const double *b, double *oa, double *ob, int d)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { oa[k] = __shfl_down(a[k], d, 64); ob[k] = __shfl_down(b[k], d, 64); }
+    }
+};
+
+constexpr int kFinishThreads = 256;
+
+struct BlockComm {
+    double *sm;  // [kFinishThreads / 64] LDS
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    template <class F>
+    __device__ __forceinline__ double reduce(double v, F f)
+    {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v = f(v, __shfl_xor(v, d, 64));
+        const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        if ((threadIdx.x & 63) == 0) sm[w] = v;
+        __syncthreads();
+        double r = sm[0];
+        for (int i = 1; i < nw; ++i) r = f(r, sm[i]);
+        __syncthreads();
+        return r;
+    }
+    __device__ __forceinline__ double reduce_sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
+    __device__ __forceinline__ double reduce_max(double v) { return reduce(v, [](double a, double b) { return fmax(a, b); }); }
+    __device__ __forceinline__ double reduce_min(double v) { return reduce(v, [](double a, double b) { return fmin(a, b); }); }
+};
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+#ifndef TDM_BLOCK_WAVES
+#define TDM_BLOCK_WAVES 2  // waves per SIMD the block kernel is register-budgeted for
+#endif
+template <int K, int NSEC, int L, int EDGE, class Loader>
+__global__ __launch_bounds__(64, TDM_BLOCK_WAVES) void k_zp_block(const ZpParams P, const Loader ld)
+{
+    WaveComm cm;
+    zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+template <int K, int NSEC, bool FWD>
+__global__ __launch_bounds__(256) void k_zp_carry(const ZpParams P, int nb, int rows)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = (int)(idx & 1);
+    const int64_t rb = idx >> 1;
+    const int b = (int)(rb % nb);
+    const int row = (int)(rb / nb);
+    if (row >= rows) return;
+    if (FWD)
+        zp_carry_fwd_body<K, NSEC>(P, row, b, ch);
+    else
+        zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_zp_fixup(const ZpParams P, int64_t n_out, double *out,
+                                                  int64_t out_row_stride, const double *freq_offset,
+                                                  double fs_out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (j >= n_out) return;
+    zp_fixup_body<D>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
+}
+
+template <class Loader>
+__global__ __launch_bounds__(256) void k_convert(const Loader ld, int64_t n, double *out, const double *freq_offset,
+                                                 double fs)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (j >= n) return;
+    convert_body(ld, row, j, out + (int64_t)row * n * 2, freq_offset, fs);
+}
+
+__global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs fa)
+{
+    __shared__ double sm[kFinishThreads / 64];
+    BlockComm cm{sm};
+    finish_body(fa, cm, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_shift(const double *x, double *y, int64_t n, double f, double fs)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) shift_body(x, y, j, f, fs);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage timing (HIP events around each launch, on the stream the kernels run on)
+// ------------------------------------------------------------------------------------------
+enum Stage { ST_DEC_BLOCK = 0, ST_DEC_CARRY, ST_DEC_FIXUP, ST_CONVERT, ST_LPF_BLOCK, ST_LPF_CARRY, ST_LPF_FIXUP, ST_FINISH, ST_COUNT };
+static const char *kStageNames[ST_COUNT] = {"dec_block", "dec_carry", "dec_fixup", "convert",
+                                            "lpf_block", "lpf_carry", "lpf_fixup", "finish"};
+
+struct StageTimer {
+    bool on = false;
+    struct Rec { int stage; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void release_all()
+    {
+        for (auto &r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
+        recs.clear();
+    }
+    ~StageTimer()
+    {
+        release_all();
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+struct HipBackend {
+    hipStream_t stream = nullptr;
+    StageTimer *timer = nullptr;
+    hipError_t err = hipSuccess;
+
+    struct Scope {
+        HipBackend &be; int stage; hipEvent_t a{}, b{}; bool on;
+        Scope(HipBackend &be_, int st) : be(be_), stage(st), on(be_.timer && be_.timer->on)
+        {
+            if (on) { a = be.timer->get(); b = be.timer->get(); (void)hipEventRecord(a, be.stream); }
+        }
+        ~Scope()
+        {
+            if (on) { (void)hipEventRecord(b, be.stream); be.timer->recs.push_back({stage, a, b}); }
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess && be.err == hipSuccess) be.err = e;
+        }
+    };
+
+    template <int K, int NSEC, int L, int EDGE, class Loader>
+    void zp_block(const ZpParams &P, Loader ld, int nb, int rows)
+    {
+        Scope s(*this, K == 2 ? ST_DEC_BLOCK : ST_LPF_BLOCK);
+        hipLaunchKernelGGL((k_zp_block<K, NSEC, L, EDGE, Loader>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
+    }
+    template <int K, int NSEC>
+    void zp_carry(const ZpParams &P, int nb, int rows)
+    {
+        Scope s(*this, K == 2 ? ST_DEC_CARRY : ST_LPF_CARRY);
+        const int64_t threads = (int64_t)rows * nb * 2;
+        const unsigned blocks = (unsigned)((threads + 255) / 256);
+        hipLaunchKernelGGL((k_zp_carry<K, NSEC, true>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
+        hipLaunchKernelGGL((k_zp_carry<K, NSEC, false>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
+    }
+    template <int D>
+    void zp_fixup(const ZpParams &P, int rows, int64_t n_out, double *out, int64_t out_row_stride,
+                  const double *freq_offset, double fs_out)
+    {
+        Scope s(*this, D == 8 ? ST_DEC_FIXUP : ST_LPF_FIXUP);
+        hipLaunchKernelGGL((k_zp_fixup<D>), dim3((unsigned)((n_out + 255) / 256), rows), dim3(256), 0, stream,
+                           P, n_out, out, out_row_stride, freq_offset, fs_out);
+    }
+    template <class Loader>
+    void convert(Loader ld, int rows, int64_t n, double *out, const double *freq_offset, double fs)
+    {
+        Scope s(*this, ST_CONVERT);
+        hipLaunchKernelGGL((k_convert<Loader>), dim3((unsigned)((n + 255) / 256), rows), dim3(256), 0, stream, ld, n,
+                           out, freq_offset, fs);
+    }
+    void finish(const FinishArgs &fa, int rows)
+    {
+        Scope s(*this, ST_FINISH);
+        hipLaunchKernelGGL(k_finish, dim3(rows), dim3(kFinishThreads), 0, stream, fa);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// device copies of a zero-phase stage
+// ------------------------------------------------------------------------------------------
+struct DevZp {
+    ZpParams params{};  // host copy whose pointers are device addresses (passed by value to kernels)
+    double *d_blob = nullptr;
+    double *d_work = nullptr;
+    int init(const ZpHostTables &t, int rows)
+    {
+        ZpParams p = t.p;
+        const int D = p.nsec * p.K;
+        HIP_TRY(hipMalloc(&d_blob, t.blob.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(d_blob, t.blob.data(), t.blob.size() * sizeof(double), hipMemcpyHostToDevice));
+        t.bind(p, d_blob);
+        const size_t n_y0 = (size_t)rows * p.n_out * 2;
+        const size_t n_e = (size_t)rows * p.nb * D * 2;
+        const size_t total = n_y0 + 4 * n_e + (size_t)rows * 2;
+        HIP_TRY(hipMalloc(&d_work, total * sizeof(double)));
+        p.y0 = d_work;
+        p.Ef = p.y0 + n_y0;
+        p.Eb = p.Ef + n_e;
+        p.Gf = p.Eb + n_e;
+        p.Hb = p.Gf + n_e;
+        p.flast = p.Hb + n_e;
+        params = p;
+        return TDM_OK;
+    }
+    void destroy()
+    {
+        if (d_blob) (void)hipFree(d_blob);
+        if (d_work) (void)hipFree(d_work);
+        d_blob = nullptr; d_work = nullptr;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct tdm_plan {
+    RefPlanHost h;
+    int rows = 0, fmt = 0, mode = 0, device = 0;
+    DevZp dec, lpf;
+    double *d_y = nullptr, *d_z = nullptr;
+    // staging for the host-pointer entry point
+    void *d_iq = nullptr;
+    size_t d_iq_bytes = 0;
+    double *d_pre = nullptr, *d_foff = nullptr, *d_soft = nullptr, *d_margin = nullptr;
+    uint8_t *d_hard = nullptr;
+    int32_t *d_nsoft = nullptr, *d_bp = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    StageTimer timer;
+};
+
+static size_t fmt_bytes(int fmt) { return fmt == TDM_CU8 || fmt == TDM_CS8 ? 2 : (fmt == TDM_CF32 ? 8 : 16); }
+
+static void plan_free(tdm_plan *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    p->dec.destroy();
+    p->lpf.destroy();
+    void *ptrs[] = {p->d_y, p->d_z, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+extern "C" {
+
+int tdm_version(void) { return TDM_VERSION; }
+
+int tdm_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(TDM_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int tdm_last_error(char *buf, size_t buflen)
+{
+    if (buf && buflen) {
+        std::snprintf(buf, buflen, "%s", g_err.c_str());
+    }
+    return (int)g_err.size();
+}
+
+int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, int32_t in_fmt, int32_t mode,
+                    int32_t device, tdm_plan **out)
+{
+    if (!out) return fail(TDM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!(sample_rate > 0) || n_samples < 1 || n_carriers < 1 || n_carriers > 65535 || in_fmt < 0 || in_fmt > 3)
+        return fail(TDM_ERR_INVALID, "bad sample_rate / n_samples / n_carriers (1..65535) / in_fmt");
+    if (mode != TDM_MODE_REFERENCE) return fail(TDM_ERR_UNSUPPORTED, "only TDM_MODE_REFERENCE is built in this version");
+    int rc = use_device(device);
+    if (rc) return rc;
+    std::unique_ptr<tdm_plan, void (*)(tdm_plan *)> p(new tdm_plan, plan_free);
+    p->device = device;
+    p->rows = n_carriers;
+    p->fmt = in_fmt;
+    p->mode = mode;
+    p->h = build_ref_plan(sample_rate, n_samples);
+    const RefPlanHost &h = p->h;
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&p->ev0));
+    HIP_TRY(hipEventCreate(&p->ev1));
+    if (h.decimated && (rc = p->dec.init(h.dec, n_carriers))) return rc;
+    if (h.lpf && (rc = p->lpf.init(h.lpf_t, n_carriers))) return rc;
+    const size_t nd = (size_t)n_carriers * h.n_dec * 2 * sizeof(double);
+    HIP_TRY(hipMalloc(&p->d_y, nd));
+    HIP_TRY(hipMalloc(&p->d_z, nd));
+    *out = p.release();
+    return TDM_OK;
+}
+
+int tdm_plan_destroy(tdm_plan *plan)
+{
+    plan_free(plan);
+    return TDM_OK;
+}
+
+int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info)
+{
+    if (!plan || !info) return fail(TDM_ERR_INVALID, "null argument");
+    const RefPlanHost &h = plan->h;
+    std::memset(info, 0, sizeof(*info));
+    info->sample_rate = h.sample_rate;
+    info->rate_dec = h.rate_dec;
+    info->n_samples = h.n;
+    info->n_dec = h.n_dec;
+    info->n_carriers = plan->rows;
+    info->q = h.decimated ? h.q : 1;
+    info->sps = h.sps;
+    info->phase_step = h.phase_step;
+    info->max_soft = (int32_t)h.max_soft;
+    info->lpf_applied = h.lpf ? 1 : 0;
+    info->in_fmt = plan->fmt;
+    info->mode = plan->mode;
+    info->device = plan->device;
+    return TDM_OK;
+}
+
+int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, const double *pre_shift_hz,
+                       const double *freq_offset_hz, uint8_t *hard, double *soft, int32_t *n_soft,
+                       int32_t *best_phase, double *min_margin, void *stream)
+{
+    if (!plan || !iq || !hard || !soft || !n_soft) return fail(TDM_ERR_INVALID, "null argument");
+    if (carrier_stride_samples < 0) return fail(TDM_ERR_INVALID, "negative carrier stride");
+    HIP_TRY(hipSetDevice(plan->device));
+    HipBackend be;
+    be.stream = stream ? (hipStream_t)stream : plan->stream;
+    be.timer = &plan->timer;
+    RefBuffers B;
+    B.dec_params = plan->dec.params;
+    B.lpf_params = plan->lpf.params;
+    B.y = plan->d_y;
+    B.z = plan->d_z;
+    RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin};
+    run_ref(be, plan->h, plan->rows, plan->fmt, B, io);
+    if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
+    return TDM_OK;
+}
+
+int tdm_plan_sync(tdm_plan *plan)
+{
+    if (!plan) return fail(TDM_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(plan->device));
+    HIP_TRY(hipStreamSynchronize(plan->stream));
+    return TDM_OK;
+}
+
+int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, const double *pre_shift_hz,
+                const double *freq_offset_hz, uint8_t *hard, double *soft, int32_t *n_soft, int32_t *best_phase,
+                double *min_margin)
+{
+    if (!plan || !iq || !hard || !soft || !n_soft) return fail(TDM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    const RefPlanHost &h = plan->h;
+    const int rows = plan->rows;
+    const size_t span = carrier_stride_samples == 0 ? (size_t)h.n
+                                                    : (size_t)(rows - 1) * carrier_stride_samples + h.n;
+    const size_t bytes = span * fmt_bytes(plan->fmt);
+    if (plan->d_iq_bytes < bytes) {
+        if (plan->d_iq) (void)hipFree(plan->d_iq);
+        plan->d_iq = nullptr;
+        plan->d_iq_bytes = 0;
+        HIP_TRY(hipMalloc(&plan->d_iq, bytes));
+        plan->d_iq_bytes = bytes;
+    }
+    if (!plan->d_soft) {
+        HIP_TRY(hipMalloc(&plan->d_pre, rows * sizeof(double)));
+        HIP_TRY(hipMalloc(&plan->d_foff, rows * sizeof(double)));
+        HIP_TRY(hipMalloc(&plan->d_soft, (size_t)rows * h.max_soft * 2 * sizeof(double)));
+        HIP_TRY(hipMalloc(&plan->d_hard, (size_t)rows * h.max_soft));
+        HIP_TRY(hipMalloc(&plan->d_nsoft, rows * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&plan->d_bp, rows * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&plan->d_margin, rows * sizeof(double)));
+    }
+    hipStream_t st = plan->stream;
+    HIP_TRY(hipMemcpyAsync(plan->d_iq, iq, bytes, hipMemcpyHostToDevice, st));
+    if (pre_shift_hz) HIP_TRY(hipMemcpyAsync(plan->d_pre, pre_shift_hz, rows * sizeof(double), hipMemcpyHostToDevice, st));
+    if (freq_offset_hz) HIP_TRY(hipMemcpyAsync(plan->d_foff, freq_offset_hz, rows * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(plan->d_hard, 0, (size_t)rows * h.max_soft, st));
+    int rc = tdm_process_device(plan, plan->d_iq, carrier_stride_samples, pre_shift_hz ? plan->d_pre : nullptr,
+                                freq_offset_hz ? plan->d_foff : nullptr, plan->d_hard, plan->d_soft, plan->d_nsoft,
+                                plan->d_bp, plan->d_margin, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(hard, plan->d_hard, (size_t)rows * h.max_soft, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(soft, plan->d_soft, (size_t)rows * h.max_soft * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(n_soft, plan->d_nsoft, rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (best_phase) HIP_TRY(hipMemcpyAsync(best_phase, plan->d_bp, rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (min_margin) HIP_TRY(hipMemcpyAsync(min_margin, plan->d_margin, rows * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return TDM_OK;
+}
+
+// ---- timing -----------------------------------------------------------------------------------
+int tdm_plan_time_begin(tdm_plan *plan)
+{
+    if (!plan) return fail(TDM_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(plan->device));
+    plan->timer.release_all();
+    plan->timer.on = true;
+    HIP_TRY(hipEventRecord(plan->ev0, plan->stream));
+    return TDM_OK;
+}
+
+int tdm_plan_time_end(tdm_plan *plan, float *elapsed_ms)
+{
+    if (!plan) return fail(TDM_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(plan->device));
+    HIP_TRY(hipEventRecord(plan->ev1, plan->stream));
+    HIP_TRY(hipEventSynchronize(plan->ev1));
+    plan->timer.on = false;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, plan->ev0, plan->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return TDM_OK;
+}
+
+int tdm_plan_stage_times(tdm_plan *plan, int32_t max_stages, const char **names, float *ms, int32_t *n_stages)
+{
+    if (!plan || !names || !ms || !n_stages) return fail(TDM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    float acc[ST_COUNT] = {0};
+    int cnt[ST_COUNT] = {0};
+    for (auto &r : plan->timer.recs) {
+        float t = 0;
+        HIP_TRY(hipEventSynchronize(r.b));
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        acc[r.stage] += t;
+        cnt[r.stage]++;
+    }
+    int n = 0;
+    for (int s = 0; s < ST_COUNT && n < max_stages; ++s) {
+        if (!cnt[s]) continue;
+        names[n] = kStageNames[s];
+        ms[n] = acc[s] / cnt[s];  // average per launch
+        ++n;
+    }
+    *n_stages = n;
+    return TDM_OK;
+}
+
+// ---- device memory helpers --------------------------------------------------------------------
+int tdm_dev_alloc(int32_t device, size_t bytes, void **ptr)
+{
+    if (!ptr) return fail(TDM_ERR_INVALID, "null ptr");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(ptr, bytes ? bytes : 1));
+    return TDM_OK;
+}
+int tdm_dev_free(int32_t device, void *ptr)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipFree(ptr));
+    return TDM_OK;
+}
+int tdm_dev_upload(int32_t device, void *dst_dev, const void *src_host, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return TDM_OK;
+}
+int tdm_dev_download(int32_t device, void *dst_host, const void *src_dev, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return TDM_OK;
+}
+int tdm_dev_sync(int32_t device)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return TDM_OK;
+}
+
+}  // extern "C"
+
+// ---- single-method entry points (host pointers, blocking) ---------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); return TDM_OK; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// one zero-phase stage on a c128 host array
+int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, double *y, int64_t n_out, double fs)
+{
+    DevZp dz;
+    DevBuf dx, dy;
+    int rc;
+    if ((rc = dz.init(t, 1))) { dz.destroy(); return rc; }
+    struct Guard { DevZp &d; ~Guard() { d.destroy(); } } g{dz};
+    if ((rc = dx.alloc((size_t)n * 16))) return rc;
+    if ((rc = dy.alloc((size_t)n_out * 16))) return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 16, hipMemcpyHostToDevice));
+    HipBackend be;
+    RawLoader<FMT_CF64, false> ld{dx.p, n, nullptr, fs};
+    if (sos) {
+        be.zp_block<2, 4, kLDec, kEdgeSos>(dz.params, ld, t.p.nb, 1);
+        be.zp_carry<2, 4>(dz.params, t.p.nb, 1);
+        be.zp_fixup<8>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
+    } else {
+        be.zp_block<4, 1, kLLpf, kEdgeTf>(dz.params, ld, t.p.nb, 1);
+        be.zp_carry<4, 1>(dz.params, t.p.nb, 1);
+        be.zp_fixup<4>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
+    }
+    if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(y, dy.p, (size_t)n_out * 16, hipMemcpyDeviceToHost));
+    return TDM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int tdm_filter_signal(const double *x, int64_t n, double bandwidth, double fs, double *y, int32_t *applied,
+                      int32_t device)
+{
+    if (!x || !y || n < 0 || !(fs > 0)) return fail(TDM_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (applied) *applied = 0;
+    if (n <= kEdgeTf) {  // filtfilt raises; the reference returns the input (processor.py:81-83)
+        std::memcpy(y, x, (size_t)n * 16);
+        return TDM_OK;
+    }
+    Tf4 tf = design_butter4(butter_cutoff(bandwidth, fs));
+    ZpHostTables t = build_zp_tables(desc_from_tf(tf), n, kEdgeTf, kLLpf, n, 1);
+    rc = run_zp_stage(t, false, x, n, y, n, fs);
+    if (rc == TDM_OK && applied) *applied = 1;
+    return rc;
+}
+
+int tdm_decimate(const double *x, int64_t n, int32_t q, double *y, int64_t *n_out, int32_t device)
+{
+    if (!x || !y || q < 2 || q > 4096) return fail(TDM_ERR_INVALID, "bad argument");
+    if (n <= kEdgeSos) return fail(TDM_ERR_INVALID, "The length of the input vector x must be greater than padlen, which is 27.");
+    int rc = use_device(device);
+    if (rc) return rc;
+    Sos4 s = design_cheby1_8(0.05, 0.8 / q);
+    const int64_t m = (n + q - 1) / q;
+    ZpHostTables t = build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, m, q);
+    rc = run_zp_stage(t, true, x, n, y, m, 1.0);
+    if (rc == TDM_OK && n_out) *n_out = m;
+    return rc;
+}
+
+int tdm_frequency_shift(const double *x, int64_t n, double freq_offset, double fs, double *y, int32_t device)
+{
+    if ((!x || !y) && n > 0) return fail(TDM_ERR_INVALID, "null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (n <= 0) return TDM_OK;
+    DevBuf dx, dy;
+    if ((rc = dx.alloc((size_t)n * 16)) || (rc = dy.alloc((size_t)n * 16))) return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_shift, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx.as<double>(), dy.as<double>(), n,
+                       freq_offset, fs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(y, dy.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return TDM_OK;
+}
+
+static int run_finish(const double *x, int64_t n, int sps, int do_extract, int do_demod, double *soft_out,
+                      uint8_t *hard_out, int64_t *n_soft_out, int32_t *best_phase, double *min_margin)
+{
+    DevBuf dx, dsoft, dhard, dmeta;
+    int rc;
+    if ((rc = dx.alloc((size_t)n * 16)) || (rc = dsoft.alloc((size_t)n * 16)) || (rc = dhard.alloc((size_t)n)) ||
+        (rc = dmeta.alloc(64)))
+        return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dmeta.p, 0, 64));
+    FinishArgs fa{};
+    fa.z = dx.as<double>();
+    fa.n = n;
+    fa.row_stride = n;
+    fa.sps = sps;
+    fa.do_extract = do_extract;
+    fa.do_demod = do_demod;
+    fa.max_soft = (int32_t)n;
+    fa.soft = dsoft.as<double>();
+    fa.hard = dhard.as<uint8_t>();
+    fa.n_soft = (int32_t *)dmeta.p;
+    fa.best_phase = (int32_t *)dmeta.p + 1;
+    fa.min_margin = (double *)dmeta.p + 1;
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, 0, fa);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    struct { int32_t ns, bp; double mm; } meta;
+    HIP_TRY(hipMemcpy(&meta, dmeta.p, sizeof(meta), hipMemcpyDeviceToHost));
+    if (soft_out && meta.ns > 0) HIP_TRY(hipMemcpy(soft_out, dsoft.p, (size_t)meta.ns * 16, hipMemcpyDeviceToHost));
+    if (hard_out && meta.ns > 1) HIP_TRY(hipMemcpy(hard_out, dhard.p, (size_t)(meta.ns - 1), hipMemcpyDeviceToHost));
+    if (n_soft_out) *n_soft_out = meta.ns;
+    if (best_phase) *best_phase = meta.bp;
+    if (min_margin) *min_margin = meta.mm;
+    return TDM_OK;
+}
+
+int tdm_extract_symbols(const double *x, int64_t n, double fs, double symbol_rate, double *y, int64_t *n_out,
+                        int32_t *best_phase, int32_t device)
+{
+    if (!n_out || (n > 0 && (!x || !y)) || !(symbol_rate > 0)) return fail(TDM_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    *n_out = 0;
+    if (best_phase) *best_phase = 0;
+    if (n <= 0) return TDM_OK;
+    return run_finish(x, n, (int)(fs / symbol_rate), 1, 0, y, nullptr, n_out, best_phase, nullptr);
+}
+
+int tdm_demodulate_dqpsk(const double *x, int64_t n, uint8_t *out, int64_t *n_out, double *min_margin, int32_t device)
+{
+    if (!n_out || (n > 1 && (!x || !out))) return fail(TDM_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    *n_out = 0;
+    if (n < 2) return TDM_OK;
+    int64_t ns = 0;
+    rc = run_finish(x, n, 1, 0, 1, nullptr, out, &ns, nullptr, min_margin);
+    if (rc == TDM_OK) *n_out = ns > 0 ? ns - 1 : 0;
+    return rc;
+}
+
+int tdm_resample(const double *, int64_t, int64_t, double *, int32_t)
+{
+    return fail(TDM_ERR_UNSUPPORTED, "tdm_resample: not built yet (SignalProcessor.resample is not on the process() path)");
+}
+
+// ---- introspection (no device needed) -----------------------------------------------------------
+int tdm_design_dump(double sample_rate, int64_t n_samples, double *sos, double *soszi, double *b, double *a,
+                    double *zi, int32_t *q, double *rate_dec)
+{
+    if (!(sample_rate > 0)) return fail(TDM_ERR_INVALID, "bad sample_rate");
+    const int qq = decimation_factor(sample_rate);
+    const bool dec = qq > 1 && n_samples > kEdgeSos;
+    const double rate = dec ? sample_rate / qq : sample_rate;
+    if (sos) std::memset(sos, 0, 24 * sizeof(double));
+    if (soszi) std::memset(soszi, 0, 8 * sizeof(double));
+    if (qq > 1) {
+        Sos4 s = design_cheby1_8(0.05, 0.8 / qq);
+        if (sos) std::memcpy(sos, s.sos, sizeof(s.sos));
+        if (soszi) std::memcpy(soszi, s.zi, sizeof(s.zi));
+    }
+    Tf4 t = design_butter4(butter_cutoff(25000.0, rate));
+    if (b) std::memcpy(b, t.b, sizeof(t.b));
+    if (a) std::memcpy(a, t.a, sizeof(t.a));
+    if (zi) std::memcpy(zi, t.zi, sizeof(t.zi));
+    if (q) *q = dec ? qq : 1;
+    if (rate_dec) *rate_dec = rate;
+    return TDM_OK;
+}
+
+int tdm_design_butter(double bandwidth, double fs, double *b, double *a, double *zi)
+{
+    if (!(fs > 0) || !b || !a || !zi) return fail(TDM_ERR_INVALID, "bad argument");
+    Tf4 t = design_butter4(butter_cutoff(bandwidth, fs));
+    std::memcpy(b, t.b, sizeof(t.b));
+    std::memcpy(a, t.a, sizeof(t.a));
+    std::memcpy(zi, t.zi, sizeof(t.zi));
+    return TDM_OK;
+}
+
+}  // extern "C"

@@ -7,7 +7,7 @@
 // used twice to restore the exact result:
 //   in-block : per section, a wavefront prefix scan over the lanes' end states (K x K transition
 //              matrices A^(L*2^j)) gives each lane its true start state; the zero-input response
-//              of that state (table csec) is added to the lane's samples;
+//              of that state (the section run on zero input) is added to the lane's samples;
 //   x-block  : each block exports its end states (forward Ef, backward Eb); a tiny carry kernel
 //              runs the D-dimensional recurrences across blocks (tables Mf, Mb, U) and the
 //              consumer adds the two carry responses (tables T1, T2) to the block-local outputs.
@@ -22,6 +22,14 @@
 #define TDM_HD __host__ __device__ __forceinline__
 #else
 #define TDM_HD inline
+#endif
+
+// Read-only tables are read through the constant address space on the device so that uniform
+// reads become scalar loads (s_load) instead of per-lane vector loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TDM_CPTR(p) ((const __attribute__((address_space(4))) double *)(p))
+#else
+#define TDM_CPTR(p) (p)
 #endif
 
 namespace tdm {
@@ -53,14 +61,13 @@ struct ZpParams {
     int32_t carry_terms; // series length of the cross-block carries (see zp_kernels.hpp)
     // ---- tables (pointers valid where the kernels run)
     const double *Mpow;     // [nsec][6][K*K]   A_s^(L*2^j), row-major
-    const double *csec;     // [nsec][L][K]     zero-input response of section s at step i
     const double *cfull;    // [64L][D]         zero-input response of the whole cascade
     const double *T1_reg;   // [64L][D]         fwd carry-in -> block-local fwd->bwd output
     const double *T1_last;  // [len_last][D]
-    double Mf[kMaxD * kMaxD];       // A^(64L)
-    double Mb_last[kMaxD * kMaxD];  // A^(len_last)
-    double U_reg[kMaxD * kMaxD];    // fwd carry-in -> bwd end state of the block
-    double U_last[kMaxD * kMaxD];
+    const double *Mf;       // [D][D] A^(64L)
+    const double *Mb_last;  // [D][D] A^(len_last)
+    const double *U_reg;    // [D][D] fwd carry-in -> bwd end state of the block
+    const double *U_last;   // [D][D]
     // ---- per-row work buffers
     double *y0;     // [rows][n_out] c128, block-local outputs
     double *Ef;     // [rows][nb][D] c128, block-local forward end states
@@ -87,6 +94,17 @@ TDM_HD T df2t_step(const T *b, const T *a, T x, T *z)
         z[K - 1] = b[K] * x - a[K] * y;
         return y;
     }
+}
+
+// Zero-input step of the same section: returns the output for x == 0 and advances the state.
+template <int K, typename T>
+TDM_HD T zir_step(const T *a, T *z)
+{
+    const T y = z[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) z[k - 1] = z[k] - a[k] * y;
+    z[K - 1] = -(a[K] * y);
+    return y;
 }
 
 }  // namespace tdm

@@ -48,16 +48,25 @@ struct alignas(16) f64x2 {
 
 // frequency_shift (processor.py:98-99): t = n/fs; shift = exp(-1j*2*pi*f*t)
 // Python evaluates ((-1j*2)*pi)*f -> (0, -(2*pi)*f) and multiplies by t[n].
-TDM_NOINLINE void nco_rotate(double &re, double &im, int64_t k, double f, double fs)
+// The phasor is computed out of line (by value, so callers' sample arrays stay in registers).
+struct phasor {
+    double c, s;
+};
+TDM_NOINLINE phasor nco_phasor(int64_t k, double f, double fs)
 {
     const double ci = -(2.0 * M_PI) * f;
     const double t = (double)k / fs;
     const double th = ci * t;
-    double s, c;
-    sincos(th, &s, &c);
+    phasor p;
+    sincos(th, &p.s, &p.c);
+    return p;
+}
+TDM_HD void nco_rotate(double &re, double &im, int64_t k, double f, double fs)
+{
+    const phasor p = nco_phasor(k, f, fs);
     const double a = re, b = im;
-    re = a * c - b * s;
-    im = a * s + b * c;
+    re = a * p.c - b * p.s;
+    im = a * p.s + b * p.c;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -90,11 +99,11 @@ TDM_HD void convert_one(const void *rowp, int64_t k, double &re, double &im)
     }
 }
 
-template <int FMT>
+template <int FMT, bool SHIFT>
 struct RawLoader {
     const void *iq;            // first sample of row 0
     int64_t row_stride;        // samples between rows (0 = shared stream)
-    const double *pre_shift;   // per row [Hz] or null
+    const double *pre_shift;   // per row [Hz]; read only when SHIFT
     double fs;
 
     static constexpr int kBytes = (FMT == FMT_CU8 || FMT == FMT_CS8) ? 2 : (FMT == FMT_CF32 ? 8 : 16);
@@ -103,10 +112,11 @@ struct RawLoader {
     {
         return (const char *)iq + (int64_t)row * row_stride * kBytes;
     }
+    TDM_HD double row_shift(int row) const { return (SHIFT && pre_shift) ? pre_shift[row] : 0.0; }
     TDM_HD void sample(const void *rowp, int64_t k, double f, double &re, double &im) const
     {
         convert_one<FMT>(rowp, k, re, im);
-        if (f != 0.0) nco_rotate(re, im, k, f, fs);
+        if (SHIFT && f != 0.0) nco_rotate(re, im, k, f, fs);
     }
 
     template <int L>
@@ -148,31 +158,21 @@ struct RawLoader {
 #pragma unroll
             for (int i = 0; i < L; ++i) convert_one<FMT>(rowp, k + i, xr[i], xi[i]);
         }
-        if (f != 0.0) {
+        if (SHIFT && f != 0.0) {
 #pragma unroll
             for (int i = 0; i < L; ++i) nco_rotate(xr[i], xi[i], k + i, f, fs);
         }
     }
 
-    // x[i] = padded-ext sample seg+i (zero outside [P0, Ne))
-    template <int L>
-    TDM_HD void load(int row, int64_t seg, const ZpParams *P, double *xr, double *xi) const
+    // Edge lanes (odd extension, zero pad): rolled loop into a small stack array, so the main
+    // kernel's register budget is not shaped by this rarely taken path.
+    TDM_NOINLINE void slow(const void *rowp, double f, int64_t e0, int64_t n, int edge, int L, double *out) const
     {
-        const void *rowp = row_ptr(row);
-        const double f = pre_shift ? pre_shift[row] : 0.0;
-        const int64_t n = P->n;
-        const int edge = P->edge;
-        const int64_t e0 = seg - P->P0;  // ext index of x[0]
-        if (e0 >= edge && e0 + L <= edge + n) {
-            fast<L>(rowp, e0 - edge, f, xr, xi);
-            return;
-        }
         double x0r = 0, x0i = 0, x1r = 0, x1i = 0;
         if (n > 0) {
             sample(rowp, 0, f, x0r, x0i);
             sample(rowp, n - 1, f, x1r, x1i);
         }
-#pragma unroll
         for (int i = 0; i < L; ++i) {
             const int64_t e = e0 + i;
             double re = 0, im = 0;
@@ -189,8 +189,27 @@ struct RawLoader {
                     im = 2 * x1i - im;
                 }
             }
-            xr[i] = re;
-            xi[i] = im;
+            out[2 * i] = re;
+            out[2 * i + 1] = im;
+        }
+    }
+
+    // x[i] = padded-ext sample seg+i (zero outside [P0, Ne))
+    template <int L>
+    TDM_HD void load(int row, int64_t seg, const ZpParams &P, double *xr, double *xi) const
+    {
+        const void *rowp = row_ptr(row);
+        const double f = row_shift(row);
+        const int64_t n = P.n;
+        const int edge = P.edge;
+        const int64_t e0 = seg - P.P0;  // ext index of x[0]
+        if (e0 >= edge && e0 + L <= edge + n) {
+            fast<L>(rowp, e0 - edge, f, xr, xi);
+        } else {
+            double tmp[2 * L];
+            slow(rowp, f, e0, n, edge, L, tmp);
+#pragma unroll
+            for (int i = 0; i < L; ++i) { xr[i] = tmp[2 * i]; xi[i] = tmp[2 * i + 1]; }
         }
     }
 };
@@ -201,8 +220,7 @@ struct RawLoader {
 //   K-vectors of doubles across the 64 lanes (own value where the source lane does not exist).
 // ------------------------------------------------------------------------------------------
 template <int K, int NSEC, int L, int EDGE, class Loader, class Comm>
-TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm &cm, int lane, int blk,
-                          int row)
+TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lane, int blk, int row)
 {
     constexpr int D = K * NSEC;
     constexpr int Bn = kWave * L;
@@ -210,20 +228,20 @@ TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm
     const int64_t seg = (int64_t)blk * Bn + (int64_t)lane * L;
     ld.template load<L>(row, seg, P, xr, xi);
 
-    constexpr int P0 = (L - EDGE % L) % L;  // == P->P0
+    constexpr int P0 = (L - EDGE % L) % L;  // == P.P0
     const bool inject = (blk == 0 && lane == 0);
     const double e0r = xr[P0], e0i = xi[P0];
 
-    const int64_t nbD = (int64_t)P->nb * D;
-    double *Ef = P->Ef + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
-    double *Eb = P->Eb + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
+    const int64_t nbD = (int64_t)P.nb * D;
+    double *Ef = P.Ef + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
+    double *Eb = P.Eb + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
 
     // ---------------- forward: sections in cascade order ----------------
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
         double b[K + 1], a[K + 1];
 #pragma unroll
-        for (int k = 0; k <= K; ++k) { b[k] = P->b[s][k]; a[k] = P->a[s][k]; }
+        for (int k = 0; k <= K; ++k) { b[k] = P.b[s][k]; a[k] = P.a[s][k]; }
         double zr[K], zq[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) { zr[k] = 0; zq[k] = 0; }
@@ -231,7 +249,7 @@ TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm
         for (int i = 0; i < L; ++i) {
             if (i == P0 && inject) {  // scipy: zi * ext[0] is the state before the first sample
 #pragma unroll
-                for (int k = 0; k < K; ++k) { zr[k] = P->zi[s][k] * e0r; zq[k] = P->zi[s][k] * e0i; }
+                for (int k = 0; k < K; ++k) { zr[k] = P.zi[s][k] * e0r; zq[k] = P.zi[s][k] * e0i; }
             }
             xr[i] = df2t_step<K, double>(b, a, xr[i], zr);
             xi[i] = df2t_step<K, double>(b, a, xi[i], zq);
@@ -240,7 +258,7 @@ TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm
 #pragma unroll
         for (int j = 0; j < kScanSteps; ++j) {
             const int d = 1 << j;
-            const double *M = P->Mpow + ((size_t)s * kScanSteps + j) * K * K;
+            const auto M = TDM_CPTR(P.Mpow + ((size_t)s * kScanSteps + j) * K * K);
             double jr[K], jq[K];
             cm.template shfl_up2<K>(zr, zq, jr, jq, d);
             if (lane >= d) {
@@ -264,23 +282,20 @@ TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (lane == 0) { sr[k] = 0; sq[k] = 0; }
-        const double *cs = P->csec + (size_t)s * L * K;
+        // add the zero-input response of the start state (run the section on zero input)
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            double ar = xr[i], aq = xi[i];
-#pragma unroll
-            for (int k = 0; k < K; ++k) { ar += cs[i * K + k] * sr[k]; aq += cs[i * K + k] * sq[k]; }
-            xr[i] = ar;
-            xi[i] = aq;
+            xr[i] += zir_step<K>(a, sr);
+            xi[i] += zir_step<K>(a, sq);
         }
     }
     // positions past the end of the extended signal must not feed the backward pass
-    if (blk == P->nb - 1) {
-        const int64_t last = P->Ne - 1;
+    if (blk == P.nb - 1) {
+        const int64_t last = P.Ne - 1;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             const int64_t g = seg + i;
-            if (g == last) { P->flast[(int64_t)row * 2] = xr[i]; P->flast[(int64_t)row * 2 + 1] = xi[i]; }
+            if (g == last) { P.flast[(int64_t)row * 2] = xr[i]; P.flast[(int64_t)row * 2 + 1] = xi[i]; }
             if (g > last) { xr[i] = 0; xi[i] = 0; }
         }
     }
@@ -289,7 +304,7 @@ TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm
     for (int s = 0; s < NSEC; ++s) {
         double b[K + 1], a[K + 1];
 #pragma unroll
-        for (int k = 0; k <= K; ++k) { b[k] = P->b[s][k]; a[k] = P->a[s][k]; }
+        for (int k = 0; k <= K; ++k) { b[k] = P.b[s][k]; a[k] = P.a[s][k]; }
         double zr[K], zq[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) { zr[k] = 0; zq[k] = 0; }
@@ -301,7 +316,7 @@ TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm
 #pragma unroll
         for (int j = 0; j < kScanSteps; ++j) {
             const int d = 1 << j;
-            const double *M = P->Mpow + ((size_t)s * kScanSteps + j) * K * K;
+            const auto M = TDM_CPTR(P.Mpow + ((size_t)s * kScanSteps + j) * K * K);
             double jr[K], jq[K];
             cm.template shfl_down2<K>(zr, zq, jr, jq, d);
             if (lane + d < kWave) {
@@ -324,30 +339,23 @@ TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (lane == kWave - 1) { sr[k] = 0; sq[k] = 0; }
-        const double *cs = P->csec + (size_t)s * L * K;
 #pragma unroll
-        for (int i = 0; i < L; ++i) {
-            double ar = xr[i], aq = xi[i];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                ar += cs[(L - 1 - i) * K + k] * sr[k];
-                aq += cs[(L - 1 - i) * K + k] * sq[k];
-            }
-            xr[i] = ar;
-            xi[i] = aq;
+        for (int i = L - 1; i >= 0; --i) {
+            xr[i] += zir_step<K>(a, sr);
+            xi[i] += zir_step<K>(a, sq);
         }
     }
     // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------
     {
-        const int64_t rel0 = seg - P->k0L;
-        const int q = P->out_stride;
+        const int64_t rel0 = seg - P.k0L;
+        const int q = P.out_stride;
         int64_t j = rel0 <= 0 ? 0 : (rel0 + q - 1) / q;
         int64_t next = j * q - rel0;  // position inside this segment
-        double *y0 = P->y0 + (int64_t)row * P->n_out * 2;
+        double *y0 = P.y0 + (int64_t)row * P.n_out * 2;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             if (i == next) {
-                if (j < P->n_out) { y0[j * 2] = xr[i]; y0[j * 2 + 1] = xi[i]; }
+                if (j < P.n_out) { y0[j * 2] = xr[i]; y0[j * 2 + 1] = xi[i]; }
                 ++j;
                 next += q;
             }
@@ -362,11 +370,11 @@ TDM_HD void zp_block_body(const ZpParams *__restrict__ P, const Loader &ld, Comm
 //     Hb[b-1] = Mb(b) Hb[b] + Eb[b] + U(b) Gf[b],        Hb[nb-1] = zi * f[last]
 // (scipy sosfiltfilt `zi * y_0`, _signaltools.py:4823-4824).  Mf = A^(64 L) is a contraction, so
 // each carry is evaluated independently per block as the Horner form of its series, cut after
-// P->carry_terms terms; the host picks carry_terms so that max|Mf^terms| < 1e-24 (or = nb, in
+// P.carry_terms terms; the host picks carry_terms so that max|Mf^terms| < 1e-24 (or = nb, in
 // which case the series is complete).  One thread per (row, block, component).
 // ------------------------------------------------------------------------------------------
-template <int D>
-TDM_HD void matvec_acc(const double *M, const double *v, double *out)
+template <int D, class MP>
+TDM_HD void matvec_acc(MP M, const double *v, double *out)
 {
 #pragma unroll
     for (int r = 0; r < D; ++r) {
@@ -378,23 +386,23 @@ TDM_HD void matvec_acc(const double *M, const double *v, double *out)
 }
 
 template <int K, int NSEC>
-TDM_HD void zp_carry_fwd_body(const ZpParams *__restrict__ P, int row, int b, int ch)
+TDM_HD void zp_carry_fwd_body(const ZpParams &P, int row, int b, int ch)
 {
     constexpr int D = K * NSEC;
-    const int nb = P->nb;
+    const int nb = P.nb;
     const int64_t base = (int64_t)row * nb * D * 2 + ch;
-    const double *Ef = P->Ef + base;
-    double *Gf = P->Gf + base;
+    const double *Ef = P.Ef + base;
+    double *Gf = P.Gf + base;
     double G[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) G[k] = 0;
-    int first = b - P->carry_terms;
+    int first = b - P.carry_terms;
     if (first < 0) first = 0;
     for (int bb = first; bb < b; ++bb) {  // G <- Mf G + Ef[bb]
         double Gn[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) Gn[k] = Ef[((int64_t)bb * D + k) * 2];
-        matvec_acc<D>(P->Mf, G, Gn);
+        matvec_acc<D>(TDM_CPTR(P.Mf), G, Gn);
 #pragma unroll
         for (int k = 0; k < D; ++k) G[k] = Gn[k];
     }
@@ -402,31 +410,31 @@ TDM_HD void zp_carry_fwd_body(const ZpParams *__restrict__ P, int row, int b, in
     for (int k = 0; k < D; ++k) Gf[((int64_t)b * D + k) * 2] = G[k];
     if (b == nb - 1) {
         // true forward output at the last extended sample -> start state of the backward pass
-        double fl = P->flast[(int64_t)row * 2 + ch];
-        const double *c = P->cfull + (size_t)(P->len_last - 1) * D;
+        double fl = P.flast[(int64_t)row * 2 + ch];
+        const auto c = TDM_CPTR(P.cfull + (size_t)(P.len_last - 1) * D);
 #pragma unroll
         for (int k = 0; k < D; ++k) fl += c[k] * G[k];
-        double *Hb = P->Hb + base;
+        double *Hb = P.Hb + base;
 #pragma unroll
         for (int s = 0; s < NSEC; ++s)
 #pragma unroll
-            for (int k = 0; k < K; ++k) Hb[((int64_t)b * D + s * K + k) * 2] = P->zi[s][k] * fl;
+            for (int k = 0; k < K; ++k) Hb[((int64_t)b * D + s * K + k) * 2] = P.zi[s][k] * fl;
     }
 }
 
 // for b < nb-1 (Hb[nb-1] was written by zp_carry_fwd_body)
 template <int K, int NSEC>
-TDM_HD void zp_carry_bwd_body(const ZpParams *__restrict__ P, int row, int b, int ch)
+TDM_HD void zp_carry_bwd_body(const ZpParams &P, int row, int b, int ch)
 {
     constexpr int D = K * NSEC;
-    const int nb = P->nb;
+    const int nb = P.nb;
     if (b >= nb - 1) return;
     const int64_t base = (int64_t)row * nb * D * 2 + ch;
-    const double *Eb = P->Eb + base;
-    const double *Gf = P->Gf + base;
-    double *Hb = P->Hb + base;
+    const double *Eb = P.Eb + base;
+    const double *Gf = P.Gf + base;
+    double *Hb = P.Hb + base;
     double H[D];
-    int far = b + P->carry_terms;  // farthest block whose contribution is kept
+    int far = b + P.carry_terms;  // farthest block whose contribution is kept
     if (far >= nb - 1) {
         far = nb - 1;
 #pragma unroll
@@ -443,8 +451,8 @@ TDM_HD void zp_carry_bwd_body(const ZpParams *__restrict__ P, int row, int b, in
             Hn[k] = Eb[((int64_t)bb * D + k) * 2];
             Gb[k] = Gf[((int64_t)bb * D + k) * 2];
         }
-        matvec_acc<D>(last ? P->Mb_last : P->Mf, H, Hn);
-        matvec_acc<D>(last ? P->U_last : P->U_reg, Gb, Hn);
+        matvec_acc<D>(TDM_CPTR(last ? P.Mb_last : P.Mf), H, Hn);
+        matvec_acc<D>(TDM_CPTR(last ? P.U_last : P.U_reg), Gb, Hn);
 #pragma unroll
         for (int k = 0; k < D; ++k) H[k] = Hn[k];
     }
@@ -457,21 +465,21 @@ TDM_HD void zp_carry_bwd_body(const ZpParams *__restrict__ P, int row, int b, in
 // freq_offset NCO at the output rate (processor.py:260-261).  One thread per output sample.
 // ------------------------------------------------------------------------------------------
 template <int D>
-TDM_HD void zp_fixup_body(const ZpParams *__restrict__ P, int row, int64_t j, double *out /* row base */,
+TDM_HD void zp_fixup_body(const ZpParams &P, int row, int64_t j, double *out /* row base */,
                           const double *freq_offset /* per row or null */, double fs_out)
 {
-    const int Bn = kWave * P->L;
-    const int64_t pos = P->k0L + j * P->out_stride;
+    const int Bn = kWave * P.L;
+    const int64_t pos = P.k0L + j * P.out_stride;
     const int b = (int)(pos / Bn);
     const int m = (int)(pos - (int64_t)b * Bn);
-    const bool last = (b == P->nb - 1);
-    const int len = last ? P->len_last : Bn;
-    const double *T1 = (last ? P->T1_last : P->T1_reg) + (size_t)m * D;
-    const double *T2 = P->cfull + (size_t)(len - 1 - m) * D;
-    const int64_t cb = ((int64_t)row * P->nb + b) * D * 2;
-    const double *Gf = P->Gf + cb;
-    const double *Hb = P->Hb + cb;
-    const double *y0 = P->y0 + ((int64_t)row * P->n_out + j) * 2;
+    const bool last = (b == P.nb - 1);
+    const int len = last ? P.len_last : Bn;
+    const double *T1 = (last ? P.T1_last : P.T1_reg) + (size_t)m * D;
+    const double *T2 = P.cfull + (size_t)(len - 1 - m) * D;
+    const int64_t cb = ((int64_t)row * P.nb + b) * D * 2;
+    const double *Gf = P.Gf + cb;
+    const double *Hb = P.Hb + cb;
+    const double *y0 = P.y0 + ((int64_t)row * P.n_out + j) * 2;
     double re = y0[0], im = y0[1];
 #pragma unroll
     for (int k = 0; k < D; ++k) {

@@ -20,7 +20,14 @@ struct ZpFilterDesc {
 struct ZpHostTables {
     ZpParams p;                // table/work pointers are null until patched by the owner
     std::vector<double> blob;  // all tables, concatenated
-    size_t off_Mpow, off_csec, off_cfull, off_T1reg, off_T1last;
+    size_t off_Mpow, off_cfull, off_T1reg, off_T1last, off_Mf, off_Mblast, off_Ureg, off_Ulast;
+    // point p's table pointers into a copy of blob that lives at `base`
+    void bind(ZpParams &q, const double *base) const
+    {
+        q.Mpow = base + off_Mpow; q.cfull = base + off_cfull;
+        q.T1_reg = base + off_T1reg; q.T1_last = base + off_T1last; q.Mf = base + off_Mf;
+        q.Mb_last = base + off_Mblast; q.U_reg = base + off_Ureg; q.U_last = base + off_Ulast;
+    }
 };
 
 namespace detail {
@@ -45,12 +52,15 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
     std::vector<double> &blob = t.blob;
     auto reserve = [&](size_t n) { size_t o = blob.size(); blob.resize(o + n, 0.0); return o; };
     t.off_Mpow = reserve((size_t)f.nsec * kScanSteps * K * K);
-    t.off_csec = reserve((size_t)f.nsec * L * K);
     t.off_cfull = reserve((size_t)Bn * D);
     t.off_T1reg = reserve((size_t)Bn * D);
     t.off_T1last = reserve((size_t)len_last * D);
+    t.off_Mf = reserve((size_t)D * D);
+    t.off_Mblast = reserve((size_t)D * D);
+    t.off_Ureg = reserve((size_t)D * D);
+    t.off_Ulast = reserve((size_t)D * D);
 
-    // ---- per-section tables: csec[s][i][k], Mpow[s][j] = A_s^(L*2^j)
+    // ---- per-section scan matrices: Mpow[s][j] = A_s^(L*2^j)
     for (int s = 0; s < f.nsec; ++s) {
         long double b[kMaxOrd + 1], a[kMaxOrd + 1];
         for (int k = 0; k <= K; ++k) { b[k] = f.b[s][k]; a[k] = f.a[s][k]; }
@@ -60,10 +70,7 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
             int step = 0;
             for (int j = 0; j < kScanSteps; ++j) {
                 const int target = L << j;
-                for (; step < target; ++step) {
-                    long double y = df2t_step<K, long double>(b, a, 0.0L, z);
-                    if (step < L) blob[t.off_csec + ((size_t)s * L + step) * K + k] = (double)y;
-                }
+                for (; step < target; ++step) (void)df2t_step<K, long double>(b, a, 0.0L, z);
                 for (int r = 0; r < K; ++r)
                     blob[t.off_Mpow + (((size_t)s * kScanSteps + j) * K + r) * K + k] = (double)z[r];
             }
@@ -79,9 +86,9 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
             zir[i] = y;
             blob[t.off_cfull + (size_t)i * D + k] = (double)y;
             if (i + 1 == len_last)
-                for (int r = 0; r < D; ++r) p.Mb_last[r * D + k] = (double)Z[r];
+                for (int r = 0; r < D; ++r) blob[t.off_Mblast + r * D + k] = (double)Z[r];
         }
-        for (int r = 0; r < D; ++r) p.Mf[r * D + k] = (double)Z[r];
+        for (int r = 0; r < D; ++r) blob[t.off_Mf + r * D + k] = (double)Z[r];
         // backward run over the forward zero-input response, regular and last-block lengths
         for (int v = 0; v < 2; ++v) {
             const int len = v ? len_last : Bn;
@@ -91,8 +98,8 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
                 long double y = cascade_step<K>(f, zir[i], W);
                 blob[off + (size_t)i * D + k] = (double)y;
             }
-            double *U = v ? p.U_last : p.U_reg;
-            for (int r = 0; r < D; ++r) U[r * D + k] = (double)W[r];
+            const size_t uo = v ? t.off_Ulast : t.off_Ureg;
+            for (int r = 0; r < D; ++r) blob[uo + r * D + k] = (double)W[r];
         }
     }
 }
@@ -130,7 +137,8 @@ inline ZpHostTables build_zp_tables(const ZpFilterDesc &f, int64_t n, int edge, 
     {
         const int D = f.nsec * f.K;
         std::vector<long double> Pw((size_t)D * D), Nx((size_t)D * D);
-        for (int i = 0; i < D * D; ++i) Pw[i] = p.Mf[i];
+        const double *Mf = t.blob.data() + t.off_Mf;
+        for (int i = 0; i < D * D; ++i) Pw[i] = Mf[i];
         int terms = 1;
         for (; terms < p.nb; ++terms) {
             long double mx = 0;
@@ -139,7 +147,7 @@ inline ZpHostTables build_zp_tables(const ZpFilterDesc &f, int64_t n, int edge, 
             for (int r = 0; r < D; ++r)
                 for (int c = 0; c < D; ++c) {
                     long double acc = 0;
-                    for (int k = 0; k < D; ++k) acc += Pw[r * D + k] * (long double)p.Mf[k * D + c];
+                    for (int k = 0; k < D; ++k) acc += Pw[r * D + k] * (long double)Mf[k * D + c];
                     Nx[r * D + c] = acc;
                 }
             Pw = Nx;
