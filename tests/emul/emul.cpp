@@ -188,8 +188,8 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         Tf4 t = design_butter4(butter_cutoff(bandwidth, fs));
         hz.t = build_zp_tables(desc_from_tf(t), n, kEdgeTf, kLLpf, n, 1);
         hz.bind(1);
-        be.zp_block<4, 1, kLLpf, kEdgeTf>(hz.t.p, ld, hz.t.p.nb, 1);
-        be.zp_carry<4, 1>(hz.t.p, hz.t.p.nb, 1);
+        be.zp_block<2, 2, kLLpf, kEdgeTf>(hz.t.p, ld, hz.t.p.nb, 1);
+        be.zp_carry<2, 2>(hz.t.p, hz.t.p.nb, 1);
         be.zp_fixup<4>(hz.t.p, 1, n, y, n, nullptr, fs);
     }
     return 0;

@@ -92,3 +92,21 @@ def test_emul_multirow_shared_and_formats(gold_process):
         for r in range(2):
             ns = int(n_soft[r])
             np.testing.assert_array_equal(hard[r, :ns - 1], ref)
+
+
+def test_emul_filter_stage_conditioning(gold_stages):
+    """filter_signal at the full 2.4 MHz rate: a very narrow order-4 Butterworth.  The device
+    evaluates it as two biquads because companion-form states have ~1e4 transient growth, which
+    the blocked evaluation would square (2e-8 error); with biquads the result sits at the
+    reference's own rounding-noise level (scipy tf-form vs exact: ~4e-11)."""
+    from tetraear_amd import synth
+    g = gold_stages
+    x = synth.cu8_to_c128(synth.noise_cu8(4000, int(g["x4000_seed"][0])))
+    for bw, fs, key, tol in [(25000, 2.4e6, "filter_default", 1e-9), (50000, 2.4e6, "filter_bw50k", 1e-9),
+                             (25000, 240000.0, "filter_240k", 1e-12), (100.0, 2.4e6, "filter_clamp_lo", 1e-9),
+                             (25000, 20000.0, "filter_clamp_hi", 1e-8)]:
+        y = emul.zp_stage(1, x, bandwidth=bw, fs=fs)
+        assert np.max(np.abs(y - g[key])) <= tol, key
+    for q in (7, 10, 41):
+        y = emul.zp_stage(0, x, q=q)
+        assert np.max(np.abs(y - g[f"decimate_q{q}"])) <= 1e-12 * np.max(np.abs(g[f"decimate_q{q}"]))

@@ -57,33 +57,34 @@ struct Sos4 {
 
 // lfilter_zi for order-K tf (a[0] == 1): solve (I - companion(a)^T) zi = b[1:] - a[1:] b[0]
 // by Gaussian elimination with partial pivoting (what LAPACK gesv does).
-static inline void lfilter_zi(const double *b, const double *a, int K, double *zi)
+static inline void lfilter_zi(const double *b, const double *a, int K, double *zi_out)
 {
-    double M[8][9];
+    long double M[8][9], zi[8];
     for (int i = 0; i < K; ++i) {
         for (int j = 0; j < K; ++j) {
             // companion(a)[0][j] = -a[j+1]; companion[i][i-1] = 1;  use its transpose
-            double compT = (j == 0 ? -a[i + 1] : 0.0) + ((i + 1 == j) ? 1.0 : 0.0);
-            M[i][j] = (i == j ? 1.0 : 0.0) - compT;
+            long double compT = (j == 0 ? -(long double)a[i + 1] : 0.0L) + ((i + 1 == j) ? 1.0L : 0.0L);
+            M[i][j] = (i == j ? 1.0L : 0.0L) - compT;
         }
-        M[i][K] = b[i + 1] - a[i + 1] * b[0];
+        M[i][K] = (long double)b[i + 1] - (long double)a[i + 1] * (long double)b[0];
     }
     for (int c = 0; c < K; ++c) {
         int piv = c;
         for (int r = c + 1; r < K; ++r)
-            if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+            if (std::fabs((double)M[r][c]) > std::fabs((double)M[piv][c])) piv = r;
         if (piv != c)
             for (int j = 0; j <= K; ++j) std::swap(M[c][j], M[piv][j]);
         for (int r = c + 1; r < K; ++r) {
-            double f = M[r][c] / M[c][c];
+            long double f = M[r][c] / M[c][c];
             for (int j = c; j <= K; ++j) M[r][j] -= f * M[c][j];
         }
     }
     for (int r = K - 1; r >= 0; --r) {
-        double s = M[r][K];
+        long double s = M[r][K];
         for (int j = r + 1; j < K; ++j) s -= M[r][j] * zi[j];
         zi[r] = s / M[r][r];
     }
+    for (int r = 0; r < K; ++r) zi_out[r] = (double)zi[r];
 }
 
 // cheby1(8, rp, Wn, output='sos') + sosfilt_zi
@@ -143,7 +144,12 @@ static inline Sos4 design_cheby1_8(double rp, double Wn)
 }
 
 struct Tf4 {
-    double b[5], a[5], zi[4];
+    double b[5], a[5], zi[4];  // transfer-function form, as scipy.signal.butter returns it
+    // The same filter as two cascaded biquads (what the device runs): the order-4 companion form
+    // has ~1e4 transient growth for narrow cutoffs, which a blocked evaluation would square;
+    // biquad coordinates keep the carried states well conditioned.
+    double sos[2][6];
+    double soszi[2][2];
 };
 
 // np.poly of a root list (sequential convolution with [1, -r])
@@ -181,6 +187,29 @@ static inline Tf4 design_butter4(double Wn)
         out.a[i] = ap[i].re;
     }
     lfilter_zi(out.b, out.a, N, out.zi);
+    // biquad form: conjugate pairs, the pair closest to the unit circle last (zpk2sos order)
+    std::vector<cplx> pos;
+    for (auto &pp : p)
+        if (pp.im > 0) pos.push_back(pp);
+    std::sort(pos.begin(), pos.end(), [](cplx x, cplx y) {
+        return std::fabs(1 - std::hypot(x.re, x.im)) > std::fabs(1 - std::hypot(y.re, y.im));
+    });
+    double scale = 1.0;
+    for (int si = 0; si < 2; ++si) {
+        const cplx p1 = pos[si];
+        const double g = si == 0 ? k : 1.0;
+        out.sos[si][0] = g; out.sos[si][1] = 2 * g; out.sos[si][2] = g;
+        out.sos[si][3] = 1.0;
+        out.sos[si][4] = -(p1.re + p1.re);
+        out.sos[si][5] = p1.re * p1.re + p1.im * p1.im;
+        double zi2[2];
+        lfilter_zi(&out.sos[si][0], &out.sos[si][3], 2, zi2);
+        out.soszi[si][0] = scale * zi2[0];
+        out.soszi[si][1] = scale * zi2[1];
+        const double bs = (out.sos[si][0] + out.sos[si][1]) + out.sos[si][2];
+        const double as = (out.sos[si][3] + out.sos[si][4]) + out.sos[si][5];
+        scale *= bs / as;
+    }
     return out;
 }
 

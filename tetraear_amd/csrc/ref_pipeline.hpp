@@ -53,8 +53,8 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     if (h.lpf) {
         // filter_signal(samples, 25000, current_rate)  (processor.py:264)
         RawLoader<FMT_CF64, false> l2{B.y, h.n_dec, nullptr, h.rate_dec};
-        be.template zp_block<4, 1, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
-        be.template zp_carry<4, 1>(B.lpf_params, h.lpf_t.p.nb, rows);
+        be.template zp_block<2, 2, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
+        be.template zp_carry<2, 2>(B.lpf_params, h.lpf_t.p.nb, rows);
         be.template zp_fixup<4>(B.lpf_params, rows, h.n_dec, B.z, h.n_dec, nullptr, h.rate_dec);
         zin = B.z;
     }

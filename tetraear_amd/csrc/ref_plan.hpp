@@ -10,7 +10,7 @@
 namespace tdm {
 
 constexpr int kLDec = 32;  // samples per lane, decimator stage (4 biquads)
-constexpr int kLLpf = 32;  // samples per lane, channel-filter stage (order-4 tf)
+constexpr int kLLpf = 32;  // samples per lane, channel-filter stage (order 4 = 2 biquads)
 constexpr int kEdgeSos = 27;  // sosfiltfilt pad for 4 sections: 3*(2*4+1)
 constexpr int kEdgeTf = 15;   // filtfilt pad for order 4: 3*5
 constexpr double kSymbolRate = 18000.0;
@@ -45,13 +45,17 @@ inline ZpFilterDesc desc_from_sos(const Sos4 &s)
     return f;
 }
 
+// the order-4 channel filter runs as its two-biquad factorisation (see Tf4 in design.hpp)
 inline ZpFilterDesc desc_from_tf(const Tf4 &t)
 {
     ZpFilterDesc f{};
-    f.nsec = 1;
-    f.K = 4;
-    for (int k = 0; k < 5; ++k) { f.b[0][k] = t.b[k]; f.a[0][k] = t.a[k]; }
-    for (int k = 0; k < 4; ++k) f.zi[0][k] = t.zi[k];
+    f.nsec = 2;
+    f.K = 2;
+    for (int i = 0; i < 2; ++i) {
+        for (int k = 0; k < 3; ++k) { f.b[i][k] = t.sos[i][k]; f.a[i][k] = t.sos[i][3 + k]; }
+        f.zi[i][0] = t.soszi[i][0];
+        f.zi[i][1] = t.soszi[i][1];
+    }
     return f;
 }
 

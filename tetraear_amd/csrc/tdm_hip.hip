@@ -205,13 +205,13 @@ struct HipBackend {
     template <int K, int NSEC, int L, int EDGE, class Loader>
     void zp_block(const ZpParams &P, Loader ld, int nb, int rows)
     {
-        Scope s(*this, K == 2 ? ST_DEC_BLOCK : ST_LPF_BLOCK);
+        Scope s(*this, NSEC == 4 ? ST_DEC_BLOCK : ST_LPF_BLOCK);
         hipLaunchKernelGGL((k_zp_block<K, NSEC, L, EDGE, Loader>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
     }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
     {
-        Scope s(*this, K == 2 ? ST_DEC_CARRY : ST_LPF_CARRY);
+        Scope s(*this, NSEC == 4 ? ST_DEC_CARRY : ST_LPF_CARRY);
         const int64_t threads = (int64_t)rows * nb * 2;
         const unsigned blocks = (unsigned)((threads + 255) / 256);
         hipLaunchKernelGGL((k_zp_carry<K, NSEC, true>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
@@ -575,8 +575,8 @@ int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, do
         be.zp_carry<2, 4>(dz.params, t.p.nb, 1);
         be.zp_fixup<8>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
     } else {
-        be.zp_block<4, 1, kLLpf, kEdgeTf>(dz.params, ld, t.p.nb, 1);
-        be.zp_carry<4, 1>(dz.params, t.p.nb, 1);
+        be.zp_block<2, 2, kLLpf, kEdgeTf>(dz.params, ld, t.p.nb, 1);
+        be.zp_carry<2, 2>(dz.params, t.p.nb, 1);
         be.zp_fixup<4>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
     }
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
