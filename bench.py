@@ -118,16 +118,8 @@ def main():
     hard, soft, n_soft, bp, mm = bd.download()
     sym_per_step = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        s = torch.tensor([sym_per_step], device="cuda", dtype=torch.int64)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        total_sym_per_step = int(s.item())
-    else:
-        total_sym_per_step = sym_per_step
+    from tetraear_amd.shard import reduce_job
+    dt, total_sym_per_step = reduce_job(dist, dt, sym_per_step, device="cuda" if dist is not None else None)
 
     if rank == 0:
         value = total_sym_per_step * args.steps / dt / 1e6
