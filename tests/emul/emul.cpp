@@ -23,7 +23,7 @@ struct Group {
     int nt;
     std::barrier<> bar;
     std::vector<double> slots;
-    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16) {}
+    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024) {}
 };
 
 struct EmuWaveComm {
@@ -52,6 +52,7 @@ struct EmuBlockComm {
     int tid() const { return t; }
     int nthreads() const { return g->nt; }
     void sync() { g->bar.arrive_and_wait(); }
+    double &lds(int i) { return g->slots[(size_t)g->nt * 2 + i]; }
     template <class F>
     double reduce(double v, F f)
     {
@@ -98,19 +99,30 @@ struct EmuBackend {
             for (int b = 0; b < nb; ++b)
                 for (int ch = 0; ch < 2; ++ch) zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
     }
-    template <int D>
+    template <int D, int L>
     void zp_fixup(const ZpParams &P, int rows, int64_t n_out, double *out, int64_t out_row_stride,
                   const double *freq_offset, double fs_out)
     {
         for (int row = 0; row < rows; ++row)
             for (int64_t j = 0; j < n_out; ++j)
-                zp_fixup_body<D>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
+                zp_fixup_body<D, L>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
     }
     template <class Loader>
     void convert(Loader ld, int rows, int64_t n, double *out, const double *freq_offset, double fs)
     {
         for (int row = 0; row < rows; ++row)
             for (int64_t j = 0; j < n; ++j) convert_body(ld, row, j, out + (int64_t)row * n * 2, freq_offset, fs);
+    }
+    template <int D, int L>
+    void power_fixup(const ZpParams &P, int rows, int64_t n, double *z, int sps, double *partials, int n_pblk)
+    {
+        for (int row = 0; row < rows; ++row)
+            for (int b = 0; b < n_pblk; ++b)
+                run_group(kPowThreads, [&](int t, Group *g) {
+                    EmuBlockComm cm{g, t};
+                    power_fixup_body<D, L>(P, cm, row, b, z + (int64_t)row * n * 2, n, sps,
+                                           partials + (int64_t)row * n_pblk * kMaxSps);
+                });
     }
     void finish(const FinishArgs &fa, int rows)
     {
@@ -162,6 +174,8 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
     std::vector<double> y((size_t)rows * h.n_dec * 2 + 2, nan), z((size_t)rows * h.n_dec * 2 + 2, nan);
     B.y = y.data();
     B.z = z.data();
+    std::vector<double> partials((size_t)rows * ((h.n_dec + kPowThreads - 1) / kPowThreads + 1) * kMaxSps, nan);
+    B.partials = partials.data();
     RefIO io{iq, stride, pre_shift, freq_offset, hard, soft, n_soft, best_phase, min_margin};
     EmuBackend be;
     run_ref(be, h, rows, fmt, B, io);
@@ -182,7 +196,7 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         hz.bind(1);
         be.zp_block<2, 4, kLDec, kEdgeSos>(hz.t.p, ld, hz.t.p.nb, 1);
         be.zp_carry<2, 4>(hz.t.p, hz.t.p.nb, 1);
-        be.zp_fixup<8>(hz.t.p, 1, n_out, y, n_out, nullptr, fs);
+        be.zp_fixup<8, kLDec>(hz.t.p, 1, n_out, y, n_out, nullptr, fs);
     } else {
         if (n <= kEdgeTf) return -1;
         Tf4 t = design_butter4(butter_cutoff(bandwidth, fs));
@@ -190,7 +204,7 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         hz.bind(1);
         be.zp_block<2, 2, kLLpf, kEdgeTf>(hz.t.p, ld, hz.t.p.nb, 1);
         be.zp_carry<2, 2>(hz.t.p, hz.t.p.nb, 1);
-        be.zp_fixup<4>(hz.t.p, 1, n, y, n, nullptr, fs);
+        be.zp_fixup<4, kLLpf>(hz.t.p, 1, n, y, n, nullptr, fs);
     }
     return 0;
 }

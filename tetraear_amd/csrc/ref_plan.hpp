@@ -32,32 +32,39 @@ struct RefPlanHost {
     ZpHostTables lpf_t;     // valid if lpf
 };
 
-inline ZpFilterDesc desc_from_sos(const Sos4 &s)
+// sos rows b = g*[1,2,1], a -> device form (unit numerators, one input gain, matching zi)
+inline ZpFilterDesc desc_from_rows(const double (*sos)[6], int nsec)
 {
     ZpFilterDesc f{};
-    f.nsec = 4;
+    f.nsec = nsec;
     f.K = 2;
-    for (int i = 0; i < 4; ++i) {
-        for (int k = 0; k < 3; ++k) { f.b[i][k] = s.sos[i][k]; f.a[i][k] = s.sos[i][3 + k]; }
-        f.zi[i][0] = s.zi[i][0];
-        f.zi[i][1] = s.zi[i][1];
+    long double g = 1.0L;
+    double scale = 1.0;
+    for (int i = 0; i < nsec; ++i) {
+        g *= (long double)sos[i][0];
+        f.b[i][0] = 1.0; f.b[i][1] = 2.0; f.b[i][2] = 1.0;
+        for (int k = 0; k < 3; ++k) f.a[i][k] = sos[i][3 + k];
+        double zi2[2];
+        lfilter_zi(f.b[i], f.a[i], 2, zi2);
+        f.zi[i][0] = scale * zi2[0];
+        f.zi[i][1] = scale * zi2[1];
+        scale *= 4.0 / ((f.a[i][0] + f.a[i][1]) + f.a[i][2]);
     }
+    f.in_gain = (double)(g * g);
     return f;
 }
 
-// the order-4 channel filter runs as its two-biquad factorisation (see Tf4 in design.hpp)
-inline ZpFilterDesc desc_from_tf(const Tf4 &t)
+inline bool rows_are_lp121(const double (*sos)[6], int nsec)
 {
-    ZpFilterDesc f{};
-    f.nsec = 2;
-    f.K = 2;
-    for (int i = 0; i < 2; ++i) {
-        for (int k = 0; k < 3; ++k) { f.b[i][k] = t.sos[i][k]; f.a[i][k] = t.sos[i][3 + k]; }
-        f.zi[i][0] = t.soszi[i][0];
-        f.zi[i][1] = t.soszi[i][1];
-    }
-    return f;
+    for (int i = 0; i < nsec; ++i)
+        if (sos[i][1] != 2 * sos[i][0] || sos[i][2] != sos[i][0] || sos[i][3] != 1.0) return false;
+    return true;
 }
+
+inline ZpFilterDesc desc_from_sos(const Sos4 &s) { return desc_from_rows(s.sos, 4); }
+
+// the order-4 channel filter runs as its two-biquad factorisation (see Tf4 in design.hpp)
+inline ZpFilterDesc desc_from_tf(const Tf4 &t) { return desc_from_rows(t.sos, 2); }
 
 inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidth = 25000.0)
 {

@@ -68,7 +68,9 @@ struct WaveComm {
 constexpr int kFinishThreads = 256;
 
 struct BlockComm {
-    double *sm;  // [kFinishThreads / 64] LDS
+    double *sm;  // [kFinishThreads / 64] LDS (reductions)
+    double *buf; // [kPowThreads] LDS (power_fixup scratch) or null
+    __device__ __forceinline__ double &lds(int i) { return buf[i]; }
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
     __device__ __forceinline__ int nthreads() const { return blockDim.x; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void k_zp_carry(const ZpParams P, int nb, int 
         zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
 }
 
-template <int D>
+template <int D, int L>
 __global__ __launch_bounds__(256) void k_zp_fixup(const ZpParams P, int64_t n_out, double *out,
                                                   int64_t out_row_stride, const double *freq_offset,
                                                   double fs_out)
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void k_zp_fixup(const ZpParams P, int64_t n_ou
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
     if (j >= n_out) return;
-    zp_fixup_body<D>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
+    zp_fixup_body<D, L>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
 }
 
 template <class Loader>
@@ -142,8 +144,19 @@ __global__ __launch_bounds__(256) void k_convert(const Loader ld, int64_t n, dou
 __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs fa)
 {
     __shared__ double sm[kFinishThreads / 64];
-    BlockComm cm{sm};
+    BlockComm cm{sm, nullptr};
     finish_body(fa, cm, (int)blockIdx.x);
+}
+
+template <int D, int L>
+__global__ __launch_bounds__(kPowThreads) void k_power_fixup(const ZpParams P, int64_t n, double *z, int sps,
+                                                            double *partials, int n_pblk)
+{
+    __shared__ double buf[kPowThreads];
+    BlockComm cm{nullptr, buf};
+    const int row = blockIdx.y;
+    power_fixup_body<D, L>(P, cm, row, (int)blockIdx.x, z + (int64_t)row * n * 2, n, sps,
+                           partials + (int64_t)row * n_pblk * kMaxSps);
 }
 
 __global__ __launch_bounds__(256) void k_shift(const double *x, double *y, int64_t n, double f, double fs)
@@ -217,12 +230,12 @@ struct HipBackend {
         hipLaunchKernelGGL((k_zp_carry<K, NSEC, true>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
         hipLaunchKernelGGL((k_zp_carry<K, NSEC, false>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
     }
-    template <int D>
+    template <int D, int L>
     void zp_fixup(const ZpParams &P, int rows, int64_t n_out, double *out, int64_t out_row_stride,
                   const double *freq_offset, double fs_out)
     {
         Scope s(*this, D == 8 ? ST_DEC_FIXUP : ST_LPF_FIXUP);
-        hipLaunchKernelGGL((k_zp_fixup<D>), dim3((unsigned)((n_out + 255) / 256), rows), dim3(256), 0, stream,
+        hipLaunchKernelGGL((k_zp_fixup<D, L>), dim3((unsigned)((n_out + 255) / 256), rows), dim3(256), 0, stream,
                            P, n_out, out, out_row_stride, freq_offset, fs_out);
     }
     template <class Loader>
@@ -231,6 +244,13 @@ struct HipBackend {
         Scope s(*this, ST_CONVERT);
         hipLaunchKernelGGL((k_convert<Loader>), dim3((unsigned)((n + 255) / 256), rows), dim3(256), 0, stream, ld, n,
                            out, freq_offset, fs);
+    }
+    template <int D, int L>
+    void power_fixup(const ZpParams &P, int rows, int64_t n, double *z, int sps, double *partials, int n_pblk)
+    {
+        Scope s(*this, ST_LPF_FIXUP);
+        hipLaunchKernelGGL((k_power_fixup<D, L>), dim3(n_pblk, rows), dim3(kPowThreads), 0, stream, P, n, z, sps,
+                           partials, n_pblk);
     }
     void finish(const FinishArgs &fa, int rows)
     {
@@ -281,7 +301,7 @@ struct tdm_plan {
     RefPlanHost h;
     int rows = 0, fmt = 0, mode = 0, device = 0;
     DevZp dec, lpf;
-    double *d_y = nullptr, *d_z = nullptr;
+    double *d_y = nullptr, *d_z = nullptr, *d_partials = nullptr;
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -301,7 +321,7 @@ static void plan_free(tdm_plan *p)
     (void)hipSetDevice(p->device);
     p->dec.destroy();
     p->lpf.destroy();
-    void *ptrs[] = {p->d_y, p->d_z, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    void *ptrs[] = {p->d_y, p->d_z, p->d_partials, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -355,6 +375,8 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     const size_t nd = (size_t)n_carriers * h.n_dec * 2 * sizeof(double);
     HIP_TRY(hipMalloc(&p->d_y, nd));
     HIP_TRY(hipMalloc(&p->d_z, nd));
+    HIP_TRY(hipMalloc(&p->d_partials, (size_t)n_carriers * ((h.n_dec + kPowThreads - 1) / kPowThreads + 1) * kMaxSps *
+                                          sizeof(double)));
     *out = p.release();
     return TDM_OK;
 }
@@ -401,6 +423,7 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     B.lpf_params = plan->lpf.params;
     B.y = plan->d_y;
     B.z = plan->d_z;
+    B.partials = plan->d_partials;
     RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin};
     run_ref(be, plan->h, plan->rows, plan->fmt, B, io);
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
@@ -573,11 +596,11 @@ int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, do
     if (sos) {
         be.zp_block<2, 4, kLDec, kEdgeSos>(dz.params, ld, t.p.nb, 1);
         be.zp_carry<2, 4>(dz.params, t.p.nb, 1);
-        be.zp_fixup<8>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
+        be.zp_fixup<8, kLDec>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
     } else {
         be.zp_block<2, 2, kLLpf, kEdgeTf>(dz.params, ld, t.p.nb, 1);
         be.zp_carry<2, 2>(dz.params, t.p.nb, 1);
-        be.zp_fixup<4>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
+        be.zp_fixup<4, kLLpf>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
     }
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
     HIP_TRY(hipDeviceSynchronize());

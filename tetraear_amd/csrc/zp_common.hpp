@@ -47,6 +47,7 @@ struct ZpParams {
     double b[kMaxSec][kMaxOrd + 1];
     double a[kMaxSec][kMaxOrd + 1];
     double zi[kMaxSec][kMaxOrd];  // steady-state start per unit input (sosfilt_zi / lfilter_zi)
+    double in_gain;               // applied once to every input sample (see ZpFilterDesc)
     // ---- geometry (padded extended domain: index = P0 + ext index)
     int64_t n;         // signal samples per row
     int32_t edge;      // odd-extension length each side (27 cheby sos, 15 butter tf)
@@ -61,9 +62,15 @@ struct ZpParams {
     int32_t carry_terms; // series length of the cross-block carries (see zp_kernels.hpp)
     // ---- tables (pointers valid where the kernels run)
     const double *Mpow;     // [nsec][6][K*K]   A_s^(L*2^j), row-major
-    const double *cfull;    // [64L][D]         zero-input response of the whole cascade
-    const double *T1_reg;   // [64L][D]         fwd carry-in -> block-local fwd->bwd output
-    const double *T1_last;  // [len_last][D]
+    // carry-response tables, one row of D doubles per in-block offset m, stored PHASE-MAJOR:
+    // row(m) = (m % out_stride) * R + m / out_stride, so that consecutive outputs (m advancing by
+    // out_stride) read consecutive rows.  "reg" = full 64L-sample block, "last" = the last block.
+    const double *cf_last;  // [D]      forward zero-input response at offset len_last-1
+    const double *T1_reg;   // [..][D]  fwd carry-in -> block-local fwd->bwd output at offset m
+    const double *T2_reg;   // [..][D]  bwd carry-in -> output at offset m (backward zero-input resp.)
+    const double *T1_last;
+    const double *T2_last;
+    int32_t R_reg, R_last;  // rows per phase: ceil(len / out_stride)
     const double *Mf;       // [D][D] A^(64L)
     const double *Mb_last;  // [D][D] A^(len_last)
     const double *U_reg;    // [D][D] fwd carry-in -> bwd end state of the block
@@ -94,6 +101,17 @@ TDM_HD T df2t_step(const T *b, const T *a, T x, T *z)
         z[K - 1] = b[K] * x - a[K] * y;
         return y;
     }
+}
+
+// Biquad with numerator exactly [1, 2, 1] (every section of a Butterworth / Chebyshev-I lowpass
+// once its gain is pulled out): 4 fp64 operations per real sample instead of 6.
+template <typename T>
+TDM_HD T lp121_step(const T *a, T x, T *z)
+{
+    const T y = x + z[0];
+    z[0] = (2 * x + z[1]) - a[1] * y;
+    z[1] = x - a[2] * y;
+    return y;
 }
 
 // Zero-input step of the same section: returns the output for x == 0 and advances the state.

@@ -211,6 +211,9 @@ struct RawLoader {
 #pragma unroll
             for (int i = 0; i < L; ++i) { xr[i] = tmp[2 * i]; xi[i] = tmp[2 * i + 1]; }
         }
+        const double g = P.in_gain;  // total gain of both passes, applied once (see ZpFilterDesc)
+#pragma unroll
+        for (int i = 0; i < L; ++i) { xr[i] *= g; xi[i] *= g; }
     }
 };
 
@@ -239,9 +242,10 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
     // ---------------- forward: sections in cascade order ----------------
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
-        double b[K + 1], a[K + 1];
+        static_assert(K == 2, "device sections are biquads with numerator [1,2,1]");
+        double a[K + 1];
 #pragma unroll
-        for (int k = 0; k <= K; ++k) { b[k] = P.b[s][k]; a[k] = P.a[s][k]; }
+        for (int k = 0; k <= K; ++k) a[k] = P.a[s][k];
         double zr[K], zq[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) { zr[k] = 0; zq[k] = 0; }
@@ -251,8 +255,8 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 #pragma unroll
                 for (int k = 0; k < K; ++k) { zr[k] = P.zi[s][k] * e0r; zq[k] = P.zi[s][k] * e0i; }
             }
-            xr[i] = df2t_step<K, double>(b, a, xr[i], zr);
-            xi[i] = df2t_step<K, double>(b, a, xi[i], zq);
+            xr[i] = lp121_step<double>(a, xr[i], zr);
+            xi[i] = lp121_step<double>(a, xi[i], zq);
         }
         // inclusive scan of end states: I_p = sum_{j<=p} M^(p-j) e_j
 #pragma unroll
@@ -302,16 +306,17 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
     // ---------------- backward: same cascade, time reversed ----------------
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
-        double b[K + 1], a[K + 1];
+        static_assert(K == 2, "device sections are biquads with numerator [1,2,1]");
+        double a[K + 1];
 #pragma unroll
-        for (int k = 0; k <= K; ++k) { b[k] = P.b[s][k]; a[k] = P.a[s][k]; }
+        for (int k = 0; k <= K; ++k) a[k] = P.a[s][k];
         double zr[K], zq[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) { zr[k] = 0; zq[k] = 0; }
 #pragma unroll
         for (int i = L - 1; i >= 0; --i) {
-            xr[i] = df2t_step<K, double>(b, a, xr[i], zr);
-            xi[i] = df2t_step<K, double>(b, a, xi[i], zq);
+            xr[i] = lp121_step<double>(a, xr[i], zr);
+            xi[i] = lp121_step<double>(a, xi[i], zq);
         }
 #pragma unroll
         for (int j = 0; j < kScanSteps; ++j) {
@@ -411,7 +416,7 @@ TDM_HD void zp_carry_fwd_body(const ZpParams &P, int row, int b, int ch)
     if (b == nb - 1) {
         // true forward output at the last extended sample -> start state of the backward pass
         double fl = P.flast[(int64_t)row * 2 + ch];
-        const auto c = TDM_CPTR(P.cfull + (size_t)(P.len_last - 1) * D);
+        const auto c = TDM_CPTR(P.cf_last);
 #pragma unroll
         for (int k = 0; k < D; ++k) fl += c[k] * G[k];
         double *Hb = P.Hb + base;
@@ -464,28 +469,38 @@ TDM_HD void zp_carry_bwd_body(const ZpParams &P, int row, int b, int ch)
 // Fix-up body: out[j] = y0[j] + T1[m].Gf_b + T2[m].Hb_b, then (optionally) process()'s
 // freq_offset NCO at the output rate (processor.py:260-261).  One thread per output sample.
 // ------------------------------------------------------------------------------------------
-template <int D>
-TDM_HD void zp_fixup_body(const ZpParams &P, int row, int64_t j, double *out /* row base */,
-                          const double *freq_offset /* per row or null */, double fs_out)
+template <int D, int L>
+TDM_HD void zp_fixup_value(const ZpParams &P, int row, int64_t j, double &re, double &im)
 {
-    const int Bn = kWave * P.L;
-    const int64_t pos = P.k0L + j * P.out_stride;
+    constexpr int Bn = kWave * L;
+    const int q = P.out_stride;
+    const int64_t pos = P.k0L + j * q;
     const int b = (int)(pos / Bn);
     const int m = (int)(pos - (int64_t)b * Bn);
     const bool last = (b == P.nb - 1);
-    const int len = last ? P.len_last : Bn;
-    const double *T1 = (last ? P.T1_last : P.T1_reg) + (size_t)m * D;
-    const double *T2 = P.cfull + (size_t)(len - 1 - m) * D;
+    const unsigned R = last ? P.R_last : P.R_reg;
+    const size_t r = ((unsigned)m % (unsigned)q) * (size_t)R + (unsigned)m / (unsigned)q;
+    const double *T1 = (last ? P.T1_last : P.T1_reg) + r * D;
+    const double *T2 = (last ? P.T2_last : P.T2_reg) + r * D;
     const int64_t cb = ((int64_t)row * P.nb + b) * D * 2;
     const double *Gf = P.Gf + cb;
     const double *Hb = P.Hb + cb;
     const double *y0 = P.y0 + ((int64_t)row * P.n_out + j) * 2;
-    double re = y0[0], im = y0[1];
+    re = y0[0];
+    im = y0[1];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         re += T1[k] * Gf[k * 2] + T2[k] * Hb[k * 2];
         im += T1[k] * Gf[k * 2 + 1] + T2[k] * Hb[k * 2 + 1];
     }
+}
+
+template <int D, int L>
+TDM_HD void zp_fixup_body(const ZpParams &P, int row, int64_t j, double *out /* row base */,
+                          const double *freq_offset /* per row or null */, double fs_out)
+{
+    double re, im;
+    zp_fixup_value<D, L>(P, row, j, re, im);
     if (freq_offset) {
         const double f = freq_offset[row];
         if (f != 0.0) nco_rotate(re, im, j, f, fs_out);
@@ -512,7 +527,13 @@ struct FinishArgs {
     int32_t *n_soft;      // [rows]
     int32_t *best_phase;  // [rows] or null
     double *min_margin;   // [rows] or null
+    // optional per-block partial phase powers made by power_fixup_body (deterministic order):
+    const double *partials;  // [rows][n_pblk][kMaxSps] or null -> powers are computed here
+    int32_t n_pblk;
 };
+
+constexpr int kMaxSps = 32;       // phases a partial-power record holds
+constexpr int kPowThreads = 256;  // threads (= samples) per partial-power block
 
 TDM_HD uint8_t dqpsk_decide(double cr, double ci, double pr, double pi_, double &margin)
 {
@@ -549,18 +570,37 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
     const int64_t sps = A.sps;
     if (A.do_extract && n > 0 && sps > 1) {
         const int64_t step = sps / 8 > 1 ? sps / 8 : 1;
-        double maxp = -1.0;
-        for (int64_t ph = 0; ph < sps; ph += step) {
-            const int64_t np_ = (n - ph) / sps;
-            if (n - ph <= 0 || np_ <= 0) continue;
-            double acc = 0;
-            for (int64_t k = tid; k < np_; k += nt) {
-                const double *s = z + (ph + k * sps) * 2;
-                const double m = hypot(s[0], s[1]);
-                acc += m * m;
+        if (A.partials) {
+            // one thread per candidate phase sums that phase's block partials in block order
+            double power = -1.0;
+            if (tid < sps && tid % step == 0) {
+                const int64_t np_ = (n - tid) / sps;
+                if (n - tid > 0 && np_ > 0) {
+                    const double *pp = A.partials + (int64_t)row * A.n_pblk * kMaxSps + tid;
+                    double acc = 0;
+                    for (int b = 0; b < A.n_pblk; ++b) acc += pp[(int64_t)b * kMaxSps];
+                    power = acc / (double)np_;
+                }
             }
-            const double power = cm.reduce_sum(acc) / (double)np_;
-            if (power > maxp) { maxp = power; best = ph; }  // identical on every thread
+            // "first strictly greater wins" == the lowest phase among those with the maximum power
+            const double mxp = cm.reduce_max(power);
+            const double cand = (power >= 0 && power == mxp) ? (double)tid : 1e9;
+            const double first = cm.reduce_min(cand);
+            best = first < 1e8 ? (int64_t)first : 0;
+        } else {
+            double maxp = -1.0;
+            for (int64_t ph = 0; ph < sps; ph += step) {
+                const int64_t np_ = (n - ph) / sps;
+                if (n - ph <= 0 || np_ <= 0) continue;
+                double acc = 0;
+                for (int64_t k = tid; k < np_; k += nt) {
+                    const double *s = z + (ph + k * sps) * 2;
+                    const double m = hypot(s[0], s[1]);
+                    acc += m * m;
+                }
+                const double power = cm.reduce_sum(acc) / (double)np_;
+                if (power > maxp) { maxp = power; best = ph; }  // identical on every thread
+            }
         }
         ns = (n - best) / sps;
     }
@@ -594,6 +634,43 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
     }
     margin = cm.reduce_min(margin);
     if (tid == 0 && A.min_margin) A.min_margin[row] = margin;
+}
+
+// ------------------------------------------------------------------------------------------
+// Power/fix-up body: z[j] = fix-up value, stored, plus this block's partial sums of |z|^2 per
+// timing phase (extract_symbols' mean powers, processor.py:196-206, summed in a fixed order so the
+// result is reproducible run to run).  One workgroup of kPowThreads threads per kPowThreads samples.
+//   Comm: tid(), sync(), lds(i) -> double& (workgroup-shared scratch of kPowThreads doubles)
+// ------------------------------------------------------------------------------------------
+template <int D, int L, class Comm>
+TDM_HD void power_fixup_body(const ZpParams &P, Comm &cm, int row, int blk, double *z_row, int64_t n, int sps,
+                             double *partials_row /* [n_pblk][kMaxSps] */)
+{
+    const int t = cm.tid();
+    const int64_t j0 = (int64_t)blk * kPowThreads;
+    const int64_t j = j0 + t;
+    double sq = 0;
+    if (j < n) {
+        double re, im;
+        zp_fixup_value<D, L>(P, row, j, re, im);
+        z_row[j * 2] = re;
+        z_row[j * 2 + 1] = im;
+        const double m = hypot(re, im);
+        sq = m * m;
+    }
+    cm.lds(t) = sq;
+    cm.sync();
+    if (t < kMaxSps) {
+        double acc = 0;
+        if (t < sps) {
+            const int64_t np_ = (n - t) / sps;           // samples phase t owns: j = t + k*sps, k < np_
+            const int64_t lim = t + np_ * (int64_t)sps;  // first j NOT owned
+            int64_t first = ((t - j0) % sps + sps) % sps; // first in-block index with (j0+i) % sps == t
+            for (int64_t i = first; i < kPowThreads; i += sps)
+                if (j0 + i < lim) acc += cm.lds((int)i);
+        }
+        partials_row[(int64_t)blk * kMaxSps + t] = acc;
+    }
 }
 
 // frequency_shift as a stand-alone elementwise op (public method, processor.py:85-100)

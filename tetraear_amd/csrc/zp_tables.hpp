@@ -10,22 +10,29 @@
 
 namespace tdm {
 
+// Device form of a lowpass cascade.  The reference's sections are b = g_s*[1,2,1]; the zero-phase
+// operator is linear, so the total gain of both passes, (prod g_s)^2, is applied once to the input
+// samples (`in_gain`) and every section runs with b = [1,2,1] (lp121_step).  `zi` is the
+// steady-state start of THAT cascade per unit input (sosfilt_zi of the unit-numerator sections),
+// which is the same physical start condition scipy's zi*x0 sets up.
 struct ZpFilterDesc {
     int nsec, K;
     double b[kMaxSec][kMaxOrd + 1];
     double a[kMaxSec][kMaxOrd + 1];
     double zi[kMaxSec][kMaxOrd];
+    double in_gain;
 };
 
 struct ZpHostTables {
     ZpParams p;                // table/work pointers are null until patched by the owner
     std::vector<double> blob;  // all tables, concatenated
-    size_t off_Mpow, off_cfull, off_T1reg, off_T1last, off_Mf, off_Mblast, off_Ureg, off_Ulast;
+    size_t off_Mpow, off_cflast, off_T1reg, off_T2reg, off_T1last, off_T2last, off_Mf, off_Mblast, off_Ureg, off_Ulast;
     // point p's table pointers into a copy of blob that lives at `base`
     void bind(ZpParams &q, const double *base) const
     {
-        q.Mpow = base + off_Mpow; q.cfull = base + off_cfull;
-        q.T1_reg = base + off_T1reg; q.T1_last = base + off_T1last; q.Mf = base + off_Mf;
+        q.Mpow = base + off_Mpow; q.cf_last = base + off_cflast;
+        q.T1_reg = base + off_T1reg; q.T2_reg = base + off_T2reg;
+        q.T1_last = base + off_T1last; q.T2_last = base + off_T2last; q.Mf = base + off_Mf;
         q.Mb_last = base + off_Mblast; q.U_reg = base + off_Ureg; q.U_last = base + off_Ulast;
     }
 };
@@ -52,9 +59,15 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
     std::vector<double> &blob = t.blob;
     auto reserve = [&](size_t n) { size_t o = blob.size(); blob.resize(o + n, 0.0); return o; };
     t.off_Mpow = reserve((size_t)f.nsec * kScanSteps * K * K);
-    t.off_cfull = reserve((size_t)Bn * D);
-    t.off_T1reg = reserve((size_t)Bn * D);
-    t.off_T1last = reserve((size_t)len_last * D);
+    const int qs = p.out_stride;
+    p.R_reg = (Bn + qs - 1) / qs;
+    p.R_last = (len_last + qs - 1) / qs;
+    t.off_cflast = reserve((size_t)D);
+    t.off_T1reg = reserve((size_t)qs * p.R_reg * D);
+    t.off_T2reg = reserve((size_t)qs * p.R_reg * D);
+    t.off_T1last = reserve((size_t)qs * p.R_last * D);
+    t.off_T2last = reserve((size_t)qs * p.R_last * D);
+    auto prow = [&](int m, int R) { return (size_t)(m % qs) * R + (size_t)(m / qs); };
     t.off_Mf = reserve((size_t)D * D);
     t.off_Mblast = reserve((size_t)D * D);
     t.off_Ureg = reserve((size_t)D * D);
@@ -84,7 +97,7 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
         for (int i = 0; i < Bn; ++i) {
             long double y = cascade_step<K>(f, 0.0L, Z);
             zir[i] = y;
-            blob[t.off_cfull + (size_t)i * D + k] = (double)y;
+            if (i + 1 == len_last) blob[t.off_cflast + k] = (double)y;
             if (i + 1 == len_last)
                 for (int r = 0; r < D; ++r) blob[t.off_Mblast + r * D + k] = (double)Z[r];
         }
@@ -93,10 +106,14 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
         for (int v = 0; v < 2; ++v) {
             const int len = v ? len_last : Bn;
             long double W[kMaxD] = {0};
-            const size_t off = v ? t.off_T1last : t.off_T1reg;
+            const size_t off1 = v ? t.off_T1last : t.off_T1reg;
+            const size_t off2 = v ? t.off_T2last : t.off_T2reg;
+            const int R = v ? p.R_last : p.R_reg;
             for (int i = len - 1; i >= 0; --i) {
                 long double y = cascade_step<K>(f, zir[i], W);
-                blob[off + (size_t)i * D + k] = (double)y;
+                blob[off1 + prow(i, R) * D + k] = (double)y;
+                // backward zero-input response reaching offset i from the block's right end
+                blob[off2 + prow(i, R) * D + k] = (double)zir[len - 1 - i];
             }
             const size_t uo = v ? t.off_Ulast : t.off_Ureg;
             for (int r = 0; r < D; ++r) blob[uo + r * D + k] = (double)W[r];
@@ -118,6 +135,7 @@ inline ZpHostTables build_zp_tables(const ZpFilterDesc &f, int64_t n, int edge, 
     std::memcpy(p.b, f.b, sizeof(p.b));
     std::memcpy(p.a, f.a, sizeof(p.a));
     std::memcpy(p.zi, f.zi, sizeof(p.zi));
+    p.in_gain = f.in_gain;
     p.n = n;
     p.edge = edge;
     p.L = L;
