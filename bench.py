@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=262144, help="samples per carrier per step")
     ap.add_argument("--fmt", default="cu8", choices=["cu8", "cf32", "cf64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rate", type=float, default=SAMPLE_RATE, help="sample rate (experiments; metric config is 2.4e6)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +92,7 @@ def main():
 
     from tetraear_amd.batch import BatchDemodulator
 
-    bd = BatchDemodulator(SAMPLE_RATE, args.chunk, args.carriers, args.fmt, device=local_rank)
+    bd = BatchDemodulator(args.rate, args.chunk, args.carriers, args.fmt, device=local_rank)
     bd.alloc_device_io()
     iq, foffs = make_batch(args.carriers, args.chunk, args.fmt, rank)
     bd.upload(iq, freq_offsets=foffs)

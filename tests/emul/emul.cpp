@@ -100,12 +100,14 @@ struct EmuBackend {
                 for (int ch = 0; ch < 2; ++ch) zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
     }
     template <int D, int L>
-    void zp_fixup(const ZpParams &P, int rows, int64_t n_out, double *out, int64_t out_row_stride,
+    void zp_fixup(const ZpParams &P, int nb, int rows, double *out, int64_t out_row_stride,
                   const double *freq_offset, double fs_out)
     {
+        const int nt = 7;  // any thread count must give the same result
         for (int row = 0; row < rows; ++row)
-            for (int64_t j = 0; j < n_out; ++j)
-                zp_fixup_body<D, L>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
+            for (int b = 0; b < nb; ++b)
+                for (int t = 0; t < nt; ++t)
+                    zp_fixup_body<D, L>(P, row, b, t, nt, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
     }
     template <class Loader>
     void convert(Loader ld, int rows, int64_t n, double *out, const double *freq_offset, double fs)
@@ -174,7 +176,7 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
     std::vector<double> y((size_t)rows * h.n_dec * 2 + 2, nan), z((size_t)rows * h.n_dec * 2 + 2, nan);
     B.y = y.data();
     B.z = z.data();
-    std::vector<double> partials((size_t)rows * ((h.n_dec + kPowThreads - 1) / kPowThreads + 1) * kMaxSps, nan);
+    std::vector<double> partials((size_t)rows * (h.n_dec / kPowThreads + 16) * kMaxSps, nan);
     B.partials = partials.data();
     RefIO io{iq, stride, pre_shift, freq_offset, hard, soft, n_soft, best_phase, min_margin};
     EmuBackend be;
@@ -196,7 +198,7 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         hz.bind(1);
         be.zp_block<2, 4, kLDec, kEdgeSos>(hz.t.p, ld, hz.t.p.nb, 1);
         be.zp_carry<2, 4>(hz.t.p, hz.t.p.nb, 1);
-        be.zp_fixup<8, kLDec>(hz.t.p, 1, n_out, y, n_out, nullptr, fs);
+        be.zp_fixup<8, kLDec>(hz.t.p, hz.t.p.nb, 1, y, n_out, nullptr, fs);
     } else {
         if (n <= kEdgeTf) return -1;
         Tf4 t = design_butter4(butter_cutoff(bandwidth, fs));
@@ -204,7 +206,7 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         hz.bind(1);
         be.zp_block<2, 2, kLLpf, kEdgeTf>(hz.t.p, ld, hz.t.p.nb, 1);
         be.zp_carry<2, 2>(hz.t.p, hz.t.p.nb, 1);
-        be.zp_fixup<4, kLLpf>(hz.t.p, 1, n, y, n, nullptr, fs);
+        be.zp_fixup<4, kLLpf>(hz.t.p, hz.t.p.nb, 1, y, n, nullptr, fs);
     }
     return 0;
 }

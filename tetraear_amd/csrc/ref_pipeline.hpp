@@ -6,8 +6,8 @@
 //   (ZpParams are passed by value with their pointers already valid where the kernels run)
 //   template<int K,int NSEC,int L,int EDGE,class Loader> void zp_block(const ZpParams&, Loader, int nb, int rows);
 //   template<int K,int NSEC> void zp_carry(const ZpParams&, int nb, int rows);
-//   template<int D,int L> void zp_fixup(const ZpParams&, int rows, int64_t n_out, double* out,
-//                                 int64_t out_row_stride, const double* freq_offset, double fs_out);
+//   template<int D,int L> void zp_fixup(const ZpParams&, int nb, int rows, double* out,
+//                                       int64_t out_row_stride, const double* freq_offset, double fs_out);
 //   template<class Loader> void convert(Loader, int rows, int64_t n, double* out,
 //                                       const double* freq_offset, double fs);
 //   template<int D,int L> void power_fixup(const ZpParams&, int rows, int64_t n, double* z, int sps,
@@ -48,7 +48,7 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
         be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
         // + frequency_shift(samples, freq_offset, current_rate)  (processor.py:260-261)
-        be.template zp_fixup<8, kLDec>(B.dec_params, rows, h.n_dec, B.y, h.n_dec, io.freq_offset, h.rate_dec);
+        be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
     } else {
         be.convert(ld, rows, h.n, B.y, io.freq_offset, h.sample_rate);
     }
@@ -61,11 +61,11 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         be.template zp_block<2, 2, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
         be.template zp_carry<2, 2>(B.lpf_params, h.lpf_t.p.nb, rows);
         if (h.sps > 1 && h.sps <= kMaxSps) {
-            n_pblk = (int)((h.n_dec + kPowThreads - 1) / kPowThreads);
+            n_pblk = h.lpf_t.p.nb * (kWave * kLLpf / kPowThreads);
             be.template power_fixup<4, kLLpf>(B.lpf_params, rows, h.n_dec, B.z, h.sps, B.partials, n_pblk);
             partials = B.partials;
         } else {
-            be.template zp_fixup<4, kLLpf>(B.lpf_params, rows, h.n_dec, B.z, h.n_dec, nullptr, h.rate_dec);
+            be.template zp_fixup<4, kLLpf>(B.lpf_params, h.lpf_t.p.nb, rows, B.z, h.n_dec, nullptr, h.rate_dec);
         }
         zin = B.z;
     }

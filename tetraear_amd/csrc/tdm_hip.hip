@@ -121,14 +121,12 @@ __global__ __launch_bounds__(256) void k_zp_carry(const ZpParams P, int nb, int 
 }
 
 template <int D, int L>
-__global__ __launch_bounds__(256) void k_zp_fixup(const ZpParams P, int64_t n_out, double *out,
-                                                  int64_t out_row_stride, const double *freq_offset,
-                                                  double fs_out)
+__global__ __launch_bounds__(256) void k_zp_fixup(const ZpParams P, double *out, int64_t out_row_stride,
+                                                  const double *freq_offset, double fs_out)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
-    if (j >= n_out) return;
-    zp_fixup_body<D, L>(P, row, j, out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
+    zp_fixup_body<D, L>(P, row, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x,
+                        out + (int64_t)row * out_row_stride * 2, freq_offset, fs_out);
 }
 
 template <class Loader>
@@ -231,12 +229,12 @@ struct HipBackend {
         hipLaunchKernelGGL((k_zp_carry<K, NSEC, false>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
     }
     template <int D, int L>
-    void zp_fixup(const ZpParams &P, int rows, int64_t n_out, double *out, int64_t out_row_stride,
+    void zp_fixup(const ZpParams &P, int nb, int rows, double *out, int64_t out_row_stride,
                   const double *freq_offset, double fs_out)
     {
         Scope s(*this, D == 8 ? ST_DEC_FIXUP : ST_LPF_FIXUP);
-        hipLaunchKernelGGL((k_zp_fixup<D, L>), dim3((unsigned)((n_out + 255) / 256), rows), dim3(256), 0, stream,
-                           P, n_out, out, out_row_stride, freq_offset, fs_out);
+        hipLaunchKernelGGL((k_zp_fixup<D, L>), dim3(nb, rows), dim3(256), 0, stream, P, out, out_row_stride,
+                           freq_offset, fs_out);
     }
     template <class Loader>
     void convert(Loader ld, int rows, int64_t n, double *out, const double *freq_offset, double fs)
@@ -375,8 +373,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     const size_t nd = (size_t)n_carriers * h.n_dec * 2 * sizeof(double);
     HIP_TRY(hipMalloc(&p->d_y, nd));
     HIP_TRY(hipMalloc(&p->d_z, nd));
-    HIP_TRY(hipMalloc(&p->d_partials, (size_t)n_carriers * ((h.n_dec + kPowThreads - 1) / kPowThreads + 1) * kMaxSps *
-                                          sizeof(double)));
+    HIP_TRY(hipMalloc(&p->d_partials, (size_t)n_carriers * (h.n_dec / kPowThreads + 16) * kMaxSps * sizeof(double)));
     *out = p.release();
     return TDM_OK;
 }
@@ -596,11 +593,11 @@ int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, do
     if (sos) {
         be.zp_block<2, 4, kLDec, kEdgeSos>(dz.params, ld, t.p.nb, 1);
         be.zp_carry<2, 4>(dz.params, t.p.nb, 1);
-        be.zp_fixup<8, kLDec>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
+        be.zp_fixup<8, kLDec>(dz.params, t.p.nb, 1, dy.as<double>(), n_out, nullptr, fs);
     } else {
         be.zp_block<2, 2, kLLpf, kEdgeTf>(dz.params, ld, t.p.nb, 1);
         be.zp_carry<2, 2>(dz.params, t.p.nb, 1);
-        be.zp_fixup<4, kLLpf>(dz.params, 1, n_out, dy.as<double>(), n_out, nullptr, fs);
+        be.zp_fixup<4, kLLpf>(dz.params, t.p.nb, 1, dy.as<double>(), n_out, nullptr, fs);
     }
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
     HIP_TRY(hipDeviceSynchronize());

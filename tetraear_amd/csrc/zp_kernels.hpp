@@ -469,22 +469,20 @@ TDM_HD void zp_carry_bwd_body(const ZpParams &P, int row, int b, int ch)
 // Fix-up body: out[j] = y0[j] + T1[m].Gf_b + T2[m].Hb_b, then (optionally) process()'s
 // freq_offset NCO at the output rate (processor.py:260-261).  One thread per output sample.
 // ------------------------------------------------------------------------------------------
-template <int D, int L>
-TDM_HD void zp_fixup_value(const ZpParams &P, int row, int64_t j, double &re, double &im)
+// One output of block b at in-block offset m (row/b uniform over the workgroup, so the carries are
+// read with scalar loads; the table rows of consecutive outputs are consecutive in memory).
+template <int D>
+TDM_HD void zp_fixup_at(const ZpParams &P, int row, int b, int m, int64_t j, double &re, double &im)
 {
-    constexpr int Bn = kWave * L;
     const int q = P.out_stride;
-    const int64_t pos = P.k0L + j * q;
-    const int b = (int)(pos / Bn);
-    const int m = (int)(pos - (int64_t)b * Bn);
     const bool last = (b == P.nb - 1);
     const unsigned R = last ? P.R_last : P.R_reg;
     const size_t r = ((unsigned)m % (unsigned)q) * (size_t)R + (unsigned)m / (unsigned)q;
     const double *T1 = (last ? P.T1_last : P.T1_reg) + r * D;
     const double *T2 = (last ? P.T2_last : P.T2_reg) + r * D;
     const int64_t cb = ((int64_t)row * P.nb + b) * D * 2;
-    const double *Gf = P.Gf + cb;
-    const double *Hb = P.Hb + cb;
+    const auto Gf = TDM_CPTR(P.Gf + cb);
+    const auto Hb = TDM_CPTR(P.Hb + cb);
     const double *y0 = P.y0 + ((int64_t)row * P.n_out + j) * 2;
     re = y0[0];
     im = y0[1];
@@ -495,18 +493,27 @@ TDM_HD void zp_fixup_value(const ZpParams &P, int row, int64_t j, double &re, do
     }
 }
 
+// Fix-up body: one workgroup per (row, block); thread t handles the block's outputs t, t+nt, ...
 template <int D, int L>
-TDM_HD void zp_fixup_body(const ZpParams &P, int row, int64_t j, double *out /* row base */,
+TDM_HD void zp_fixup_body(const ZpParams &P, int row, int b, int tid, int nt, double *out /* row base */,
                           const double *freq_offset /* per row or null */, double fs_out)
 {
-    double re, im;
-    zp_fixup_value<D, L>(P, row, j, re, im);
-    if (freq_offset) {
-        const double f = freq_offset[row];
+    constexpr int Bn = kWave * L;
+    const int q = P.out_stride;
+    const int64_t base = (int64_t)b * Bn - P.k0L;  // pos - k0L of offset m == 0
+    // first offset m0 >= 0 of this block that is an output: (base + m0) % q == 0 and base + m0 >= 0
+    int64_t m0 = base >= 0 ? (q - base % q) % q : -base;
+    const int len = (b == P.nb - 1) ? P.len_last : Bn;
+    const double f = freq_offset ? freq_offset[row] : 0.0;
+    for (int64_t m = m0 + (int64_t)tid * q; m < len; m += (int64_t)nt * q) {
+        const int64_t j = (base + m) / q;
+        if (j >= P.n_out) break;
+        double re, im;
+        zp_fixup_at<D>(P, row, b, (int)m, j, re, im);
         if (f != 0.0) nco_rotate(re, im, j, f, fs_out);
+        out[j * 2] = re;
+        out[j * 2 + 1] = im;
     }
-    out[j * 2] = re;
-    out[j * 2 + 1] = im;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -646,17 +653,22 @@ template <int D, int L, class Comm>
 TDM_HD void power_fixup_body(const ZpParams &P, Comm &cm, int row, int blk, double *z_row, int64_t n, int sps,
                              double *partials_row /* [n_pblk][kMaxSps] */)
 {
+    constexpr int Bn = kWave * L;
+    constexpr int kSub = Bn / kPowThreads;  // workgroups per filter block (out_stride == 1 here)
+    static_assert(Bn % kPowThreads == 0, "block must be a whole number of power workgroups");
     const int t = cm.tid();
-    const int64_t j0 = (int64_t)blk * kPowThreads;
+    const int b = blk / kSub;
+    const int m = (blk % kSub) * kPowThreads + t;
+    const int64_t j0 = (int64_t)b * Bn + (blk % kSub) * kPowThreads - P.k0L;  // may be negative
     const int64_t j = j0 + t;
     double sq = 0;
-    if (j < n) {
+    if (j >= 0 && j < n) {
         double re, im;
-        zp_fixup_value<D, L>(P, row, j, re, im);
+        zp_fixup_at<D>(P, row, b, m, j, re, im);
         z_row[j * 2] = re;
         z_row[j * 2 + 1] = im;
-        const double m = hypot(re, im);
-        sq = m * m;
+        const double mg = hypot(re, im);
+        sq = mg * mg;
     }
     cm.lds(t) = sq;
     cm.sync();
@@ -665,9 +677,9 @@ TDM_HD void power_fixup_body(const ZpParams &P, Comm &cm, int row, int blk, doub
         if (t < sps) {
             const int64_t np_ = (n - t) / sps;           // samples phase t owns: j = t + k*sps, k < np_
             const int64_t lim = t + np_ * (int64_t)sps;  // first j NOT owned
-            int64_t first = ((t - j0) % sps + sps) % sps; // first in-block index with (j0+i) % sps == t
+            const int64_t first = (((int64_t)t - j0) % sps + sps) % sps;  // (j0 + first) % sps == t
             for (int64_t i = first; i < kPowThreads; i += sps)
-                if (j0 + i < lim) acc += cm.lds((int)i);
+                if (j0 + i >= 0 && j0 + i < lim) acc += cm.lds((int)i);
         }
         partials_row[(int64_t)blk * kMaxSps + t] = acc;
     }
