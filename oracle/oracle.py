@@ -191,7 +191,8 @@ def resample_np(samples, sample_rate, target_rate):
         Y[nyq - N:] = X[nyq - N:]
     if N % 2 == 0:
         if num < Nx:  # downsampling: fold the Nyquist bin
-            Y[-N // 2] += X[-N // 2]
+            sl = slice(-N // 2, -N // 2 + 1)  # scipy's own slice form: empty when N == 2
+            Y[sl] += X[sl]
         elif Nx < num:  # upsampling: split it
             Y[N // 2] *= 0.5
             Y[num - N // 2] = Y[N // 2]

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../tetraear_amd/csrc/ref_pipeline.hpp"
+#include "../../tetraear_amd/csrc/resample_plan.hpp"
 
 using namespace tdm;
 
@@ -208,6 +209,24 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         be.zp_carry<2, 2>(hz.t.p, hz.t.p.nb, 1);
         be.zp_fixup<4, kLLpf>(hz.t.p, hz.t.p.nb, 1, y, n, nullptr, fs);
     }
+    return 0;
+}
+
+int emu_resample(const double *x, int64_t n, int64_t num, double *y)
+{
+    ResamplePlan rp = build_resample_plan(n, num);
+    std::vector<double> X(rp.src_bins.size() * 2 + 2);
+    for (size_t o = 0; o < rp.src_bins.size(); ++o)
+        run_group(8, [&](int t, Group *g) {
+            EmuBlockComm cm{g, t};
+            dft_terms_body(cm, (int64_t)o, rp.src_bins.data(), x, n, nullptr, nullptr, nullptr, n, -1.0, 1.0, X.data());
+        });
+    for (int64_t o = 0; o < num; ++o)
+        run_group(8, [&](int t, Group *g) {
+            EmuBlockComm cm{g, t};
+            dft_terms_body(cm, o, nullptr, X.data(), (int64_t)rp.term_src.size(), rp.term_src.data(),
+                           rp.term_dst.data(), rp.term_w.data(), num, 1.0, 1.0 / (double)n, y);
+        });
     return 0;
 }
 

@@ -54,3 +54,11 @@ def zp_stage(kind, x, q=10, bandwidth=25000.0, fs=240000.0):
     if rc != 0:
         raise ValueError("input too short")
     return y
+
+
+def resample(x, num):
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    y = np.zeros(num, dtype=np.complex128)
+    L.emu_resample(x.ctypes.data_as(C.c_void_p), C.c_int64(len(x)), C.c_int64(num), y.ctypes.data_as(C.c_void_p))
+    return y

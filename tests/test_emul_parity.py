@@ -110,3 +110,19 @@ def test_emul_filter_stage_conditioning(gold_stages):
     for q in (7, 10, 41):
         y = emul.zp_stage(0, x, q=q)
         assert np.max(np.abs(y - g[f"decimate_q{q}"])) <= 1e-12 * np.max(np.abs(g[f"decimate_q{q}"]))
+
+
+def test_emul_resample(gold_stages):
+    """SignalProcessor.resample (processor.py:35-49): direct-DFT kernels vs scipy goldens + scipy's
+    bin bookkeeping on odd/even, up/down, tiny lengths (incl. the empty-slice quirk at N == 2)."""
+    from oracle.oracle import resample_np
+    from tetraear_amd import synth
+    g = gold_stages
+    x = synth.cu8_to_c128(synth.noise_cu8(4000, int(g["x4000_seed"][0])))
+    assert np.max(np.abs(emul.resample(x[:1000], 500) - g["resample_1200k"])) < 1e-13
+    assert np.max(np.abs(emul.resample(x[:301], int(301 * 3.0e6 / 2.4e6)) - g["resample_up"])) < 1e-13
+    for n, num in [(16, 8), (16, 32), (15, 7), (15, 31), (7, 7), (2, 5), (3, 2), (4, 2), (2, 1), (1, 4), (64, 63),
+                   (63, 64), (2, 2), (2, 4), (5, 2)]:
+        ref = resample_np(x[:n], 1.0, num / n + 1e-12)
+        assert len(ref) == num
+        assert np.max(np.abs(emul.resample(x[:n], num) - ref)) < 1e-13, (n, num)

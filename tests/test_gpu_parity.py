@@ -105,6 +105,8 @@ def test_stage_methods(gold_stages, SP):
     np.testing.assert_array_equal(p.demodulate_dqpsk(x), g["demod_x"])
     np.testing.assert_array_equal(p.demodulate_dqpsk(x[:2]), g["demod_2"])
     np.testing.assert_array_equal(p.demodulate_dqpsk(np.zeros(10, dtype=complex)), g["demod_zeros"])
+    close(p.resample(x[:1000], 1.2e6), g["resample_1200k"], 1e-12)
+    close(p.resample(x[:301], 3.0e6), g["resample_up"], 1e-12)
     # 1-ulp threshold probes: decisions depend on the last bit of libm's atan2; require agreement
     # on every probe that is not within 4 ulp of a threshold
     probe = p.demodulate_dqpsk(g["demod_probe_in"])
@@ -143,6 +145,8 @@ def test_reference_style_contracts(SP):
     d = p.demodulate_dqpsk(f)
     s = p.extract_symbols(f)
     assert len(d) > 0 and len(s) > 0
+    r = p.resample(iq, 1.2e6)   # tests/unit/test_signal_processor.py:27-34
+    assert len(r) == len(iq) // 2 and isinstance(r, np.ndarray) and np.iscomplexobj(r)
 
 
 def test_batch_vs_oracle_many_rows():

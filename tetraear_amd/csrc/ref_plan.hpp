@@ -9,7 +9,10 @@
 
 namespace tdm {
 
-constexpr int kLDec = 32;  // samples per lane, decimator stage (4 biquads)
+#ifndef TDM_LDEC
+#define TDM_LDEC 32
+#endif
+constexpr int kLDec = TDM_LDEC;  // samples per lane, decimator stage (4 biquads)
 constexpr int kLLpf = 32;  // samples per lane, channel-filter stage (order 4 = 2 biquads)
 constexpr int kEdgeSos = 27;  // sosfiltfilt pad for 4 sections: 3*(2*4+1)
 constexpr int kEdgeTf = 15;   // filtfilt pad for order 4: 3*5

@@ -13,6 +13,7 @@
 
 #include "../../include/tetrahip.h"
 #include "ref_pipeline.hpp"
+#include "resample_plan.hpp"
 
 using namespace tdm;
 
@@ -99,7 +100,7 @@ struct BlockComm {
 #define TDM_BLOCK_WAVES 2  // waves per SIMD the block kernel is register-budgeted for
 #endif
 template <int K, int NSEC, int L, int EDGE, class Loader>
-__global__ __launch_bounds__(64, TDM_BLOCK_WAVES) void k_zp_block(const ZpParams P, const Loader ld)
+__global__ __launch_bounds__(64, (L <= 16 ? 4 : (L <= 24 ? 3 : TDM_BLOCK_WAVES))) void k_zp_block(const ZpParams P, const Loader ld)
 {
     WaveComm cm;
     zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
@@ -155,6 +156,16 @@ __global__ __launch_bounds__(kPowThreads) void k_power_fixup(const ZpParams P, i
     const int row = blockIdx.y;
     power_fixup_body<D, L>(P, cm, row, (int)blockIdx.x, z + (int64_t)row * n * 2, n, sps,
                            partials + (int64_t)row * n_pblk * kMaxSps);
+}
+
+__global__ __launch_bounds__(kFinishThreads) void k_dft_terms(const int64_t *o_list, const double *in, int64_t n_terms,
+                                                           const int64_t *src, const int64_t *freq,
+                                                           const double *weight, int64_t n, double sign, double scale,
+                                                           double *out)
+{
+    __shared__ double sm[kFinishThreads / 64];
+    BlockComm cm{sm, nullptr};
+    dft_terms_body(cm, (int64_t)blockIdx.x, o_list, in, n_terms, src, freq, weight, n, sign, scale, out);
 }
 
 __global__ __launch_bounds__(256) void k_shift(const double *x, double *y, int64_t n, double f, double fs)
@@ -718,9 +729,39 @@ int tdm_demodulate_dqpsk(const double *x, int64_t n, uint8_t *out, int64_t *n_ou
     return rc;
 }
 
-int tdm_resample(const double *, int64_t, int64_t, double *, int32_t)
+int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t device)
 {
-    return fail(TDM_ERR_UNSUPPORTED, "tdm_resample: not built yet (SignalProcessor.resample is not on the process() path)");
+    if (n < 0 || num < 0 || (n > 0 && !x) || (num > 0 && !y)) return fail(TDM_ERR_INVALID, "bad argument");
+    if (n >= (int64_t(1) << 31) || num >= (int64_t(1) << 31)) return fail(TDM_ERR_UNSUPPORTED, "resample: length >= 2^31");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (num == 0) return TDM_OK;
+    if (n == 0) { std::memset(y, 0, (size_t)num * 16); return TDM_OK; }
+    ResamplePlan rp = build_resample_plan(n, num);
+    const int64_t nb = (int64_t)rp.src_bins.size(), nt = (int64_t)rp.term_src.size();
+    DevBuf dx, dX, dy, dbins, dsrc, ddst, dw;
+    if ((rc = dx.alloc((size_t)n * 16)) || (rc = dX.alloc((size_t)nb * 16)) || (rc = dy.alloc((size_t)num * 16)) ||
+        (rc = dbins.alloc((size_t)nb * 8)) || (rc = dsrc.alloc((size_t)nt * 8)) || (rc = ddst.alloc((size_t)nt * 8)) ||
+        (rc = dw.alloc((size_t)nt * 8)))
+        return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dbins.p, rp.src_bins.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dsrc.p, rp.term_src.data(), (size_t)nt * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ddst.p, rp.term_dst.data(), (size_t)nt * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dw.p, rp.term_w.data(), (size_t)nt * 8, hipMemcpyHostToDevice));
+    // X[k] = sum_n x[n] exp(-2 pi i k n / N) for the needed bins k
+    hipLaunchKernelGGL(k_dft_terms, dim3((unsigned)nb), dim3(kFinishThreads), 0, 0, dbins.as<int64_t>(),
+                       dx.as<double>(), n, (const int64_t *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
+                       n, -1.0, 1.0, dX.as<double>());
+    HIP_TRY(hipGetLastError());
+    // y[t] = (1/N) sum_terms w X[src] exp(+2 pi i dst t / num)      (ifft's 1/num times num/N)
+    hipLaunchKernelGGL(k_dft_terms, dim3((unsigned)num), dim3(kFinishThreads), 0, 0, (const int64_t *)nullptr,
+                       dX.as<double>(), nt, dsrc.as<int64_t>(), ddst.as<int64_t>(), dw.as<double>(), num, 1.0,
+                       1.0 / (double)n, dy.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(y, dy.p, (size_t)num * 16, hipMemcpyDeviceToHost));
+    return TDM_OK;
 }
 
 // ---- introspection (no device needed) -----------------------------------------------------------

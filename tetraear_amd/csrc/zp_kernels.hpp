@@ -694,4 +694,69 @@ TDM_HD void shift_body(const double *x, double *y, int64_t k, double f, double f
     y[k * 2 + 1] = im;
 }
 
+// ------------------------------------------------------------------------------------------
+// resample (processor.py:35-49 -> scipy.signal.resample, FFT method): X = fft(x); keep the
+// min(num, N) lowest-|f| bins (Nyquist bin folded / split as scipy does); y = ifft(Y) * num/N.
+// Evaluated as two direct DFTs over the kept bins only; every twiddle is an exact sincospi of the
+// integer phase index (k*n mod N), so the error does not grow with N.  O(N * kept) work: this
+// method is not on the process() path (no caller in the reference uses it) and is built for
+// completeness of the class interface, not for speed.
+//   Comm: tid(), nthreads(), reduce_sum(double)
+// ------------------------------------------------------------------------------------------
+
+TDM_HD void sincospi_d(double t, double *s, double *c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincospi(t, s, c);
+#else
+    // host (test harness): exact quadrant reduction, then libm on |r| <= 1/4
+    const double k = rint(2.0 * t);
+    const double r = t - 0.5 * k;
+    double sr, cr;
+    sincos(M_PI * r, &sr, &cr);
+    switch (((long long)k % 4 + 4) % 4) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+    }
+#endif
+}
+
+TDM_HD void unit_root(int64_t m, int64_t n, double sign, double &c, double &s)
+{
+    // exp(sign * 2*pi*i * m / n), 0 <= m < n
+    sincospi_d(2.0 * (double)m / (double)n, &s, &c);
+    s *= sign;
+}
+
+// out[o] = scale * sum_i w[i] * in[src[i]] * exp(sign*2*pi*i * f[i]*o' / n) with o' = (o_list ? o_list[o] : o)
+// one workgroup per output o; threads stride over the terms i.
+template <class Comm>
+TDM_HD void dft_terms_body(Comm &cm, int64_t o, const int64_t *o_list, const double *in, int64_t n_terms,
+                           const int64_t *src, const int64_t *freq, const double *weight, int64_t n, double sign,
+                           double scale, double *out)
+{
+    const int64_t oo = o_list ? o_list[o] : o;
+    const int tid = cm.tid(), nt = cm.nthreads();
+    double accr = 0, acci = 0;
+    for (int64_t i = tid; i < n_terms; i += nt) {
+        const int64_t f = freq ? freq[i] : i;
+        const int64_t m = (int64_t)(((uint64_t)f * (uint64_t)oo) % (uint64_t)n);  // f, oo < n < 2^31
+        double c, s;
+        unit_root(m, n, sign, c, s);
+        const int64_t k = src ? src[i] : i;
+        const double w = weight ? weight[i] : 1.0;
+        const double xr = in[2 * k] * w, xi = in[2 * k + 1] * w;
+        accr += xr * c - xi * s;
+        acci += xr * s + xi * c;
+    }
+    accr = cm.reduce_sum(accr);
+    acci = cm.reduce_sum(acci);
+    if (tid == 0) {
+        out[2 * o] = accr * scale;
+        out[2 * o + 1] = acci * scale;
+    }
+}
+
 }  // namespace tdm
