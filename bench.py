@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=262144, help="samples per carrier per step")
     ap.add_argument("--fmt", default="cu8", choices=["cu8", "cf32", "cf64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--zero-foff", action="store_true", help="experiment: all freq offsets 0 (NCO skipped)")
     ap.add_argument("--rate", type=float, default=SAMPLE_RATE, help="sample rate (experiments; metric config is 2.4e6)")
     args = ap.parse_args()
 
@@ -95,6 +96,8 @@ def main():
     bd = BatchDemodulator(args.rate, args.chunk, args.carriers, args.fmt, device=local_rank)
     bd.alloc_device_io()
     iq, foffs = make_batch(args.carriers, args.chunk, args.fmt, rank)
+    if args.zero_foff:
+        foffs = foffs * 0.0
     bd.upload(iq, freq_offsets=foffs)
 
     def barrier():

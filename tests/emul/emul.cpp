@@ -24,12 +24,14 @@ struct Group {
     int nt;
     std::barrier<> bar;
     std::vector<double> slots;
-    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024) {}
+    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024 + 2 * 2200) {}
 };
 
 struct EmuWaveComm {
     Group *g;
     int lane;
+    double *stage() { return &g->slots[(size_t)g->nt * 16 + 1024]; }
+    void wave_sync() { g->bar.arrive_and_wait(); }
     template <int K>
     void xchg(const double *a, const double *b, double *oa, double *ob, int src)
     {
@@ -205,7 +207,8 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         Tf4 t = design_butter4(butter_cutoff(bandwidth, fs));
         hz.t = build_zp_tables(desc_from_tf(t), n, kEdgeTf, kLLpf, n, 1);
         hz.bind(1);
-        be.zp_block<2, 2, kLLpf, kEdgeTf>(hz.t.p, ld, hz.t.p.nb, 1);
+        StagedLoader<PlainC128Src> ls{{x, n}};
+        be.zp_block<2, 2, kLLpf, kEdgeTf>(hz.t.p, ls, hz.t.p.nb, 1);
         be.zp_carry<2, 2>(hz.t.p, hz.t.p.nb, 1);
         be.zp_fixup<4, kLLpf>(hz.t.p, hz.t.p.nb, 1, y, n, nullptr, fs);
     }

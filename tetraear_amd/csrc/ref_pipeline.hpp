@@ -44,11 +44,11 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
 {
     RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
     if (h.decimated) {
-        // scipy.signal.decimate(samples, q)  (processor.py:254)
+        // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
         be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
         be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
-        // + frequency_shift(samples, freq_offset, current_rate)  (processor.py:260-261)
-        be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
+        if (!h.lpf)  // (n_dec <= 15) nothing downstream finishes the decimator output: do it here
+            be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
     } else {
         be.convert(ld, rows, h.n, B.y, io.freq_offset, h.sample_rate);
     }
@@ -56,9 +56,16 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     const double *partials = nullptr;
     int n_pblk = 0;
     if (h.lpf) {
-        // filter_signal(samples, 25000, current_rate)  (processor.py:264)
-        RawLoader<FMT_CF64, false> l2{B.y, h.n_dec, nullptr, h.rate_dec};
-        be.template zp_block<2, 2, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
+        // filter_signal(samples, 25000, current_rate)  (processor.py:264).  When decimated, the
+        // loader finishes the decimator output (carry responses) and applies
+        // frequency_shift(samples, freq_offset, current_rate) (processor.py:260-261) on the fly.
+        if (h.decimated) {
+            StagedLoader<DecFixSrc<kLDec>> l2{{B.dec_params, io.freq_offset, h.rate_dec}};
+            be.template zp_block<2, 2, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
+        } else {
+            StagedLoader<PlainC128Src> l2{{B.y, h.n_dec}};
+            be.template zp_block<2, 2, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
+        }
         be.template zp_carry<2, 2>(B.lpf_params, h.lpf_t.p.nb, rows);
         if (h.sps > 1 && h.sps <= kMaxSps) {
             n_pblk = h.lpf_t.p.nb * (kWave * kLLpf / kPowThreads);

@@ -52,6 +52,9 @@ static int use_device(int device)
 // device-side communication objects
 // ------------------------------------------------------------------------------------------
 struct WaveComm {
+    double *stg;
+    __device__ __forceinline__ double *stage() { return stg; }
+    __device__ __forceinline__ void wave_sync() { __syncthreads(); }  // one wavefront per workgroup
     template <int K>
     __device__ __forceinline__ void shfl_up2(const double *a, const double *b, double *oa, double *ob, int d)
     {
@@ -102,7 +105,8 @@ struct BlockComm {
 template <int K, int NSEC, int L, int EDGE, class Loader>
 __global__ __launch_bounds__(64, (L <= 16 ? 4 : (L <= 24 ? 3 : TDM_BLOCK_WAVES))) void k_zp_block(const ZpParams P, const Loader ld)
 {
-    WaveComm cm;
+    __shared__ __attribute__((aligned(16))) double stg[Loader::kStaged ? StageGeom<L>::kDoubles : 2];
+    WaveComm cm{stg};
     zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -601,12 +605,13 @@ int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, do
     HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 16, hipMemcpyHostToDevice));
     HipBackend be;
     RawLoader<FMT_CF64, false> ld{dx.p, n, nullptr, fs};
+    StagedLoader<PlainC128Src> ls{{dx.as<double>(), n}};
     if (sos) {
         be.zp_block<2, 4, kLDec, kEdgeSos>(dz.params, ld, t.p.nb, 1);
         be.zp_carry<2, 4>(dz.params, t.p.nb, 1);
         be.zp_fixup<8, kLDec>(dz.params, t.p.nb, 1, dy.as<double>(), n_out, nullptr, fs);
     } else {
-        be.zp_block<2, 2, kLLpf, kEdgeTf>(dz.params, ld, t.p.nb, 1);
+        be.zp_block<2, 2, kLLpf, kEdgeTf>(dz.params, ls, t.p.nb, 1);
         be.zp_carry<2, 2>(dz.params, t.p.nb, 1);
         be.zp_fixup<4, kLLpf>(dz.params, t.p.nb, 1, dy.as<double>(), n_out, nullptr, fs);
     }

@@ -107,6 +107,7 @@ struct RawLoader {
     double fs;
 
     static constexpr int kBytes = (FMT == FMT_CU8 || FMT == FMT_CS8) ? 2 : (FMT == FMT_CF32 ? 8 : 16);
+    static constexpr bool kStaged = false;  // lanes load their own segment straight from memory
 
     TDM_HD const void *row_ptr(int row) const
     {
@@ -195,9 +196,10 @@ struct RawLoader {
     }
 
     // x[i] = padded-ext sample seg+i (zero outside [P0, Ne))
-    template <int L>
-    TDM_HD void load(int row, int64_t seg, const ZpParams &P, double *xr, double *xi) const
+    template <int L, class Comm>
+    TDM_HD void load(Comm &, int row, int blk, int lane, const ZpParams &P, double *xr, double *xi) const
     {
+        const int64_t seg = (int64_t)blk * (kWave * L) + (int64_t)lane * L;
         const void *rowp = row_ptr(row);
         const double f = row_shift(row);
         const int64_t n = P.n;
@@ -218,8 +220,108 @@ struct RawLoader {
 };
 
 // ------------------------------------------------------------------------------------------
+// LDS staging for 16-byte complex samples.  A lane's L consecutive samples are 16*L bytes apart
+// from its neighbour's, so direct per-lane loads/stores make 64 cache-line requests per
+// instruction; instead the wavefront moves the block with fully coalesced accesses and transposes
+// it through LDS.  Slot s (16 bytes) lives at s + s/32: the one-slot pad per 32 makes both the
+// row-wise (coalesced side) and the column-wise (lane side) ds_*_b128 accesses conflict-free.
+// ------------------------------------------------------------------------------------------
+template <int L>
+struct StageGeom {
+    static constexpr int kSlots = kWave * L + (kWave * L) / 32 + 1;
+    static constexpr int kDoubles = 2 * kSlots;
+};
+TDM_HD int stage_slot(int s) { return s + (s >> 5); }
+
+// sample sources for the staged loader: get(row, j) -> sample j of the row, 0 <= j < n
+struct PlainC128Src {
+    const double *x;
+    int64_t row_stride;  // samples
+    TDM_HD void get(int row, int64_t j, double &re, double &im) const
+    {
+        const f64x2 v = *(const f64x2 *)(x + ((int64_t)row * row_stride + j) * 2);
+        re = v.x;
+        im = v.y;
+    }
+};
+
+template <int D>
+TDM_HD void zp_fixup_at(const ZpParams &P, int row, int b, int m, int64_t j, double &re, double &im);
+
+// decimator output finished on the fly: block-local y0 + carry responses, then process()'s
+// freq_offset NCO (processor.py:260-261) -- the former separate fix-up pass, fused into the load
+template <int LDEC>
+struct DecFixSrc {
+    ZpParams dec;
+    const double *freq_offset;  // per row or null
+    double fs_out;
+    TDM_HD void get(int row, int64_t j, double &re, double &im) const
+    {
+        constexpr int Bn = kWave * LDEC;
+        const int64_t pos = dec.k0L + j * dec.out_stride;
+        const int b = (int)(pos / Bn);
+        const int m = (int)(pos - (int64_t)b * Bn);
+        zp_fixup_at<8>(dec, row, b, m, j, re, im);
+        if (freq_offset) {
+            const double f = freq_offset[row];
+            if (f != 0.0) nco_rotate(re, im, j, f, fs_out);
+        }
+    }
+};
+
+template <class Src>
+struct StagedLoader {
+    Src src;
+    static constexpr bool kStaged = true;
+
+    template <int L, class Comm>
+    TDM_HD void load(Comm &cm, int row, int blk, int lane, const ZpParams &P, double *xr, double *xi) const
+    {
+        constexpr int Bn = kWave * L;
+        f64x2 *lds = (f64x2 *)cm.stage();
+        const int64_t n = P.n;
+        const int edge = P.edge;
+        const int64_t e_blk = (int64_t)blk * Bn - P.P0;  // ext index of the block's first position
+#pragma unroll 1
+        for (int it = 0; it < L; ++it) {
+            const int s = it * kWave + lane;
+            const int64_t e = e_blk + s;
+            double re = 0, im = 0;
+            if (e >= 0 && e < n + 2 * (int64_t)edge) {
+                if (e >= edge && e < edge + n) {
+                    src.get(row, e - edge, re, im);
+                } else if (e < edge) {  // 2*x[0] - x[edge - e]
+                    double ar, ai;
+                    src.get(row, 0, ar, ai);
+                    src.get(row, edge - e, re, im);
+                    re = 2 * ar - re;
+                    im = 2 * ai - im;
+                } else {  // 2*x[n-1] - x[n-2-(e-edge-n)]
+                    double ar, ai;
+                    src.get(row, n - 1, ar, ai);
+                    src.get(row, n - 2 - (e - edge - n), re, im);
+                    re = 2 * ar - re;
+                    im = 2 * ai - im;
+                }
+            }
+            lds[stage_slot(s)] = f64x2{re, im};
+        }
+        cm.wave_sync();
+        const double g = P.in_gain;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const f64x2 v = lds[stage_slot(lane * L + i)];
+            xr[i] = v.x * g;
+            xi[i] = v.y * g;
+        }
+        cm.wave_sync();  // the output stage reuses the buffer
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // Block kernel body: one wavefront filters one block forward then backward.
-//   Comm: shfl_up2<K>(a, b, outa, outb, d) / shfl_down2<K>: out[lane] = in[lane -/+ d] for two
+//   Comm: stage() -> workgroup LDS of StageGeom<L>::kDoubles doubles (staged loaders only),
+//   wave_sync(); shfl_up2<K>(a, b, outa, outb, d) / shfl_down2<K>: out[lane] = in[lane -/+ d] for two
 //   K-vectors of doubles across the 64 lanes (own value where the source lane does not exist).
 // ------------------------------------------------------------------------------------------
 template <int K, int NSEC, int L, int EDGE, class Loader, class Comm>
@@ -229,7 +331,7 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
     constexpr int Bn = kWave * L;
     double xr[L], xi[L];
     const int64_t seg = (int64_t)blk * Bn + (int64_t)lane * L;
-    ld.template load<L>(row, seg, P, xr, xi);
+    ld.template load<L>(cm, row, blk, lane, P, xr, xi);
 
     constexpr int P0 = (L - EDGE % L) % L;  // == P.P0
     const bool inject = (blk == 0 && lane == 0);
@@ -351,7 +453,21 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
         }
     }
     // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------
-    {
+    if (Loader::kStaged) {
+        // stride-1 stage: transpose back through LDS and store 16 B per lane, coalesced
+        f64x2 *lds = (f64x2 *)cm.stage();
+#pragma unroll
+        for (int i = 0; i < L; ++i) lds[stage_slot(lane * L + i)] = f64x2{xr[i], xi[i]};
+        cm.wave_sync();
+        f64x2 *y0 = (f64x2 *)(P.y0 + (int64_t)row * P.n_out * 2);
+        const int64_t j_blk = (int64_t)blk * Bn - P.k0L;
+#pragma unroll 1
+        for (int it = 0; it < L; ++it) {
+            const int s = it * kWave + lane;
+            const int64_t j = j_blk + s;
+            if (j >= 0 && j < P.n_out) y0[j] = lds[stage_slot(s)];
+        }
+    } else {
         const int64_t rel0 = seg - P.k0L;
         const int q = P.out_stride;
         int64_t j = rel0 <= 0 ? 0 : (rel0 + q - 1) / q;
