@@ -233,11 +233,13 @@ struct StageGeom {
 };
 TDM_HD int stage_slot(int s) { return s + (s >> 5); }
 
-// sample sources for the staged loader: get(row, j) -> sample j of the row, 0 <= j < n
+// sample sources for the staged loader: get(state, row, j) -> sample j of the row, 0 <= j < n.
+// `State` lets a source exploit that a lane asks for j, j+64, j+128, ... in turn.
 struct PlainC128Src {
     const double *x;
     int64_t row_stride;  // samples
-    TDM_HD void get(int row, int64_t j, double &re, double &im) const
+    struct State {};
+    TDM_HD void get(State &, int row, int64_t j, double &re, double &im) const
     {
         const f64x2 v = *(const f64x2 *)(x + ((int64_t)row * row_stride + j) * 2);
         re = v.x;
@@ -248,6 +250,51 @@ struct PlainC128Src {
 template <int D>
 TDM_HD void zp_fixup_at(const ZpParams &P, int row, int b, int m, int64_t j, double &re, double &im);
 
+// Running NCO for a lane that visits j_a, j_a+64, j_a+128, ...: the reference's phase is
+// theta_j = fl(ci * fl(j / fs)) (processor.py:98-99).  One exact sincos anchors the lane; after that
+// exp(i theta_j) = A * W^k * (1 + i eps_j), W = exp(i 64 Dd) advanced by complex multiplication and
+// eps_j = (theta_j - theta_a) - (j - j_a) Dd, computed exactly (Dd has 40 significant bits so the
+// product is exact; the difference of neighbouring thetas is exact), |eps| ~ 1e-11 so eps^2 drops.
+// This reproduces the reference's own rounding of theta_j, not an idealised phase ramp.
+struct NcoRun {
+    double ar = 1, ai = 0;   // anchor phasor (cos, sin)(theta_a)
+    double wr = 1, wi = 0;   // W^k
+    double sr = 1, si = 0;   // W = exp(i * 64 * Dd)
+    double th_a = 0, dd = 0;
+    int64_t j_a = 0, j_cur = 0;
+    bool on = false;
+    TDM_HD void step(int64_t j, double f, double fs, double &c, double &s)
+    {
+        const double ci = -(2.0 * M_PI) * f;
+        const double t = (double)j / fs;
+        const double th = ci * t;
+        if (!on || j != j_cur + kWave || j - j_a > 4096) {
+            const phasor p = nco_phasor(j, f, fs);
+            ar = p.c; ai = p.s; wr = 1; wi = 0; th_a = th; j_a = j; j_cur = j;
+            if (!on) {
+                // Dd: ci/fs with the low 13 mantissa bits cleared -> (j - j_a) * Dd is exact
+                union { double d; uint64_t u; } v;
+                v.d = ci / fs;
+                v.u &= ~uint64_t(0x1FFF);
+                dd = v.d;
+                sincos((double)kWave * dd, &si, &sr);
+                on = true;
+            }
+            c = ar;
+            s = ai;
+            return;
+        }
+        j_cur = j;
+        const double nwr = wr * sr - wi * si, nwi = wr * si + wi * sr;
+        wr = nwr;
+        wi = nwi;
+        const double eps = (th - th_a) - (double)(j - j_a) * dd;
+        const double pr = ar * wr - ai * wi, pi_ = ar * wi + ai * wr;
+        c = pr - eps * pi_;
+        s = pi_ + eps * pr;
+    }
+};
+
 // decimator output finished on the fly: block-local y0 + carry responses, then process()'s
 // freq_offset NCO (processor.py:260-261) -- the former separate fix-up pass, fused into the load
 template <int LDEC>
@@ -255,7 +302,10 @@ struct DecFixSrc {
     ZpParams dec;
     const double *freq_offset;  // per row or null
     double fs_out;
-    TDM_HD void get(int row, int64_t j, double &re, double &im) const
+    struct State {
+        NcoRun nco;
+    };
+    TDM_HD void get(State &st, int row, int64_t j, double &re, double &im) const
     {
         constexpr int Bn = kWave * LDEC;
         const int64_t pos = dec.k0L + j * dec.out_stride;
@@ -264,7 +314,13 @@ struct DecFixSrc {
         zp_fixup_at<8>(dec, row, b, m, j, re, im);
         if (freq_offset) {
             const double f = freq_offset[row];
-            if (f != 0.0) nco_rotate(re, im, j, f, fs_out);
+            if (f != 0.0) {
+                double c, s;
+                st.nco.step(j, f, fs_out, c, s);
+                const double a = re, bb = im;
+                re = a * c - bb * s;
+                im = a * s + bb * c;
+            }
         }
     }
 };
@@ -282,6 +338,7 @@ struct StagedLoader {
         const int64_t n = P.n;
         const int edge = P.edge;
         const int64_t e_blk = (int64_t)blk * Bn - P.P0;  // ext index of the block's first position
+        typename Src::State st{};
 #pragma unroll 1
         for (int it = 0; it < L; ++it) {
             const int s = it * kWave + lane;
@@ -289,17 +346,19 @@ struct StagedLoader {
             double re = 0, im = 0;
             if (e >= 0 && e < n + 2 * (int64_t)edge) {
                 if (e >= edge && e < edge + n) {
-                    src.get(row, e - edge, re, im);
+                    src.get(st, row, e - edge, re, im);
                 } else if (e < edge) {  // 2*x[0] - x[edge - e]
+                    typename Src::State t0{}, t1{};
                     double ar, ai;
-                    src.get(row, 0, ar, ai);
-                    src.get(row, edge - e, re, im);
+                    src.get(t0, row, 0, ar, ai);
+                    src.get(t1, row, edge - e, re, im);
                     re = 2 * ar - re;
                     im = 2 * ai - im;
                 } else {  // 2*x[n-1] - x[n-2-(e-edge-n)]
+                    typename Src::State t0{}, t1{};
                     double ar, ai;
-                    src.get(row, n - 1, ar, ai);
-                    src.get(row, n - 2 - (e - edge - n), re, im);
+                    src.get(t0, row, n - 1, ar, ai);
+                    src.get(t1, row, n - 2 - (e - edge - n), re, im);
                     re = 2 * ar - re;
                     im = 2 * ai - im;
                 }
