@@ -245,6 +245,12 @@ struct PlainC128Src {
         re = v.x;
         im = v.y;
     }
+    // stage samples j0..j1-1 into LDS slots slot0 + (j - j0), coalesced
+    TDM_HD void stage_range(int row, int64_t j0, int64_t j1, int lane, f64x2 *lds, int slot0) const
+    {
+        const f64x2 *p = (const f64x2 *)(x + (int64_t)row * row_stride * 2);
+        for (int64_t j = j0 + lane; j < j1; j += kWave) lds[stage_slot(slot0 + (int)(j - j0))] = p[j];
+    }
 };
 
 template <int D>
@@ -323,6 +329,39 @@ struct DecFixSrc {
             }
         }
     }
+    // Bulk form: walk the decimator blocks that cover [j0, j1); inside one block the carries are
+    // wave-uniform (scalar loads) and consecutive lanes read consecutive table rows.
+    TDM_HD void stage_range(int row, int64_t j0, int64_t j1, int lane, f64x2 *lds, int slot0) const
+    {
+        constexpr int Bn = kWave * LDEC;
+        const int q = dec.out_stride;
+        const double f = freq_offset ? freq_offset[row] : 0.0;
+        int b = (int)((dec.k0L + j0 * q) / Bn);
+        for (;; ++b) {
+            // outputs of block b: positions pos = k0L + j*q in [b*Bn, (b+1)*Bn)
+            const int64_t lo_pos = (int64_t)b * Bn - dec.k0L;
+            const int64_t hi_pos = lo_pos + Bn;
+            int64_t jl = lo_pos <= 0 ? 0 : (lo_pos + q - 1) / q;
+            int64_t jh = (hi_pos + q - 1) / q;
+            if (jl < j0) jl = j0;
+            if (jh > j1) jh = j1;
+            if (jl >= j1 || b >= dec.nb) break;
+            NcoRun nco;
+            for (int64_t j = jl + lane; j < jh; j += kWave) {
+                const int m = (int)(dec.k0L + j * q - (int64_t)b * Bn);
+                double re, im;
+                zp_fixup_at<8>(dec, row, b, m, j, re, im);
+                if (f != 0.0) {
+                    double c, s;
+                    nco.step(j, f, fs_out, c, s);
+                    const double a = re, bb = im;
+                    re = a * c - bb * s;
+                    im = a * s + bb * c;
+                }
+                lds[stage_slot(slot0 + (int)(j - j0))] = f64x2{re, im};
+            }
+        }
+    }
 };
 
 template <class Src>
@@ -338,32 +377,37 @@ struct StagedLoader {
         const int64_t n = P.n;
         const int edge = P.edge;
         const int64_t e_blk = (int64_t)blk * Bn - P.P0;  // ext index of the block's first position
-        typename Src::State st{};
+        // interior samples (the signal itself), staged in bulk
+        {
+            int64_t j0 = e_blk - edge, j1 = j0 + Bn;
+            const int64_t jb = j0;
+            if (j0 < 0) j0 = 0;
+            if (j1 > n) j1 = n;
+            if (j0 < j1) src.stage_range(row, j0, j1, lane, lds, (int)(j0 - jb));
+        }
+        // positions in the odd extension or in the zero pad (first / last block only)
+        if (e_blk < edge || e_blk + Bn > edge + n) {
 #pragma unroll 1
-        for (int it = 0; it < L; ++it) {
-            const int s = it * kWave + lane;
-            const int64_t e = e_blk + s;
-            double re = 0, im = 0;
-            if (e >= 0 && e < n + 2 * (int64_t)edge) {
-                if (e >= edge && e < edge + n) {
-                    src.get(st, row, e - edge, re, im);
-                } else if (e < edge) {  // 2*x[0] - x[edge - e]
+            for (int it = 0; it < L; ++it) {
+                const int s = it * kWave + lane;
+                const int64_t e = e_blk + s;
+                if (e >= edge && e < edge + n) continue;
+                double re = 0, im = 0;
+                if (e >= 0 && e < n + 2 * (int64_t)edge) {
                     typename Src::State t0{}, t1{};
                     double ar, ai;
-                    src.get(t0, row, 0, ar, ai);
-                    src.get(t1, row, edge - e, re, im);
-                    re = 2 * ar - re;
-                    im = 2 * ai - im;
-                } else {  // 2*x[n-1] - x[n-2-(e-edge-n)]
-                    typename Src::State t0{}, t1{};
-                    double ar, ai;
-                    src.get(t0, row, n - 1, ar, ai);
-                    src.get(t1, row, n - 2 - (e - edge - n), re, im);
+                    if (e < edge) {  // 2*x[0] - x[edge - e]
+                        src.get(t0, row, 0, ar, ai);
+                        src.get(t1, row, edge - e, re, im);
+                    } else {  // 2*x[n-1] - x[n-2-(e-edge-n)]
+                        src.get(t0, row, n - 1, ar, ai);
+                        src.get(t1, row, n - 2 - (e - edge - n), re, im);
+                    }
                     re = 2 * ar - re;
                     im = 2 * ai - im;
                 }
+                lds[stage_slot(s)] = f64x2{re, im};
             }
-            lds[stage_slot(s)] = f64x2{re, im};
         }
         cm.wave_sync();
         const double g = P.in_gain;
