@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void k_convert(const Loader ld, int64_t n, dou
 __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs fa)
 {
     __shared__ double sm[kFinishThreads / 64];
-    BlockComm cm{sm, nullptr};
+    __shared__ double buf[kFinishThreads];
+    BlockComm cm{sm, buf};
     finish_body(fa, cm, (int)blockIdx.x);
 }
 

@@ -347,7 +347,8 @@ struct DecFixSrc {
             if (jh > j1) jh = j1;
             if (jl >= j1 || b >= dec.nb) break;
             NcoRun nco;
-            for (int64_t j = jl + lane; j < jh; j += kWave) {
+#pragma unroll 4
+            for (int64_t j = jl + lane; j < jh; j += kWave) {  // <= 4 trips at q = 10: loads overlap
                 const int m = (int)(dec.k0L + j * q - (int64_t)b * Bn);
                 double re, im;
                 zp_fixup_at<8>(dec, row, b, m, j, re, im);
@@ -738,7 +739,8 @@ TDM_HD void zp_fixup_body(const ZpParams &P, int row, int b, int tid, int nt, do
 // ------------------------------------------------------------------------------------------
 // Finish body: timing-phase pick + symbol gather (extract_symbols) and the differential slicer
 // (demodulate_dqpsk).  One workgroup per row.
-//   Comm: tid(), nthreads(), sync(), reduce_sum/max/min(double) -> value on every thread.
+//   Comm: tid(), nthreads() (a multiple of kMaxSps), sync(), lds(i) -> double& (nthreads() doubles of
+//   workgroup scratch), reduce_sum/max/min(double) -> value on every thread.
 // ------------------------------------------------------------------------------------------
 struct FinishArgs {
     const double *z;      // [rows][n] c128 input at rate fs
@@ -797,14 +799,25 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
     if (A.do_extract && n > 0 && sps > 1) {
         const int64_t step = sps / 8 > 1 ? sps / 8 : 1;
         if (A.partials) {
-            // one thread per candidate phase sums that phase's block partials in block order
+            // phase p = tid % kMaxSps, group g = tid / kMaxSps: each thread sums every (nt/kMaxSps)-th
+            // block record of its phase, then the groups are added in group order (fixed order ->
+            // reproducible result)
+            const int p = tid % kMaxSps, g = tid / kMaxSps, ng = nt / kMaxSps;
+            {
+                double acc = 0;
+                if (p < sps) {
+                    const double *pp = A.partials + (int64_t)row * A.n_pblk * kMaxSps + p;
+                    for (int b = g; b < A.n_pblk; b += ng) acc += pp[(int64_t)b * kMaxSps];
+                }
+                cm.lds(tid) = acc;
+            }
+            cm.sync();
             double power = -1.0;
             if (tid < sps && tid % step == 0) {
                 const int64_t np_ = (n - tid) / sps;
                 if (n - tid > 0 && np_ > 0) {
-                    const double *pp = A.partials + (int64_t)row * A.n_pblk * kMaxSps + tid;
                     double acc = 0;
-                    for (int b = 0; b < A.n_pblk; ++b) acc += pp[(int64_t)b * kMaxSps];
+                    for (int gg = 0; gg < ng; ++gg) acc += cm.lds(gg * kMaxSps + tid);
                     power = acc / (double)np_;
                 }
             }
