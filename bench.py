@@ -48,6 +48,19 @@ def make_batch(carriers, chunk, fmt, rank):
     raise ValueError(fmt)
 
 
+def measured_traffic(samples_per_launch, fmt):
+    """HBM bytes per K1 launch from the last committed rocprofv3 PMC profile (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, separate passes; profiles/*_pmc_traffic.json), scaled per input sample.
+    PMC counters cannot be read from inside this script, hence the committed figure."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", "*_pmc_traffic.json")))
+    if not files or fmt != "cu8":
+        return None, None
+    with open(files[-1]) as f:
+        k1 = json.load(f)["k1"]
+    return k1["hbm_bytes_per_input_sample"] * samples_per_launch, os.path.basename(files[-1])
+
+
 def cpu_baseline(chunk, budget_s=10.0):
     """The CPU oracle (C restatement of the reference chain, single thread) on the same workload,
     bounded to ~budget_s of CPU work.  Reported next to the GPU number; never the thing shipped."""
@@ -134,6 +147,7 @@ def main():
         n_dec = bd.info.n_dec
         k1_bytes = samples_per_launch * in_bytes + args.carriers * n_dec * 16
         achieved_tf = samples_per_launch * FLOP_PER_INPUT_SAMPLE / (k1_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(samples_per_launch, args.fmt)
         out = {
             "metric": "Msymbols/s demodulated (reference-parity mode, hard symbols written)",
             "value": value,
@@ -161,7 +175,8 @@ def main():
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_flop_per_launch": samples_per_launch * FLOP_PER_INPUT_SAMPLE,
                 "avg_launch_ms": k1_ms,
                 "hbm": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
