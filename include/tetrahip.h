@@ -137,6 +137,18 @@ TDM_API int tdm_decimate(const double *x, int64_t n, int32_t q, double *y, int64
 /* resample (processor.py:35-49): scipy.signal.resample (FFT method) to `num` points */
 TDM_API int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t device);
 
+/* ---- burst synchronisation, the immediate consumer of process() -------------
+ * TetraDecoder.symbols_to_bits + TetraDecoder.find_sync (tetraear/core/decoder.py:140-169, :171-295),
+ * batched over rows.  units = hard symbols 0..3 (from_bits = 0; bit stream = (s>>1, s&1) per symbol) or
+ * the bit stream itself, one byte per bit (from_bits = 1).  Row r holds n_units[r] entries at
+ * units + r*row_stride.  positions [rows][max_pos] receives the accepted bit positions in order
+ * (n_pos[r] may exceed max_pos: only max_pos are stored), max_corr[r] the reference's max correlation.
+ * device_pointers != 0: units/n_units/positions/n_pos/max_corr are device memory (e.g. the `hard`
+ * and `n_soft` buffers of tdm_process_device, with n_units = n_soft-1 prepared by the caller).      */
+TDM_API int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_units, int32_t rows,
+                          int32_t from_bits, double threshold, int32_t max_pos, int32_t *positions,
+                          int32_t *n_pos, double *max_corr, int32_t device_pointers, int32_t device);
+
 /* ---- device memory helpers for callers without a HIP binding (bench, tests) ---------------- */
 TDM_API int tdm_dev_alloc(int32_t device, size_t bytes, void **ptr);
 TDM_API int tdm_dev_free(int32_t device, void *ptr);

@@ -15,6 +15,7 @@
 
 #include "../../tetraear_amd/csrc/ref_pipeline.hpp"
 #include "../../tetraear_amd/csrc/resample_plan.hpp"
+#include "../../tetraear_amd/csrc/sync_kernels.hpp"
 
 using namespace tdm;
 
@@ -230,6 +231,16 @@ int emu_resample(const double *x, int64_t n, int64_t num, double *y)
             dft_terms_body(cm, o, nullptr, X.data(), (int64_t)rp.term_src.size(), rp.term_src.data(),
                            rp.term_dst.data(), rp.term_w.data(), num, 1.0, 1.0 / (double)n, y);
         });
+    return 0;
+}
+
+int emu_find_sync(const uint8_t *units, int64_t n_units, int from_bits, double threshold, int max_pos,
+                  int32_t *positions, int32_t *n_pos, double *max_corr)
+{
+    const int64_t n_bits = from_bits ? n_units : 2 * n_units;
+    std::vector<uint16_t> counts((size_t)n_bits + 1, 0xffff);
+    for (int64_t pos = 0; pos < n_bits; ++pos) sync_count_body(units, n_bits, pos, from_bits, counts.data());
+    *n_pos = sync_walk_body(counts.data(), n_bits, threshold, positions, max_pos, max_corr);
     return 0;
 }
 

@@ -62,3 +62,14 @@ def resample(x, num):
     y = np.zeros(num, dtype=np.complex128)
     L.emu_resample(x.ctypes.data_as(C.c_void_p), C.c_int64(len(x)), C.c_int64(num), y.ctypes.data_as(C.c_void_p))
     return y
+
+
+def find_sync(units, from_bits, threshold, max_pos=64):
+    L = lib()
+    u = np.ascontiguousarray(units, dtype=np.uint8)
+    pos = np.zeros(max_pos, dtype=np.int32)
+    n = C.c_int32()
+    mc = C.c_double()
+    L.emu_find_sync(u.ctypes.data_as(C.c_void_p), C.c_int64(len(u)), int(from_bits), C.c_double(threshold), max_pos,
+                    pos.ctypes.data_as(C.c_void_p), C.byref(n), C.byref(mc))
+    return list(pos[:min(n.value, max_pos)]), mc.value

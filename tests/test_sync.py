@@ -1,0 +1,83 @@
+"""Burst sync: device kernel bodies (CPU emulation) and the GPU path against
+golden vectors made by running the reference's own find_sync."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden.make_golden_sync import make_case
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "sync.npz"))
+TS1 = [1, 1, 0, 1, 0, 0, 0, 0, 1, 1, 1, 0, 1, 0, 0, 1, 1, 1, 0, 1, 0, 0]
+
+
+def _cases():
+    for seed in G["seeds"]:
+        sym = make_case(int(seed))
+        for ti, thr in enumerate(G["thresholds"]):
+            yield int(seed), sym, float(thr), G[f"pos_{seed}_{ti}"], float(G[f"mc_{seed}_{ti}"][0])
+
+
+def test_emul_find_sync_matches_reference():
+    from tests.emul import emul
+    n_found = 0
+    for seed, sym, thr, g_pos, g_mc in _cases():
+        pos, mc = emul.find_sync(sym, False, thr, max_pos=64)
+        assert pos == list(g_pos), (seed, thr)
+        assert mc == g_mc, (seed, thr)          # counts/22 in double: exact
+        bits = np.empty(2 * len(sym), dtype=np.uint8)
+        bits[0::2] = sym >> 1
+        bits[1::2] = sym & 1
+        pos_b, mc_b = emul.find_sync(bits, True, thr, max_pos=64)
+        assert pos_b == pos and mc_b == mc
+        n_found += len(pos)
+    assert n_found > 500
+    bits = np.zeros(100, dtype=np.uint8)
+    bits[20:42] = TS1
+    pos, mc = emul.find_sync(bits, True, 0.8)
+    assert pos == list(G["unit_pos"]) and mc == float(G["unit_mc"][0])
+
+
+@pytest.mark.gpu
+def test_gpu_find_sync_matches_reference():
+    from tetraear_amd import sync
+    for seed, sym, thr, g_pos, g_mc in _cases():
+        pos, mc = sync.find_sync_symbols(sym, thr, return_max_corr=True)
+        assert pos == list(g_pos) and mc == g_mc, (seed, thr)
+    # reference unit tests (tests/unit/test_tetra_decoder.py:43-66)
+    assert sync.find_sync(np.array([0] * 10)) == []
+    bits = np.array([0] * 100)
+    bits[20:42] = TS1
+    pos, mc = sync.find_sync(bits, threshold=0.8, return_max_corr=True)
+    assert isinstance(pos, list) and isinstance(mc, float)
+    assert pos == list(G["unit_pos"]) and mc == float(G["unit_mc"][0])
+    rnd = np.random.default_rng(3).integers(0, 2, size=100)
+    assert isinstance(sync.find_sync(rnd, threshold=0.9), list)
+
+
+@pytest.mark.gpu
+def test_gpu_sync_batched_on_demodulator_output():
+    """process() -> find_sync chained: rows of hard symbols straight into the batched entry point."""
+    import ctypes as C
+    from tests.emul import emul
+    from tetraear_amd import _lib, synth
+    from tetraear_amd.batch import BatchDemodulator
+    rows, n = 6, 131072
+    u8 = np.concatenate([synth.dqpsk_cu8(n, 2.4e6, seed=40 + r)[0] for r in range(rows)])
+    bd = BatchDemodulator(2.4e6, n, rows, "cu8")
+    hards, softs, bp, mm = bd.process(u8)
+    ms = max(len(h) for h in hards)
+    units = np.zeros((rows, ms), dtype=np.uint8)
+    nun = np.zeros(rows, dtype=np.int32)
+    for r in range(rows):
+        units[r, :len(hards[r])] = hards[r]
+        nun[r] = len(hards[r])
+    pos = np.zeros((rows, 32), dtype=np.int32)
+    npos = np.zeros(rows, dtype=np.int32)
+    mc = np.zeros(rows)
+    _lib.check(_lib.load().tdm_find_sync(_lib.ptr(units), ms, _lib.ptr(nun), rows, 0, 0.8, 32, _lib.ptr(pos),
+                                         _lib.ptr(npos), _lib.ptr(mc), 0, 0))
+    for r in range(rows):
+        e_pos, e_mc = emul.find_sync(hards[r], False, 0.8, max_pos=32)
+        assert list(pos[r, :npos[r]]) == e_pos and mc[r] == e_mc
+    bd.close()

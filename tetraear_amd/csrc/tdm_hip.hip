@@ -14,6 +14,7 @@
 #include "../../include/tetrahip.h"
 #include "ref_pipeline.hpp"
 #include "resample_plan.hpp"
+#include "sync_kernels.hpp"
 
 using namespace tdm;
 
@@ -171,6 +172,28 @@ __global__ __launch_bounds__(kFinishThreads) void k_dft_terms(const int64_t *o_l
     __shared__ double sm[kFinishThreads / 64];
     BlockComm cm{sm, nullptr};
     dft_terms_body(cm, (int64_t)blockIdx.x, o_list, in, n_terms, src, freq, weight, n, sign, scale, out);
+}
+
+__global__ __launch_bounds__(256) void k_sync_count(const uint8_t *sym, int64_t row_stride, const int32_t *n_units,
+                                                    int from_bits, int64_t max_bits, uint16_t *counts)
+{
+    const int row = blockIdx.y;
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_bits = from_bits ? (int64_t)n_units[row] : 2 * (int64_t)n_units[row];
+    sync_count_body(sym + (int64_t)row * row_stride, n_bits, pos, from_bits, counts + (int64_t)row * max_bits);
+}
+
+__global__ __launch_bounds__(64) void k_sync_walk(const uint16_t *counts, const int32_t *n_units, int from_bits,
+                                                  int64_t max_bits, int rows, double threshold, int32_t *positions,
+                                                  int max_pos, int32_t *n_pos, double *max_corr)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int64_t n_bits = from_bits ? (int64_t)n_units[row] : 2 * (int64_t)n_units[row];
+    double mc;
+    n_pos[row] = sync_walk_body(counts + (int64_t)row * max_bits, n_bits, threshold,
+                                positions + (int64_t)row * max_pos, max_pos, &mc);
+    max_corr[row] = mc;
 }
 
 __global__ __launch_bounds__(256) void k_shift(const double *x, double *y, int64_t n, double f, double fs)
@@ -767,6 +790,56 @@ int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t dev
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(y, dy.p, (size_t)num * 16, hipMemcpyDeviceToHost));
+    return TDM_OK;
+}
+
+// ---- burst sync: TetraDecoder.find_sync on the hard symbols, batched ---------------
+int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_units, int32_t rows, int32_t from_bits,
+                  double threshold, int32_t max_pos, int32_t *positions, int32_t *n_pos, double *max_corr,
+                  int32_t device_pointers, int32_t device)
+{
+    if (!units || !n_units || !positions || !n_pos || !max_corr || rows < 1 || max_pos < 1 || row_stride < 0)
+        return fail(TDM_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf du, dn, dp, dnp, dmc, dcnt;
+    const uint8_t *u = units;
+    const int32_t *nu = n_units;
+    int32_t *pp = positions, *np_ = n_pos;
+    double *mc = max_corr;
+    std::vector<int32_t> hn(rows);
+    if (device_pointers) {
+        HIP_TRY(hipMemcpy(hn.data(), n_units, rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+    } else {
+        std::memcpy(hn.data(), n_units, rows * sizeof(int32_t));
+    }
+    int64_t max_units = 0;
+    for (int r = 0; r < rows; ++r) {
+        if (hn[r] < 0 || hn[r] > row_stride) return fail(TDM_ERR_INVALID, "n_units out of range");
+        if (hn[r] > max_units) max_units = hn[r];
+    }
+    const int64_t max_bits = (from_bits ? max_units : 2 * max_units) + 1;
+    if (!device_pointers) {
+        if ((rc = du.alloc((size_t)rows * row_stride + 1)) || (rc = dn.alloc(rows * 4)) ||
+            (rc = dp.alloc((size_t)rows * max_pos * 4)) || (rc = dnp.alloc(rows * 4)) || (rc = dmc.alloc(rows * 8)))
+            return rc;
+        HIP_TRY(hipMemcpy(du.p, units, (size_t)rows * row_stride, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dn.p, n_units, rows * 4, hipMemcpyHostToDevice));
+        u = du.as<uint8_t>(); nu = dn.as<int32_t>(); pp = dp.as<int32_t>(); np_ = dnp.as<int32_t>(); mc = dmc.as<double>();
+    }
+    if ((rc = dcnt.alloc((size_t)rows * max_bits * 2))) return rc;
+    hipLaunchKernelGGL(k_sync_count, dim3((unsigned)((max_bits + 255) / 256), rows), dim3(256), 0, 0, u, row_stride, nu,
+                       from_bits, max_bits, dcnt.as<uint16_t>());
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_sync_walk, dim3((rows + 63) / 64), dim3(64), 0, 0, dcnt.as<uint16_t>(), nu, from_bits, max_bits,
+                       rows, threshold, pp, max_pos, np_, mc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (!device_pointers) {
+        HIP_TRY(hipMemcpy(positions, dp.p, (size_t)rows * max_pos * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(n_pos, dnp.p, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(max_corr, dmc.p, rows * 8, hipMemcpyDeviceToHost));
+    }
     return TDM_OK;
 }
 
