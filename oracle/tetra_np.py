@@ -1,0 +1,122 @@
+"""ORACLE for TETRA mode (test infrastructure): fp64 numpy restatement of the tetra-mode receiver.
+
+TETRA mode has NO reference implementation: syrex1013/TetraEar contains no RRC filter, no timing
+recovery and no pi/4-DQPSK quadrant slicer.  This file therefore pins nothing
+against the reference ("parity unpinned" for this mode); it is the project's own definition of
+the algorithm, written in plain numpy/fp64, against which the fp32 HIP kernels are checked, and
+which is itself checked against the known transmitted symbols of the synthetic generator.
+
+Algorithm (per carrier, per chunk, stateless like the reference's process()):
+  1. matched filter: centred root-raised-cosine FIR (alpha 0.35, span 8 symbols, unit energy),
+     zero-padded at the chunk edges; output at the input rate.
+  2. timing: feed-forward square-law (Oerder-Meyr) estimate per sub-block of `TB` samples,
+     C_b = sum |y[n]|^2 exp(-2 pi i n / sps); vector-averaged over +-`TW` sub-blocks with prefix
+     sums; tau_b = -arg(C_b)/(2 pi) unwrapped along the chunk; linear interpolation between
+     sub-block centres gives tau(k) for symbol k.
+  3. symbol instants t_k = (k + tau(k)) * sps; cubic Lagrange (Farrow) interpolation of y.
+  4. differential detection d_k = s_k conj(s_{k-1}); residual carrier offset from the 4th-power
+     estimate delta = arg(-sum d_k^4)/4; decision = quadrant of d_k exp(-i delta):
+     +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3 (ETSI EN 300 392-2 table 5.1 as quoted in
+     tetraear/signal/processor.py:106-110).
+"""
+import numpy as np
+
+SYMBOL_RATE = 18000.0
+ALPHA = 0.35
+SPAN = 8      # symbols
+TB = 256      # samples per timing sub-block
+TW = 2        # sub-blocks averaged on each side
+
+
+def rrc_taps(sps, alpha=ALPHA, span=SPAN):
+    """Centred RRC taps, odd length, unit energy."""
+    half = int(np.floor(span * sps / 2))
+    t = np.arange(-half, half + 1, dtype=np.float64) / sps
+    h = np.empty_like(t)
+    eps = 1e-9
+    for i, ti in enumerate(t):
+        if abs(ti) < eps:
+            h[i] = 1.0 - alpha + 4 * alpha / np.pi
+        elif abs(abs(ti) - 1.0 / (4 * alpha)) < eps:
+            h[i] = (alpha / np.sqrt(2)) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * alpha))
+                                           + (1 - 2 / np.pi) * np.cos(np.pi / (4 * alpha)))
+        else:
+            h[i] = (np.sin(np.pi * ti * (1 - alpha)) + 4 * alpha * ti * np.cos(np.pi * ti * (1 + alpha))) \
+                / (np.pi * ti * (1 - (4 * alpha * ti) ** 2))
+    return h / np.sqrt(np.sum(h * h))
+
+
+def matched_filter(x, h):
+    """y[n] = sum_t h[t] x[n + t - (T-1)/2], zero outside the chunk (h is symmetric)."""
+    return np.convolve(x, h, mode="same")
+
+
+def timing_estimates(y, sps):
+    n = len(y)
+    nb = (n + TB - 1) // TB
+    idx = np.arange(n, dtype=np.float64)
+    w = (np.abs(y) ** 2) * np.exp(-2j * np.pi * idx / sps)
+    C = np.array([np.sum(w[b * TB:(b + 1) * TB]) for b in range(nb)])
+    P = np.concatenate([[0], np.cumsum(C)])
+    Cs = np.array([P[min(nb, b + TW + 1)] - P[max(0, b - TW)] for b in range(nb)])
+    tau = -np.angle(Cs) / (2 * np.pi)
+    # unwrap in units of one symbol
+    out = np.empty(nb)
+    prev = 0.0
+    for b in range(nb):
+        t = tau[b]
+        if b > 0:
+            t += np.round(prev - t)
+        out[b] = t
+        prev = t
+    return out
+
+
+def tau_of_sample(pos, tau_b):
+    """piecewise-linear tau at sample position pos (sub-block centres at (b+0.5)*TB)."""
+    nb = len(tau_b)
+    u = pos / TB - 0.5
+    b0 = np.clip(np.floor(u).astype(np.int64), 0, max(nb - 2, 0))
+    if nb == 1:
+        return np.full_like(np.asarray(pos, dtype=np.float64), tau_b[0])
+    f = np.clip(u - b0, 0.0, 1.0)
+    return tau_b[b0] * (1 - f) + tau_b[b0 + 1] * f
+
+
+def farrow(y, t):
+    """cubic Lagrange interpolation of y at fractional positions t (1 <= t <= len-3)."""
+    m = np.floor(t).astype(np.int64)
+    mu = t - m
+    ym1, y0, y1, y2 = y[m - 1], y[m], y[m + 1], y[m + 2]
+    c0 = y0
+    c1 = y1 - ym1 / 3 - y0 / 2 - y2 / 6
+    c2 = (ym1 + y1) / 2 - y0
+    c3 = (y2 - ym1) / 6 + (y0 - y1) / 2
+    return ((c3 * mu + c2) * mu + c1) * mu + c0
+
+
+def demod(x, sample_rate):
+    """Returns (hard uint8[n_sym-1], soft complex[n_sym-1] = derotated d_k, info dict)."""
+    x = np.asarray(x, dtype=np.complex128)
+    sps = sample_rate / SYMBOL_RATE
+    h = rrc_taps(sps)
+    y = matched_filter(x, h)
+    n = len(y)
+    tau_b = timing_estimates(y, sps)
+    # symbol instants: k such that 1 <= t_k <= n-3 using the nominal position k*sps for tau lookup
+    kmax = int(np.floor(n / sps)) + 2
+    k = np.arange(0, kmax, dtype=np.float64)
+    t = (k + tau_of_sample(k * sps, tau_b)) * sps
+    ok = (t >= 1.0) & (t <= n - 3.0)
+    t = t[ok]
+    s = farrow(y, t)
+    d = s[1:] * np.conj(s[:-1])
+    if len(d) == 0:
+        return np.zeros(0, np.uint8), d, dict(tau=tau_b, delta=0.0, n_sym=len(s), sym=s, t=t)
+    acc = np.sum(d ** 4)
+    delta = np.angle(-acc) / 4 if acc != 0 else 0.0
+    dd = d * np.exp(-1j * delta)
+    hard = np.where(dd.imag >= 0, np.where(dd.real >= 0, 0, 1), np.where(dd.real >= 0, 2, 3)).astype(np.uint8)
+    margin = np.min(np.minimum(np.arctan2(np.abs(dd.imag), np.abs(dd.real)),
+                               np.pi / 2 - np.arctan2(np.abs(dd.imag), np.abs(dd.real))))
+    return hard, dd, dict(tau=tau_b, delta=delta, n_sym=len(s), t=t, sym=s, margin=margin)

@@ -15,6 +15,7 @@
 #include "ref_pipeline.hpp"
 #include "resample_plan.hpp"
 #include "sync_kernels.hpp"
+#include "tetra_kernels.hpp"
 
 using namespace tdm;
 
@@ -205,9 +206,10 @@ __global__ __launch_bounds__(256) void k_shift(const double *x, double *y, int64
 // ------------------------------------------------------------------------------------------
 // stage timing (HIP events around each launch, on the stream the kernels run on)
 // ------------------------------------------------------------------------------------------
-enum Stage { ST_DEC_BLOCK = 0, ST_DEC_CARRY, ST_DEC_FIXUP, ST_CONVERT, ST_LPF_BLOCK, ST_LPF_CARRY, ST_LPF_FIXUP, ST_FINISH, ST_COUNT };
+enum Stage { ST_DEC_BLOCK = 0, ST_DEC_CARRY, ST_DEC_FIXUP, ST_CONVERT, ST_LPF_BLOCK, ST_LPF_CARRY, ST_LPF_FIXUP, ST_FINISH, ST_TETRA_RRC, ST_TETRA_SYM, ST_COUNT };
 static const char *kStageNames[ST_COUNT] = {"dec_block", "dec_carry", "dec_fixup", "convert",
-                                            "lpf_block", "lpf_carry", "lpf_fixup", "finish"};
+                                            "lpf_block", "lpf_carry", "lpf_fixup", "finish",
+                                            "tetra_rrc", "tetra_sym"};
 
 struct StageTimer {
     bool on = false;
@@ -296,6 +298,32 @@ struct HipBackend {
     }
 };
 
+// centred root-raised-cosine taps, alpha 0.35, span 8 symbols, odd length, unit energy
+// (the definition in oracle/tetra_np.py rrc_taps)
+static std::vector<double> tetra_rrc_taps(double sps)
+{
+    const double alpha = 0.35;
+    const int span = 8;
+    const int half = (int)std::floor(span * sps / 2);
+    std::vector<double> h(2 * half + 1);
+    double e = 0;
+    for (int i = -half; i <= half; ++i) {
+        const double t = (double)i / sps;
+        double v;
+        if (std::fabs(t) < 1e-9)
+            v = 1.0 - alpha + 4 * alpha / M_PI;
+        else if (std::fabs(std::fabs(t) - 1.0 / (4 * alpha)) < 1e-9)
+            v = (alpha / std::sqrt(2.0)) * ((1 + 2 / M_PI) * std::sin(M_PI / (4 * alpha)) + (1 - 2 / M_PI) * std::cos(M_PI / (4 * alpha)));
+        else
+            v = (std::sin(M_PI * t * (1 - alpha)) + 4 * alpha * t * std::cos(M_PI * t * (1 + alpha))) /
+                (M_PI * t * (1 - (4 * alpha * t) * (4 * alpha * t)));
+        h[i + half] = v;
+        e += v * v;
+    }
+    for (auto &v : h) v /= std::sqrt(e);
+    return h;
+}
+
 // ------------------------------------------------------------------------------------------
 // device copies of a zero-phase stage
 // ------------------------------------------------------------------------------------------
@@ -339,6 +367,9 @@ struct tdm_plan {
     int rows = 0, fmt = 0, mode = 0, device = 0;
     DevZp dec, lpf;
     double *d_y = nullptr, *d_z = nullptr, *d_partials = nullptr;
+    // TETRA mode
+    TetraParams tp{};
+    float2 *d_ty = nullptr, *d_tsym = nullptr;
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -358,7 +389,7 @@ static void plan_free(tdm_plan *p)
     (void)hipSetDevice(p->device);
     p->dec.destroy();
     p->lpf.destroy();
-    void *ptrs[] = {p->d_y, p->d_z, p->d_partials, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    void *ptrs[] = {p->d_y, p->d_z, p->d_partials, p->d_ty, p->d_tsym, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -394,7 +425,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     *out = nullptr;
     if (!(sample_rate > 0) || n_samples < 1 || n_carriers < 1 || n_carriers > 65535 || in_fmt < 0 || in_fmt > 3)
         return fail(TDM_ERR_INVALID, "bad sample_rate / n_samples / n_carriers (1..65535) / in_fmt");
-    if (mode != TDM_MODE_REFERENCE) return fail(TDM_ERR_UNSUPPORTED, "only TDM_MODE_REFERENCE is built in this version");
+    if (mode != TDM_MODE_REFERENCE && mode != TDM_MODE_TETRA) return fail(TDM_ERR_INVALID, "bad mode");
     int rc = use_device(device);
     if (rc) return rc;
     std::unique_ptr<tdm_plan, void (*)(tdm_plan *)> p(new tdm_plan, plan_free);
@@ -402,6 +433,36 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     p->rows = n_carriers;
     p->fmt = in_fmt;
     p->mode = mode;
+    if (mode == TDM_MODE_TETRA) {
+        // channelised baseband in: sample_rate is the per-carrier rate, >= 2 samples per symbol
+        if (in_fmt != TDM_CF32) return fail(TDM_ERR_UNSUPPORTED, "TETRA mode takes cf32 channelised baseband");
+        const double sps = sample_rate / kSymbolRate;
+        if (sps < 2.0 || sps > 8.0) return fail(TDM_ERR_UNSUPPORTED, "TETRA mode needs 2..8 samples per symbol");
+        if (n_samples < 64 || n_samples > (int64_t)kMaxTimingBlocks * kTimingBlock)
+            return fail(TDM_ERR_UNSUPPORTED, "TETRA mode chunk length must be 64..131072 samples");
+        std::vector<double> h = tetra_rrc_taps(sps);
+        if ((int)h.size() > kRrcMaxTaps) return fail(TDM_ERR_UNSUPPORTED, "too many RRC taps");
+        TetraParams &tp = p->tp;
+        tp.n = (int32_t)n_samples;
+        tp.ntaps = (int32_t)h.size();
+        tp.sps = sps;
+        tp.max_soft = (int32_t)(n_samples / sps) + 4;
+        for (size_t i = 0; i < h.size(); ++i) tp.taps[i] = (float)h[i];
+        p->h.sample_rate = sample_rate;
+        p->h.n = n_samples;
+        p->h.n_dec = n_samples;
+        p->h.rate_dec = sample_rate;
+        p->h.sps = (int)sps;
+        p->h.max_soft = tp.max_soft;
+        p->h.lpf = true;
+        HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&p->ev0));
+        HIP_TRY(hipEventCreate(&p->ev1));
+        HIP_TRY(hipMalloc(&p->d_ty, (size_t)n_carriers * n_samples * sizeof(float2)));
+        HIP_TRY(hipMalloc(&p->d_tsym, (size_t)n_carriers * tp.max_soft * sizeof(float2)));
+        *out = p.release();
+        return TDM_OK;
+    }
     p->h = build_ref_plan(sample_rate, n_samples);
     const RefPlanHost &h = p->h;
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -454,6 +515,30 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     HipBackend be;
     be.stream = stream ? (hipStream_t)stream : plan->stream;
     be.timer = &plan->timer;
+    if (plan->mode == TDM_MODE_TETRA) {
+        if (pre_shift_hz || freq_offset_hz)
+            return fail(TDM_ERR_UNSUPPORTED, "TETRA mode: carrier offsets are estimated, not supplied");
+        if (carrier_stride_samples != plan->tp.n) return fail(TDM_ERR_INVALID, "TETRA mode: carriers must be contiguous");
+        const TetraParams &tp = plan->tp;
+        const dim3 grid((tp.n + kRrcTile - 1) / kRrcTile, plan->rows);
+        {
+            HipBackend::Scope s(be, ST_TETRA_RRC);
+            const float2 *x = (const float2 *)iq;
+            switch (tp.ntaps) {
+#define TDM_RRC_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_rrc<NT>), grid, dim3(kRrcThreads), 0, be.stream, x, plan->d_ty, tp); break;
+                TDM_RRC_CASE(17) TDM_RRC_CASE(25) TDM_RRC_CASE(33) TDM_RRC_CASE(35) TDM_RRC_CASE(41) TDM_RRC_CASE(49) TDM_RRC_CASE(57) TDM_RRC_CASE(65)
+#undef TDM_RRC_CASE
+            default: return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
+            }
+        }
+        {
+            HipBackend::Scope s(be, ST_TETRA_SYM);
+            hipLaunchKernelGGL(k_tetra_sym, dim3(plan->rows), dim3(kSymThreads), 0, be.stream, plan->d_ty, tp, plan->d_tsym, hard,
+                               soft, n_soft, best_phase, min_margin);
+        }
+        if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
+        return TDM_OK;
+    }
     RefBuffers B;
     B.dec_params = plan->dec.params;
     B.lpf_params = plan->lpf.params;

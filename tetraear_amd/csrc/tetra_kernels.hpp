@@ -1,0 +1,264 @@
+// TETRA mode (north-star receiver): per-carrier pi/4-DQPSK demodulation of channelised baseband.
+//
+// There is no reference implementation of this mode: the algorithm is defined by
+// oracle/tetra_np.py (fp64 numpy) and restated here in fp32 for gfx950:
+//   k_tetra_rrc : root-raised-cosine matched filter, LDS-tiled sliding window, one pass
+//                 HBM -> LDS -> registers -> LDS -> HBM (8 B in + 8 B out per sample, HBM-bound)
+//   k_tetra_sym : feed-forward square-law timing estimate (wavefront reductions + prefix sums),
+//                 cubic Farrow interpolation at the symbol instants, 4th-power carrier-offset
+//                 estimate, differential quadrant decision.  One workgroup per carrier chunk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tdm {
+
+constexpr int kRrcMaxTaps = 96;
+constexpr int kRrcThreads = 256;
+constexpr int kRrcPerThread = 8;                          // consecutive outputs per thread
+constexpr int kRrcTile = kRrcThreads * kRrcPerThread;     // 2048 samples per workgroup
+constexpr int kTimingBlock = 256;                         // samples per timing sub-block (TB)
+constexpr int kTimingHalfWin = 2;                         // sub-blocks averaged each side (TW)
+constexpr int kMaxTimingBlocks = 512;
+constexpr int kSymThreads = 256;
+
+struct TetraParams {
+    int32_t n;          // samples per carrier chunk
+    int32_t ntaps;      // odd
+    int32_t max_soft;   // capacity of per-carrier symbol outputs
+    int32_t pad_;
+    double sps;         // samples per symbol (sample_rate / 18000)
+    float taps[kRrcMaxTaps];
+};
+
+// LDS index of tile sample s: one pad slot per 8 samples so that a thread's 8-sample-strided
+// window reads (ds_read_b64, lane stride 9 slots = 18 dwords) hit 32 distinct bank pairs.
+__device__ __forceinline__ int rrc_slot(int s) { return s + (s >> 3); }
+
+template <int NT>
+__global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restrict__ x, float2 *__restrict__ y,
+                                                            const TetraParams P)
+{
+    constexpr int HALO = NT - 1;
+    constexpr int NS = kRrcTile + HALO;  // samples staged
+    __shared__ float2 lds[NS + NS / 8 + 2];
+    const int row = blockIdx.y;
+    const int n = P.n;
+    const int64_t base = (int64_t)blockIdx.x * kRrcTile;          // first output of the tile
+    const float2 *xr = x + (int64_t)row * n;
+    float2 *yr = y + (int64_t)row * n;
+    const int t = threadIdx.x;
+    // stage inputs base - HALO/2 .. base + tile + HALO/2 (zero outside the chunk), coalesced
+    for (int s = t; s < NS; s += kRrcThreads) {
+        const int64_t g = base + s - HALO / 2;
+        float2 v = make_float2(0.f, 0.f);
+        if (g >= 0 && g < n) v = xr[g];
+        lds[rrc_slot(s)] = v;
+    }
+    __syncthreads();
+    // sliding window in registers: outputs base + 8t + v need staged samples 8t + v .. 8t + v + NT-1
+    float2 w[kRrcPerThread + HALO];
+#pragma unroll
+    for (int j = 0; j < kRrcPerThread + HALO; ++j) w[j] = lds[rrc_slot(kRrcPerThread * t + j)];
+    float2 acc[kRrcPerThread];
+#pragma unroll
+    for (int v = 0; v < kRrcPerThread; ++v) acc[v] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const float h = P.taps[k];
+#pragma unroll
+        for (int v = 0; v < kRrcPerThread; ++v) {
+            acc[v].x = fmaf(h, w[v + k].x, acc[v].x);
+            acc[v].y = fmaf(h, w[v + k].y, acc[v].y);
+        }
+    }
+    __syncthreads();
+    // transpose through LDS so that the stores are coalesced
+#pragma unroll
+    for (int v = 0; v < kRrcPerThread; ++v) lds[rrc_slot(kRrcPerThread * t + v)] = acc[v];
+    __syncthreads();
+    for (int s = t; s < kRrcTile; s += kRrcThreads) {
+        const int64_t g = base + s;
+        if (g < n) yr[g] = lds[rrc_slot(s)];
+    }
+}
+
+// ---- workgroup helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ float block_sum(float v, float *sm)
+{
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_min(float v, float *sm)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fminf(r, sm[i]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// cubic Lagrange (Farrow) interpolation at position t (1 <= t <= n-3)
+__device__ __forceinline__ float2 farrow_at(const float2 *y, double t)
+{
+    const int m = (int)floor(t);
+    const float mu = (float)(t - (double)m);
+    const float2 ym1 = y[m - 1], y0 = y[m], y1 = y[m + 1], y2 = y[m + 2];
+    float2 r;
+    {
+        const float c1 = y1.x - ym1.x * (1.f / 3.f) - y0.x * 0.5f - y2.x * (1.f / 6.f);
+        const float c2 = (ym1.x + y1.x) * 0.5f - y0.x;
+        const float c3 = (y2.x - ym1.x) * (1.f / 6.f) + (y0.x - y1.x) * 0.5f;
+        r.x = ((c3 * mu + c2) * mu + c1) * mu + y0.x;
+    }
+    {
+        const float c1 = y1.y - ym1.y * (1.f / 3.f) - y0.y * 0.5f - y2.y * (1.f / 6.f);
+        const float c2 = (ym1.y + y1.y) * 0.5f - y0.y;
+        const float c3 = (y2.y - ym1.y) * (1.f / 6.f) + (y0.y - y1.y) * 0.5f;
+        r.y = ((c3 * mu + c2) * mu + c1) * mu + y0.y;
+    }
+    return r;
+}
+
+// piecewise-linear timing estimate at sample position pos (sub-block centres at (b+0.5)*TB)
+__device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
+{
+    if (nb == 1) return tau[0];
+    const double u = pos / (double)kTimingBlock - 0.5;
+    int b0 = (int)floor(u);
+    if (b0 < 0) b0 = 0;
+    if (b0 > nb - 2) b0 = nb - 2;
+    double f = u - (double)b0;
+    if (f < 0.0) f = 0.0;
+    if (f > 1.0) f = 1.0;
+    return (float)((double)tau[b0] * (1.0 - f) + (double)tau[b0 + 1] * f);
+}
+
+__global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restrict__ y, const TetraParams P,
+                                                            float2 *__restrict__ sym_scratch, uint8_t *hard, double *soft,
+                                                            int32_t *n_soft, int32_t *timing_milli, double *min_margin)
+{
+    __shared__ float Cr[kMaxTimingBlocks + 1], Ci[kMaxTimingBlocks + 1];  // later: prefix sums
+    __shared__ float tau[kMaxTimingBlocks];
+    __shared__ float sm[kSymThreads / 64];
+    __shared__ int k_lo_s, n_sym_s;
+    __shared__ float delta_s;
+    const int row = blockIdx.x;
+    const int n = P.n;
+    const double sps = P.sps;
+    const float2 *yr = y + (int64_t)row * n;
+    float2 *sr = sym_scratch + (int64_t)row * P.max_soft;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = (n + kTimingBlock - 1) / kTimingBlock;
+    // 1. square-law timing statistic per sub-block (one wavefront per sub-block, round robin)
+    for (int b = wv; b < nb; b += kSymThreads / 64) {
+        float ar = 0.f, ai = 0.f;
+        for (int i = lane; i < kTimingBlock; i += 64) {
+            const int g = b * kTimingBlock + i;
+            if (g < n) {
+                const float2 v = yr[g];
+                const float p = v.x * v.x + v.y * v.y;
+                const double ph = (double)g / sps;               // cycles of the symbol clock
+                const float fr = (float)(ph - floor(ph));
+                float s, c;
+                sincospif(-2.f * fr, &s, &c);
+                ar = fmaf(p, c, ar);
+                ai = fmaf(p, s, ai);
+            }
+        }
+        ar = wave_sum(ar);
+        ai = wave_sum(ai);
+        if (lane == 0) { Cr[b + 1] = ar; Ci[b + 1] = ai; }
+    }
+    __syncthreads();
+    // 2. prefix sums, vector average over +-TW sub-blocks, arg, unwrap (<= 512 terms: one thread)
+    if (tid == 0) {
+        Cr[0] = 0.f; Ci[0] = 0.f;
+        for (int b = 1; b <= nb; ++b) { Cr[b] += Cr[b - 1]; Ci[b] += Ci[b - 1]; }
+        float prev = 0.f;
+        for (int b = 0; b < nb; ++b) {
+            const int hi = min(nb, b + kTimingHalfWin + 1), lo = max(0, b - kTimingHalfWin);
+            const float cr = Cr[hi] - Cr[lo], ci = Ci[hi] - Ci[lo];
+            float tb = -atan2f(ci, cr) * 0.15915494309189535f;  // / (2 pi)
+            if (b > 0) tb += rintf(prev - tb);
+            tau[b] = tb;
+            prev = tb;
+        }
+        // symbol index range: t_k = (k + tau(k*sps)) * sps must lie in [1, n-3]
+        int k_lo = 0;
+        while (k_lo < 8 && ((double)k_lo + (double)tau_at(tau, nb, k_lo * sps)) * sps < 1.0) ++k_lo;
+        int k_hi = (int)floor((double)n / sps) + 1;
+        while (k_hi >= k_lo && ((double)k_hi + (double)tau_at(tau, nb, k_hi * sps)) * sps > (double)n - 3.0) --k_hi;
+        int ns = k_hi - k_lo + 1;
+        if (ns < 0) ns = 0;
+        if (ns > P.max_soft) ns = P.max_soft;
+        k_lo_s = k_lo;
+        n_sym_s = ns;
+    }
+    __syncthreads();
+    const int k_lo = k_lo_s, ns = n_sym_s;
+    // 3. interpolate the matched-filter output at the symbol instants
+    for (int i = tid; i < ns; i += kSymThreads) {
+        const int k = k_lo + i;
+        const double t = ((double)k + (double)tau_at(tau, nb, (double)k * sps)) * sps;
+        const float2 s = farrow_at(yr, t);
+        sr[i] = s;
+        soft[((int64_t)row * P.max_soft + i) * 2] = (double)s.x;
+        soft[((int64_t)row * P.max_soft + i) * 2 + 1] = (double)s.y;
+    }
+    __syncthreads();
+    // 4. differential products and the 4th-power carrier-offset estimate
+    float a4r = 0.f, a4i = 0.f;
+    for (int i = 1 + tid; i < ns; i += kSymThreads) {
+        const float2 c = sr[i], p = sr[i - 1];
+        const float2 d = make_float2(c.x * p.x + c.y * p.y, c.y * p.x - c.x * p.y);
+        const float2 d2 = cmulf(d, d);
+        const float2 d4 = cmulf(d2, d2);
+        a4r += d4.x;
+        a4i += d4.y;
+    }
+    a4r = block_sum(a4r, sm);
+    a4i = block_sum(a4i, sm);
+    if (tid == 0) delta_s = (a4r == 0.f && a4i == 0.f) ? 0.f : atan2f(-a4i, -a4r) * 0.25f;
+    __syncthreads();
+    float rs, rc;
+    sincosf(-delta_s, &rs, &rc);
+    // 5. quadrant decision of d_k exp(-i delta): +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3
+    float margin = 3.4e38f;
+    for (int i = 1 + tid; i < ns; i += kSymThreads) {
+        const float2 c = sr[i], p = sr[i - 1];
+        const float2 d = make_float2(c.x * p.x + c.y * p.y, c.y * p.x - c.x * p.y);
+        const float2 dd = make_float2(d.x * rc - d.y * rs, d.x * rs + d.y * rc);
+        const uint8_t h = dd.y >= 0.f ? (dd.x >= 0.f ? 0 : 1) : (dd.x >= 0.f ? 2 : 3);
+        hard[(int64_t)row * P.max_soft + i - 1] = h;
+        // angular distance to the nearest decision boundary (an axis)
+        const float ang = atan2f(fabsf(dd.y), fabsf(dd.x));      // 0 .. pi/2
+        margin = fminf(margin, fminf(ang, 1.5707963267948966f - ang));
+    }
+    margin = block_min(margin, sm);
+    if (tid == 0) {
+        n_soft[row] = ns;
+        if (timing_milli) timing_milli[row] = (int32_t)rintf(tau[nb / 2] * 1000.f);
+        if (min_margin) min_margin[row] = (double)margin;
+    }
+}
+
+}  // namespace tdm
