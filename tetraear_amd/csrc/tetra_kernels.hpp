@@ -31,6 +31,8 @@ struct TetraParams {
     float taps[kRrcMaxTaps];
 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // LDS index of tile sample s: one pad slot per 8 samples so that a thread's 8-sample-strided
 // window reads (ds_read_b64, lane stride 9 slots = 18 dwords) hit 32 distinct bank pairs.
 __device__ __forceinline__ int rrc_slot(int s) { return s + (s >> 3); }
@@ -48,12 +50,30 @@ __global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restr
     const float2 *xr = x + (int64_t)row * n;
     float2 *yr = y + (int64_t)row * n;
     const int t = threadIdx.x;
-    // stage inputs base - HALO/2 .. base + tile + HALO/2 (zero outside the chunk), coalesced
-    for (int s = t; s < NS; s += kRrcThreads) {
-        const int64_t g = base + s - HALO / 2;
-        float2 v = make_float2(0.f, 0.f);
-        if (g >= 0 && g < n) v = xr[g];
-        lds[rrc_slot(s)] = v;
+    // stage inputs base - HALO/2 .. base + tile + HALO/2 (zero outside the chunk), coalesced;
+    // 16 bytes per lane (two samples) when the tile start is 16-byte aligned in the row
+    if (((HALO / 2) & 1) == 0 && (n & 1) == 0) {
+        const f32x4 *x4 = (const f32x4 *)xr;
+        for (int s2 = t; s2 < NS / 2; s2 += kRrcThreads) {
+            const int s = 2 * s2;
+            const int64_t g = base + s - HALO / 2;  // even
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (g >= 0 && g + 1 < n) v = __builtin_nontemporal_load(x4 + (g >> 1));
+            lds[rrc_slot(s)] = make_float2(v.x, v.y);
+            lds[rrc_slot(s + 1)] = make_float2(v.z, v.w);
+        }
+        if ((NS & 1) && t == 0) {
+            const int s = NS - 1;
+            const int64_t g = base + s - HALO / 2;
+            lds[rrc_slot(s)] = (g >= 0 && g < n) ? xr[g] : make_float2(0.f, 0.f);
+        }
+    } else {
+        for (int s = t; s < NS; s += kRrcThreads) {
+            const int64_t g = base + s - HALO / 2;
+            float2 v = make_float2(0.f, 0.f);
+            if (g >= 0 && g < n) v = xr[g];
+            lds[rrc_slot(s)] = v;
+        }
     }
     __syncthreads();
     // sliding window in registers: outputs base + 8t + v need staged samples 8t + v .. 8t + v + NT-1
@@ -77,9 +97,22 @@ __global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restr
 #pragma unroll
     for (int v = 0; v < kRrcPerThread; ++v) lds[rrc_slot(kRrcPerThread * t + v)] = acc[v];
     __syncthreads();
-    for (int s = t; s < kRrcTile; s += kRrcThreads) {
-        const int64_t g = base + s;
-        if (g < n) yr[g] = lds[rrc_slot(s)];
+    if ((n & 1) == 0) {
+        f32x4 *y4 = (f32x4 *)yr;
+        for (int s2 = t; s2 < kRrcTile / 2; s2 += kRrcThreads) {
+            const int s = 2 * s2;
+            const int64_t g = base + s;
+            if (g + 1 < n) {
+                const float2 a = lds[rrc_slot(s)], b = lds[rrc_slot(s + 1)];
+                const f32x4 o = {a.x, a.y, b.x, b.y};
+                __builtin_nontemporal_store(o, y4 + (g >> 1));
+            }
+        }
+    } else {
+        for (int s = t; s < kRrcTile; s += kRrcThreads) {
+            const int64_t g = base + s;
+            if (g < n) yr[g] = lds[rrc_slot(s)];
+        }
     }
 }
 
