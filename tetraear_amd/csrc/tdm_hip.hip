@@ -369,7 +369,7 @@ struct tdm_plan {
     double *d_y = nullptr, *d_z = nullptr, *d_partials = nullptr;
     // TETRA mode
     TetraParams tp{};
-    float2 *d_ty = nullptr, *d_tsym = nullptr;
+    float2 *d_ty = nullptr, *d_tsym = nullptr, *d_tstat = nullptr;
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -389,7 +389,7 @@ static void plan_free(tdm_plan *p)
     (void)hipSetDevice(p->device);
     p->dec.destroy();
     p->lpf.destroy();
-    void *ptrs[] = {p->d_y, p->d_z, p->d_partials, p->d_ty, p->d_tsym, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    void *ptrs[] = {p->d_y, p->d_z, p->d_partials, p->d_ty, p->d_tsym, p->d_tstat, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -446,6 +446,9 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         tp.n = (int32_t)n_samples;
         tp.ntaps = (int32_t)h.size();
         tp.sps = sps;
+        tp.inv_sps = 1.0 / sps;
+        tp.step_c = (float)std::cos(-2.0 * M_PI / sps);
+        tp.step_s = (float)std::sin(-2.0 * M_PI / sps);
         tp.max_soft = (int32_t)(n_samples / sps) + 4;
         for (size_t i = 0; i < h.size(); ++i) tp.taps[i] = (float)h[i];
         p->h.sample_rate = sample_rate;
@@ -460,6 +463,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         HIP_TRY(hipEventCreate(&p->ev1));
         HIP_TRY(hipMalloc(&p->d_ty, (size_t)n_carriers * n_samples * sizeof(float2)));
         HIP_TRY(hipMalloc(&p->d_tsym, (size_t)n_carriers * tp.max_soft * sizeof(float2)));
+        HIP_TRY(hipMalloc(&p->d_tstat, (size_t)n_carriers * kMaxTimingBlocks * sizeof(float2)));
         *out = p.release();
         return TDM_OK;
     }
@@ -525,7 +529,7 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
             HipBackend::Scope s(be, ST_TETRA_RRC);
             const float2 *x = (const float2 *)iq;
             switch (tp.ntaps) {
-#define TDM_RRC_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_rrc<NT>), grid, dim3(kRrcThreads), 0, be.stream, x, plan->d_ty, tp); break;
+#define TDM_RRC_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_rrc<NT>), grid, dim3(kRrcThreads), 0, be.stream, x, plan->d_ty, plan->d_tstat, tp); break;
                 TDM_RRC_CASE(17) TDM_RRC_CASE(25) TDM_RRC_CASE(33) TDM_RRC_CASE(35) TDM_RRC_CASE(41) TDM_RRC_CASE(49) TDM_RRC_CASE(57) TDM_RRC_CASE(65)
 #undef TDM_RRC_CASE
             default: return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
@@ -533,7 +537,7 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
         }
         {
             HipBackend::Scope s(be, ST_TETRA_SYM);
-            hipLaunchKernelGGL(k_tetra_sym, dim3(plan->rows), dim3(kSymThreads), 0, be.stream, plan->d_ty, tp, plan->d_tsym, hard,
+            hipLaunchKernelGGL(k_tetra_sym, dim3(plan->rows), dim3(kSymThreads), 0, be.stream, plan->d_ty, plan->d_tstat, tp, plan->d_tsym, hard,
                                soft, n_soft, best_phase, min_margin);
         }
         if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));

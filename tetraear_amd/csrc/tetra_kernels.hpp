@@ -28,6 +28,8 @@ struct TetraParams {
     int32_t max_soft;   // capacity of per-carrier symbol outputs
     int32_t pad_;
     double sps;         // samples per symbol (sample_rate / 18000)
+    double inv_sps;
+    float step_c, step_s;  // exp(-2 pi i / sps): symbol-clock phasor advance per sample
     float taps[kRrcMaxTaps];
 };
 
@@ -39,8 +41,9 @@ __device__ __forceinline__ int rrc_slot(int s) { return s + (s >> 3); }
 
 template <int NT>
 __global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restrict__ x, float2 *__restrict__ y,
-                                                            const TetraParams P)
+                                                            float2 *__restrict__ tstat, const TetraParams P)
 {
+    static_assert(kTimingBlock == 32 * kRrcPerThread, "one timing sub-block = 32 threads x 8 outputs");
     constexpr int HALO = NT - 1;
     constexpr int NS = kRrcTile + HALO;  // samples staged
     __shared__ float2 lds[NS + NS / 8 + 2];
@@ -91,6 +94,35 @@ __global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restr
             acc[v].x = fmaf(h, w[v + k].x, acc[v].x);
             acc[v].y = fmaf(h, w[v + k].y, acc[v].y);
         }
+    }
+    // square-law timing statistic of this tile's 8 sub-blocks while the outputs are in registers:
+    // C_b = sum |y[g]|^2 exp(-2 pi i g / sps)   (Oerder-Meyr); 32 threads x 8 samples per sub-block
+    {
+        const int64_t g0 = base + kRrcPerThread * t;
+        const double ph = (double)g0 * P.inv_sps;
+        const float fr = (float)(ph - floor(ph));
+        float ps, pc;
+        sincospif(-2.f * fr, &ps, &pc);
+        float ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int v = 0; v < kRrcPerThread; ++v) {
+            if (g0 + v < n) {
+                const float p = acc[v].x * acc[v].x + acc[v].y * acc[v].y;
+                ar = fmaf(p, pc, ar);
+                ai = fmaf(p, ps, ai);
+            }
+            const float nc = pc * P.step_c - ps * P.step_s, ns = pc * P.step_s + ps * P.step_c;
+            pc = nc;
+            ps = ns;
+        }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            ar += __shfl_xor(ar, d, 64);
+            ai += __shfl_xor(ai, d, 64);
+        }
+        const int nb = (n + kTimingBlock - 1) / kTimingBlock;
+        const int b = (int)(base / kTimingBlock) + (t >> 5);
+        if ((t & 31) == 0 && b < nb) tstat[(int64_t)row * nb + b] = make_float2(ar, ai);
     }
     __syncthreads();
     // transpose through LDS so that the stores are coalesced
@@ -185,7 +217,8 @@ __device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
     return (float)((double)tau[b0] * (1.0 - f) + (double)tau[b0 + 1] * f);
 }
 
-__global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restrict__ y, const TetraParams P,
+__global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restrict__ y,
+                                                            const float2 *__restrict__ tstat, const TetraParams P,
                                                             float2 *__restrict__ sym_scratch, uint8_t *hard, double *soft,
                                                             int32_t *n_soft, int32_t *timing_milli, double *min_margin)
 {
@@ -199,27 +232,13 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
     const double sps = P.sps;
     const float2 *yr = y + (int64_t)row * n;
     float2 *sr = sym_scratch + (int64_t)row * P.max_soft;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     const int nb = (n + kTimingBlock - 1) / kTimingBlock;
-    // 1. square-law timing statistic per sub-block (one wavefront per sub-block, round robin)
-    for (int b = wv; b < nb; b += kSymThreads / 64) {
-        float ar = 0.f, ai = 0.f;
-        for (int i = lane; i < kTimingBlock; i += 64) {
-            const int g = b * kTimingBlock + i;
-            if (g < n) {
-                const float2 v = yr[g];
-                const float p = v.x * v.x + v.y * v.y;
-                const double ph = (double)g / sps;               // cycles of the symbol clock
-                const float fr = (float)(ph - floor(ph));
-                float s, c;
-                sincospif(-2.f * fr, &s, &c);
-                ar = fmaf(p, c, ar);
-                ai = fmaf(p, s, ai);
-            }
-        }
-        ar = wave_sum(ar);
-        ai = wave_sum(ai);
-        if (lane == 0) { Cr[b + 1] = ar; Ci[b + 1] = ai; }
+    // 1. square-law timing statistic per sub-block: produced by k_tetra_rrc
+    for (int b = tid; b < nb; b += kSymThreads) {
+        const float2 c = tstat[(int64_t)row * nb + b];
+        Cr[b + 1] = c.x;
+        Ci[b + 1] = c.y;
     }
     __syncthreads();
     // 2. prefix sums, vector average over +-TW sub-blocks, arg, unwrap (<= 512 terms: one thread)
