@@ -55,7 +55,8 @@ typedef enum tdm_fmt {
 
 typedef enum tdm_mode {
     TDM_MODE_REFERENCE = 0, /* reproduces processor.py:221-273 (parity mode) */
-    TDM_MODE_TETRA = 1      /* RRC + Gardner/Farrow pi/4-DQPSK receiver (no reference oracle) */
+    TDM_MODE_TETRA = 1      /* RRC matched filter + feed-forward timing + Farrow + quadrant slicer on cf32
+                               channelised baseband (no reference oracle; defined by oracle/tetra_np.py) */
 } tdm_mode;
 
 typedef struct tdm_plan tdm_plan;
@@ -100,7 +101,8 @@ TDM_API int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
  *                (processor.py:85-100; the composition SURVEY.md 8(d) C3 uses to channelise)
  *  freq_offset_hz per carrier, or NULL: process()'s freq_offset (applied after the decimator)
  *  hard          [n_carriers][max_soft] uint8 symbols 0..3   (n_hard = max(n_soft-1, 0))
- *  soft          [n_carriers][max_soft] c128, = SignalProcessor.symbols (processor.py:268)
+ *  soft          [n_carriers][max_soft] c128, = SignalProcessor.symbols (processor.py:268);
+ *                in TDM_MODE_TETRA: cf32 (float I,Q) symbol-spaced matched-filter outputs
  *  n_soft        [n_carriers]
  *  best_phase    [n_carriers] timing phase chosen (processor.py:196-210), may be NULL
  *  min_margin    [n_carriers] min |phase - threshold| over the decisions (rad), may be NULL

@@ -61,6 +61,8 @@ class BatchDemodulator:
         check(self.lib.tdm_plan_get_info(self.handle, C.byref(self.info)))
         self.n_carriers = int(n_carriers)
         self.n_samples = int(n_samples)
+        self.mode = mode
+        self.soft_dtype = np.complex64 if mode == _lib.MODE_TETRA else np.complex128
 
     # ---- host-pointer path ------------------------------------------------------------------
     def process(self, iq, freq_offsets=None, pre_shifts=None, shared_input=False):
@@ -74,7 +76,7 @@ class BatchDemodulator:
         fo = None if freq_offsets is None else np.ascontiguousarray(freq_offsets, dtype=np.float64)
         ps = None if pre_shifts is None else np.ascontiguousarray(pre_shifts, dtype=np.float64)
         hard = np.zeros((rows, ms), dtype=np.uint8)
-        soft = np.zeros((rows, ms), dtype=np.complex128)
+        soft = np.zeros((rows, ms), dtype=self.soft_dtype)
         n_soft = np.zeros(rows, dtype=np.int32)
         bp = np.zeros(rows, dtype=np.int32)
         mm = np.zeros(rows, dtype=np.float64)
@@ -128,7 +130,7 @@ class BatchDemodulator:
         rows, ms = self.n_carriers, self.info.max_soft
         n_soft = d["n_soft"].download(np.int32, rows)
         hard = d["hard"].download(np.uint8, rows * ms).reshape(rows, ms)
-        soft = d["soft"].download(np.complex128, rows * ms).reshape(rows, ms)
+        soft = d["soft"].download(self.soft_dtype, rows * ms).reshape(rows, ms)
         bp = d["bp"].download(np.int32, rows)
         mm = d["mm"].download(np.float64, rows)
         return hard, soft, n_soft, bp, mm

@@ -537,8 +537,8 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
         }
         {
             HipBackend::Scope s(be, ST_TETRA_SYM);
-            hipLaunchKernelGGL(k_tetra_sym, dim3(plan->rows), dim3(kSymThreads), 0, be.stream, plan->d_ty, plan->d_tstat, tp, plan->d_tsym, hard,
-                               soft, n_soft, best_phase, min_margin);
+            hipLaunchKernelGGL(k_tetra_sym, dim3(plan->rows), dim3(kSymThreads), 0, be.stream, plan->d_ty, plan->d_tstat, tp,
+                               (float2 *)soft, hard, n_soft, best_phase, min_margin);
         }
         if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
         return TDM_OK;
@@ -584,7 +584,7 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
     if (!plan->d_soft) {
         HIP_TRY(hipMalloc(&plan->d_pre, rows * sizeof(double)));
         HIP_TRY(hipMalloc(&plan->d_foff, rows * sizeof(double)));
-        HIP_TRY(hipMalloc(&plan->d_soft, (size_t)rows * h.max_soft * 2 * sizeof(double)));
+        HIP_TRY(hipMalloc(&plan->d_soft, (size_t)rows * h.max_soft * 2 * sizeof(double)));  // cf32 in TETRA mode uses half
         HIP_TRY(hipMalloc(&plan->d_hard, (size_t)rows * h.max_soft));
         HIP_TRY(hipMalloc(&plan->d_nsoft, rows * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&plan->d_bp, rows * sizeof(int32_t)));
@@ -600,7 +600,8 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
                                 plan->d_bp, plan->d_margin, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(hard, plan->d_hard, (size_t)rows * h.max_soft, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(soft, plan->d_soft, (size_t)rows * h.max_soft * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    const size_t soft_elem = plan->mode == TDM_MODE_TETRA ? 2 * sizeof(float) : 2 * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(soft, plan->d_soft, (size_t)rows * h.max_soft * soft_elem, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(n_soft, plan->d_nsoft, rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (best_phase) HIP_TRY(hipMemcpyAsync(best_phase, plan->d_bp, rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (min_margin) HIP_TRY(hipMemcpyAsync(min_margin, plan->d_margin, rows * sizeof(double), hipMemcpyDeviceToHost, st));

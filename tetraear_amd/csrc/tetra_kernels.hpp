@@ -34,6 +34,7 @@ struct TetraParams {
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // LDS index of tile sample s: one pad slot per 8 samples so that a thread's 8-sample-strided
 // window reads (ds_read_b64, lane stride 9 slots = 18 dwords) hit 32 distinct bank pairs.
@@ -80,20 +81,20 @@ __global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restr
     }
     __syncthreads();
     // sliding window in registers: outputs base + 8t + v need staged samples 8t + v .. 8t + v + NT-1
-    float2 w[kRrcPerThread + HALO];
+    f32x2 w[kRrcPerThread + HALO];
 #pragma unroll
-    for (int j = 0; j < kRrcPerThread + HALO; ++j) w[j] = lds[rrc_slot(kRrcPerThread * t + j)];
-    float2 acc[kRrcPerThread];
+    for (int j = 0; j < kRrcPerThread + HALO; ++j) {
+        const float2 q = lds[rrc_slot(kRrcPerThread * t + j)];
+        w[j] = f32x2{q.x, q.y};
+    }
+    f32x2 acc[kRrcPerThread];
 #pragma unroll
-    for (int v = 0; v < kRrcPerThread; ++v) acc[v] = make_float2(0.f, 0.f);
+    for (int v = 0; v < kRrcPerThread; ++v) acc[v] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        const float h = P.taps[k];
+        const f32x2 hh = {P.taps[k], P.taps[k]};
 #pragma unroll
-        for (int v = 0; v < kRrcPerThread; ++v) {
-            acc[v].x = fmaf(h, w[v + k].x, acc[v].x);
-            acc[v].y = fmaf(h, w[v + k].y, acc[v].y);
-        }
+        for (int v = 0; v < kRrcPerThread; ++v) acc[v] = __builtin_elementwise_fma(hh, w[v + k], acc[v]);  // v_pk_fma_f32
     }
     // square-law timing statistic of this tile's 8 sub-blocks while the outputs are in registers:
     // C_b = sum |y[g]|^2 exp(-2 pi i g / sps)   (Oerder-Meyr); 32 threads x 8 samples per sub-block
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restr
     __syncthreads();
     // transpose through LDS so that the stores are coalesced
 #pragma unroll
-    for (int v = 0; v < kRrcPerThread; ++v) lds[rrc_slot(kRrcPerThread * t + v)] = acc[v];
+    for (int v = 0; v < kRrcPerThread; ++v) lds[rrc_slot(kRrcPerThread * t + v)] = make_float2(acc[v].x, acc[v].y);
     __syncthreads();
     if ((n & 1) == 0) {
         f32x4 *y4 = (f32x4 *)yr;
@@ -219,7 +220,7 @@ __device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
 
 __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restrict__ y,
                                                             const float2 *__restrict__ tstat, const TetraParams P,
-                                                            float2 *__restrict__ sym_scratch, uint8_t *hard, double *soft,
+                                                            float2 *__restrict__ soft, uint8_t *hard,
                                                             int32_t *n_soft, int32_t *timing_milli, double *min_margin)
 {
     __shared__ float Cr[kMaxTimingBlocks + 1], Ci[kMaxTimingBlocks + 1];  // later: prefix sums
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
     const int n = P.n;
     const double sps = P.sps;
     const float2 *yr = y + (int64_t)row * n;
-    float2 *sr = sym_scratch + (int64_t)row * P.max_soft;
+    float2 *sr = soft + (int64_t)row * P.max_soft;  // soft symbols (cf32) double as the scratch of step 4
     const int tid = threadIdx.x;
     const int nb = (n + kTimingBlock - 1) / kTimingBlock;
     // 1. square-law timing statistic per sub-block: produced by k_tetra_rrc
@@ -273,8 +274,6 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
         const double t = ((double)k + (double)tau_at(tau, nb, (double)k * sps)) * sps;
         const float2 s = farrow_at(yr, t);
         sr[i] = s;
-        soft[((int64_t)row * P.max_soft + i) * 2] = (double)s.x;
-        soft[((int64_t)row * P.max_soft + i) * 2 + 1] = (double)s.y;
     }
     __syncthreads();
     // 4. differential products and the 4th-power carrier-offset estimate
