@@ -151,6 +151,13 @@ TDM_API int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_
                           int32_t from_bits, double threshold, int32_t max_pos, int32_t *positions,
                           int32_t *n_pos, double *max_corr, int32_t device_pointers, int32_t device);
 
+/* ---- tetra-mode channeliser: oversampled polyphase DFT filter bank (no counterpart in the reference) --
+ * One wideband stream (cu8 / cs8 / cf32, n_in samples at fs) -> M channels spaced fs/M, each decimated by
+ * D (output rate fs/D), out [M][n_out] cf32 with n_out = ceil(n_in/D); channel k is centred on k*fs/M
+ * (k >= M/2: negative frequencies).  Built for M in {72, 80, 96, 128, 400}.                          */
+TDM_API int tdm_channelise(const void *iq, int32_t in_fmt, int64_t n_in, int32_t M, int32_t D, float *out,
+                           int64_t *n_out, int32_t device_pointers, int32_t device);
+
 /* ---- device memory helpers for callers without a HIP binding (bench, tests) ---------------- */
 TDM_API int tdm_dev_alloc(int32_t device, size_t bytes, void **ptr);
 TDM_API int tdm_dev_free(int32_t device, void *ptr);

@@ -16,6 +16,7 @@
 #include "resample_plan.hpp"
 #include "sync_kernels.hpp"
 #include "tetra_kernels.hpp"
+#include "pfb_kernels.hpp"
 
 using namespace tdm;
 
@@ -930,6 +931,122 @@ int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_uni
         HIP_TRY(hipMemcpy(n_pos, dnp.p, rows * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(max_corr, dmc.p, rows * 8, hipMemcpyDeviceToHost));
     }
+    return TDM_OK;
+}
+
+}  // extern "C"
+
+// ---- tetra-mode channeliser (oversampled polyphase DFT filter bank) ------------------------------------
+namespace {
+// Kaiser-windowed sinc prototype, cutoff at half the output rate, unit DC gain (oracle/pfb_np.py prototype)
+static double bessel_i0(double x)
+{
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 64; ++k) {
+        term *= (x / (2.0 * k)) * (x / (2.0 * k));
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+static std::vector<float> pfb_prototype(int M, int D, int P)
+{
+    const int L = M * P;
+    const double beta = 8.0, fc = 0.5 / D;
+    std::vector<double> h(L);
+    double sum = 0;
+    for (int i = 0; i < L; ++i) {
+        const double n = i - (L - 1) / 2.0;
+        const double a = 2.0 * fc * n;
+        const double sinc = std::fabs(a) < 1e-12 ? 1.0 : std::sin(M_PI * a) / (M_PI * a);
+        const double r = 2.0 * i / (L - 1) - 1.0;
+        const double w = bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / bessel_i0(beta);
+        h[i] = 2 * fc * sinc * w;
+        sum += h[i];
+    }
+    std::vector<float> out(L);
+    for (int i = 0; i < L; ++i) out[i] = (float)(h[i] / sum);
+    return out;
+}
+template <int M1, int M2, int P>
+int launch_pfb(const void *iq, int fmt, int64_t n_in, int D, float2 *out, int64_t n_out, hipStream_t st)
+{
+    constexpr int M = M1 * M2, L = M * P;
+    // tables (built per call: small; a plan-level cache is future work)
+    std::vector<float> h = pfb_prototype(M, D, P);
+    std::vector<float2> tw((size_t)M1 * M1 + M + (size_t)M2 * M2);
+    for (int k = 0; k < M1; ++k)
+        for (int n = 0; n < M1; ++n) {
+            const double a = 2.0 * M_PI * ((k * n) % M1) / M1;
+            tw[k * M1 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k1 = 0; k1 < M1; ++k1)
+        for (int n2 = 0; n2 < M2; ++n2) {
+            const double a = 2.0 * M_PI * ((k1 * n2) % M) / M;
+            tw[M1 * M1 + k1 * M2 + n2] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k = 0; k < M2; ++k)
+        for (int n = 0; n < M2; ++n) {
+            const double a = 2.0 * M_PI * ((k * n) % M2) / M2;
+            tw[M1 * M1 + M + k * M2 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    DevBuf dh, dtw;
+    int rc;
+    if ((rc = dh.alloc(h.size() * 4)) || (rc = dtw.alloc(tw.size() * 8))) return rc;
+    HIP_TRY(hipMemcpy(dh.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dtw.p, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+    PfbParams Q{};
+    Q.D = D;
+    Q.T = M <= 128 ? 32 : 8;
+    Q.fmt = fmt;
+    Q.n_in = n_in;
+    Q.n_out = n_out;
+    Q.h = dh.as<float>();
+    Q.W1 = dtw.as<float2>();
+    Q.WM = Q.W1 + M1 * M1;
+    Q.W2 = Q.WM + M;
+    const size_t lds = ((size_t)(Q.T - 1) * D + L + 2 * (size_t)Q.T * (M + 1) + M1 * M1 + M + M2 * M2) * sizeof(float2);
+    if (lds > 160 * 1024) return fail(TDM_ERR_UNSUPPORTED, "channeliser tile does not fit LDS");
+    HIP_TRY(hipFuncSetAttribute((const void *)k_pfb<M1, M2, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned blocks = (unsigned)((n_out + Q.T - 1) / Q.T);
+    hipLaunchKernelGGL((k_pfb<M1, M2, P>), dim3(blocks), dim3(kPfbThreads), lds, st, iq, out, n_out, Q);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return TDM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int tdm_channelise(const void *iq, int32_t in_fmt, int64_t n_in, int32_t M, int32_t D, float *out, int64_t *n_out,
+                   int32_t device_pointers, int32_t device)
+{
+    if (!iq || !out || !n_out || n_in < 1 || D < 1 || (in_fmt != TDM_CU8 && in_fmt != TDM_CS8 && in_fmt != TDM_CF32))
+        return fail(TDM_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    const int64_t no = (n_in + D - 1) / D;
+    *n_out = no;
+    DevBuf din, dout;
+    const void *src = iq;
+    float2 *dst = (float2 *)out;
+    if (!device_pointers) {
+        const size_t ib = (size_t)n_in * fmt_bytes(in_fmt), ob = (size_t)M * no * sizeof(float2);
+        if ((rc = din.alloc(ib)) || (rc = dout.alloc(ob))) return rc;
+        HIP_TRY(hipMemcpy(din.p, iq, ib, hipMemcpyHostToDevice));
+        src = din.p;
+        dst = dout.as<float2>();
+    }
+    switch (M) {
+    case 96: rc = launch_pfb<8, 12, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
+    case 72: rc = launch_pfb<8, 9, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
+    case 80: rc = launch_pfb<8, 10, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
+    case 128: rc = launch_pfb<8, 16, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
+    case 400: rc = launch_pfb<20, 20, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
+    default: return fail(TDM_ERR_UNSUPPORTED, "channeliser built for M in {72, 80, 96, 128, 400}");
+    }
+    if (rc) return rc;
+    if (!device_pointers) HIP_TRY(hipMemcpy(out, dout.p, (size_t)M * no * sizeof(float2), hipMemcpyDeviceToHost));
     return TDM_OK;
 }
 
