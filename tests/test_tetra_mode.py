@@ -22,13 +22,15 @@ def make_signal(n, fs, seed, toff=0.0, coff=0.0, snr_db=20.0):
     return x.astype(np.complex64), dib
 
 
-def best_ber(hard, dib):
+def best_ber(hard, dib, edge=0):
+    """symbol error rate at the best alignment; `edge` symbols at each end of the chunk are ignored
+    (a chunk is processed statelessly, so filters are still filling there)."""
     best = (1.0, -1)
     for lag in range(0, 40):
         m = min(len(hard), len(dib) - lag)
         if m < 50:
             continue
-        e = float(np.mean(hard[:m] != dib[lag:lag + m]))
+        e = float(np.mean(hard[edge:m - edge] != dib[lag + edge:lag + m - edge]))
         if e < best[0]:
             best = (e, lag)
     return best
