@@ -137,6 +137,6 @@ def test_gpu_wideband_to_symbols():
     bd = BatchDemodulator(fs / D, n_c, len(ks), "cf32", mode=MODE_TETRA)
     hards, softs, timing, margin = bd.process(np.ascontiguousarray(y[ks]))
     for i, k in enumerate(ks):
-        ber, lag = best_ber(hards[i], dibs[k])
+        ber, lag = best_ber(hards[i], dibs[k], edge=8)
         assert len(hards[i]) > 900 and ber == 0.0, (k, ber, lag)
     bd.close()
