@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=262144, help="samples per carrier per step")
     ap.add_argument("--fmt", default="cu8", choices=["cu8", "cf32", "cf64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="reference", choices=["reference", "tetra"],
+    ap.add_argument("--mode", default="reference", choices=["reference", "tetra", "pfb"],
                     help="reference = parity mode (the metric); tetra = RRC/timing/Farrow receiver on channelised cf32")
     ap.add_argument("--zero-foff", action="store_true", help="experiment: all freq offsets 0 (NCO skipped)")
     ap.add_argument("--rate", type=float, default=SAMPLE_RATE, help="sample rate (experiments; metric config is 2.4e6)")
@@ -98,6 +98,8 @@ def main():
 
     if args.mode == "tetra":
         return main_tetra(args)
+    if args.mode == "pfb":
+        return main_pfb(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -196,6 +198,48 @@ def main():
     bd.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main_pfb(args):
+    """Channeliser leg (BASELINE config 5): 10 MS/s cu8 -> 400 x 25 kHz channels at 80 kS/s (D = 125),
+    1 048 576-sample chunks.  Algorithmic bytes: n_in*2 in + 400*n_out*8 out (SURVEY 8(d) 'PFB stage')."""
+    import ctypes as C
+    from tetraear_amd import _lib, synth
+    from tetraear_amd.batch import DeviceBuffer
+    L = _lib.load()
+    M, D, n_in = 400, 125, 1048576
+    n_out = (n_in + D - 1) // D
+    streams = max(1, args.carriers // 400)
+    u8 = synth.noise_cu8(n_in, 1)
+    din = [DeviceBuffer(0, n_in * 2) for _ in range(streams)]
+    dout = [DeviceBuffer(0, M * n_out * 8) for _ in range(streams)]
+    for b in din:
+        b.upload(u8)
+    no = C.c_int64()
+
+    def step():
+        for i in range(streams):
+            _lib.check(L.tdm_channelise(din[i].ptr, 0, n_in, M, D, dout[i].ptr, C.byref(no), 1, 0))
+    for _ in range(args.warmup):
+        step()
+    _lib.check(L.tdm_dev_sync(0))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(L.tdm_dev_sync(0))
+    dt = time.perf_counter() - t0
+    bytes_alg = streams * (n_in * 2 + M * n_out * 8)
+    ms = dt / args.steps * 1e3
+    out = {"metric": "channeliser throughput (tetra mode, polyphase DFT filter bank)", "value": streams * n_in * args.steps / dt / 1e6,
+           "unit": "Msamples/s in", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{streams} x (10 MS/s cu8, {n_in} samples -> 400 channels x {n_out} cf32 @80 kS/s)"},
+           "realtime_10MSps_streams": streams * n_in * args.steps / dt / 10e6,
+           "roofline": {"kernel": "k_pfb<20,20,3>", "bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9,
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                        "traffic": None, "algorithmic_bytes_per_step": bytes_alg,
+                        "note": "wall-clock over back-to-back launches (one kernel per stream per step)"}}
+    print(json.dumps(out))
 
 
 def main_tetra(args):

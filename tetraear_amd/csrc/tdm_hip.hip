@@ -7,7 +7,10 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -968,41 +971,58 @@ static std::vector<float> pfb_prototype(int M, int D, int P)
     for (int i = 0; i < L; ++i) out[i] = (float)(h[i] / sum);
     return out;
 }
+struct PfbTables {
+    float *h = nullptr;
+    float2 *tw = nullptr;
+};
+static std::mutex g_pfb_mu;
+static std::map<std::tuple<int, int, int, int>, PfbTables> g_pfb_cache;  // (device, M1, M2, D) -> tables (kept)
+
 template <int M1, int M2, int P>
-int launch_pfb(const void *iq, int fmt, int64_t n_in, int D, float2 *out, int64_t n_out, hipStream_t st)
+int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 *out, int64_t n_out, hipStream_t st,
+               bool sync)
 {
     constexpr int M = M1 * M2, L = M * P;
-    // tables (built per call: small; a plan-level cache is future work)
-    std::vector<float> h = pfb_prototype(M, D, P);
-    std::vector<float2> tw((size_t)M1 * M1 + M + (size_t)M2 * M2);
-    for (int k = 0; k < M1; ++k)
-        for (int n = 0; n < M1; ++n) {
-            const double a = 2.0 * M_PI * ((k * n) % M1) / M1;
-            tw[k * M1 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+    PfbTables tb;
+    {
+        std::lock_guard<std::mutex> lk(g_pfb_mu);
+        auto key = std::make_tuple(device, M1, M2, D);
+        auto it = g_pfb_cache.find(key);
+        if (it == g_pfb_cache.end()) {
+            std::vector<float> h = pfb_prototype(M, D, P);
+            std::vector<float2> tw((size_t)M1 * M1 + M + (size_t)M2 * M2);
+            for (int k = 0; k < M1; ++k)
+                for (int n = 0; n < M1; ++n) {
+                    const double a = 2.0 * M_PI * ((k * n) % M1) / M1;
+                    tw[k * M1 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+                }
+            for (int k1 = 0; k1 < M1; ++k1)
+                for (int n2 = 0; n2 < M2; ++n2) {
+                    const double a = 2.0 * M_PI * ((k1 * n2) % M) / M;
+                    tw[M1 * M1 + k1 * M2 + n2] = make_float2((float)std::cos(a), (float)std::sin(a));
+                }
+            for (int k = 0; k < M2; ++k)
+                for (int n = 0; n < M2; ++n) {
+                    const double a = 2.0 * M_PI * ((k * n) % M2) / M2;
+                    tw[M1 * M1 + M + k * M2 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+                }
+            HIP_TRY(hipMalloc(&tb.h, h.size() * 4));
+            HIP_TRY(hipMalloc(&tb.tw, tw.size() * 8));
+            HIP_TRY(hipMemcpy(tb.h, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(tb.tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+            g_pfb_cache[key] = tb;
+        } else {
+            tb = it->second;
         }
-    for (int k1 = 0; k1 < M1; ++k1)
-        for (int n2 = 0; n2 < M2; ++n2) {
-            const double a = 2.0 * M_PI * ((k1 * n2) % M) / M;
-            tw[M1 * M1 + k1 * M2 + n2] = make_float2((float)std::cos(a), (float)std::sin(a));
-        }
-    for (int k = 0; k < M2; ++k)
-        for (int n = 0; n < M2; ++n) {
-            const double a = 2.0 * M_PI * ((k * n) % M2) / M2;
-            tw[M1 * M1 + M + k * M2 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
-        }
-    DevBuf dh, dtw;
-    int rc;
-    if ((rc = dh.alloc(h.size() * 4)) || (rc = dtw.alloc(tw.size() * 8))) return rc;
-    HIP_TRY(hipMemcpy(dh.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dtw.p, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+    }
     PfbParams Q{};
     Q.D = D;
     Q.T = M <= 128 ? 32 : 8;
     Q.fmt = fmt;
     Q.n_in = n_in;
     Q.n_out = n_out;
-    Q.h = dh.as<float>();
-    Q.W1 = dtw.as<float2>();
+    Q.h = tb.h;
+    Q.W1 = tb.tw;
     Q.WM = Q.W1 + M1 * M1;
     Q.W2 = Q.WM + M;
     const size_t lds = ((size_t)(Q.T - 1) * D + L + 2 * (size_t)Q.T * (M + 1) + M1 * M1 + M + M2 * M2) * sizeof(float2);
@@ -1011,7 +1031,7 @@ int launch_pfb(const void *iq, int fmt, int64_t n_in, int D, float2 *out, int64_
     const unsigned blocks = (unsigned)((n_out + Q.T - 1) / Q.T);
     hipLaunchKernelGGL((k_pfb<M1, M2, P>), dim3(blocks), dim3(kPfbThreads), lds, st, iq, out, n_out, Q);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
+    if (sync) HIP_TRY(hipStreamSynchronize(st));
     return TDM_OK;
 }
 }  // namespace
@@ -1038,11 +1058,12 @@ int tdm_channelise(const void *iq, int32_t in_fmt, int64_t n_in, int32_t M, int3
         dst = dout.as<float2>();
     }
     switch (M) {
-    case 96: rc = launch_pfb<8, 12, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
-    case 72: rc = launch_pfb<8, 9, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
-    case 80: rc = launch_pfb<8, 10, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
-    case 128: rc = launch_pfb<8, 16, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
-    case 400: rc = launch_pfb<20, 20, 3>(src, in_fmt, n_in, D, dst, no, 0); break;
+    // device pointers: enqueue on the default stream and return (tdm_dev_sync waits)
+    case 96: rc = launch_pfb<8, 12, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
+    case 72: rc = launch_pfb<8, 9, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
+    case 80: rc = launch_pfb<8, 10, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
+    case 128: rc = launch_pfb<8, 16, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
+    case 400: rc = launch_pfb<20, 20, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
     default: return fail(TDM_ERR_UNSUPPORTED, "channeliser built for M in {72, 80, 96, 128, 400}");
     }
     if (rc) return rc;
