@@ -14,3 +14,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
 find $OUT -name "*.csv" | head -20
+# tetra-mode legs (no reference oracle): RRC stage HBM roofline, channeliser
+python bench.py --mode tetra --carriers 4096 --steps 20 --warmup 3 > $OUT/bench_tetra.json 2> $OUT/bench_tetra.err
+python bench.py --mode pfb --carriers 3200 --steps 10 --warmup 2 > $OUT/bench_pfb.json 2> $OUT/bench_pfb.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tetra -o tetra -- python bench.py --mode tetra --carriers 4096 --steps 5 --warmup 2 > /dev/null 2> $OUT/trace_tetra.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_fetch -o fetch -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_write -o write -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_write.err
+python bench.py --carriers 1 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_single.json 2> /dev/null
+python bench.py --carriers 256 --fmt cf64 --no-cpu-baseline > $OUT/bench_cf64_256.json 2> /dev/null
+tail -c 300 $OUT/bench_tetra.json; echo; tail -c 200 $OUT/bench_single.json
