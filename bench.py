@@ -48,17 +48,19 @@ def make_batch(carriers, chunk, fmt, rank):
     raise ValueError(fmt)
 
 
-def measured_traffic(samples_per_launch, fmt):
+def measured_traffic(samples_per_launch, fmt, key="k1"):
     """HBM bytes per K1 launch from the last committed rocprofv3 PMC profile (FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE, separate passes; profiles/*_pmc_traffic.json), scaled per input sample.
     PMC counters cannot be read from inside this script, hence the committed figure."""
     import glob
     files = sorted(glob.glob(os.path.join(HERE, "profiles", "*_pmc_traffic.json")))
-    if not files or fmt != "cu8":
+    if not files or fmt not in ("cu8", "tetra-cf32"):
         return None, None
     with open(files[-1]) as f:
-        k1 = json.load(f)["k1"]
-    return k1["hbm_bytes_per_input_sample"] * samples_per_launch, os.path.basename(files[-1])
+        prof = json.load(f)
+    if key not in prof:
+        return None, None
+    return prof[key]["hbm_bytes_per_input_sample"] * samples_per_launch, os.path.basename(files[-1])
 
 
 def cpu_baseline(chunk, budget_s=10.0):
@@ -272,6 +274,7 @@ def main_tetra(args):
     nsym = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
     rrc_ms = st.get("tetra_rrc", float("nan"))
     bytes_alg = rows * n * 16
+    traffic, traffic_src = measured_traffic(rows * n, "tetra-cf32", key="tetra_rrc")
     out = {"metric": "Msymbols/s demodulated (TETRA mode: RRC + feed-forward timing + Farrow + quadrant slicer)",
            "value": nsym * args.steps / dt / 1e6, "unit": "Msym/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -281,7 +284,8 @@ def main_tetra(args):
            "stage_ms_per_launch": st,
            "roofline": {"kernel": "k_tetra_rrc<33> (RRC matched filter, LDS-tiled)", "bound": "hbm",
                         "achieved": bytes_alg / (rrc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": bytes_alg / (rrc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                        "frac": bytes_alg / (rrc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": rrc_ms}}
     print(json.dumps(out))
     bd.close()
