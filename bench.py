@@ -106,7 +106,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TDM_FORCE_DIST") == "1":   # the env switch lets a 1-GPU box exercise this path
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
