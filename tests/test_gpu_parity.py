@@ -222,3 +222,47 @@ def test_abi_direct():
     # error convention: negative status + text, no exception across the ABI
     assert L.tdm_plan_create(-1.0, n, 1, 0, 0, 0, C.byref(h)) == -1
     assert "bad" in _lib.last_error()
+
+
+def test_config3_64_carriers_shared_stream_vs_oracle():
+    """BASELINE config 3 at full size: 64 carriers on a 25 kHz grid in ONE 2.4 MS/s cu8 stream of
+    262144 samples, demodulated in one batch (per-carrier input-rate shift fused into the decimator
+    load); oracle per carrier = p.process(p.frequency_shift(x, f_k)) on a sample of the carriers."""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    from tetraear_amd.batch import BatchDemodulator
+    n = 262144
+    offs = [(k - 31.5) * 25000.0 for k in range(64)]
+    u8, _ = synth.multicarrier_cu8(n, 2.4e6, offs, seed0=100)
+    bd = BatchDemodulator(2.4e6, n, 64, "cu8")
+    hards, softs, bp, mm = bd.process(u8, pre_shifts=offs, shared_input=True)
+    x = synth.cu8_to_c128(u8)
+    for k in (0, 13, 31, 32, 50, 63):
+        o = OracleSignalProcessor(2.4e6)
+        ref = o.process(o.frequency_shift(x, offs[k]))
+        assert bp[k] == o.best_phase
+        np.testing.assert_array_equal(hards[k], ref)
+        assert np.max(np.abs(softs[k] - o.symbols)) <= SOFT_TOL * np.max(np.abs(o.symbols))
+    assert all(len(h) >= 2013 for h in hards)
+    bd.close()
+
+
+def test_config5_10Msps_q41_channels_vs_oracle():
+    """BASELINE config 5 in reference mode: 10 MS/s (q = 41, filter memory 8246 samples), 1 048 576-sample
+    chunk, carriers on the 25 kHz grid picked by pre-shift; checked against the oracle on 3 of them."""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    from tetraear_amd.batch import BatchDemodulator
+    n = 1048576
+    u8 = synth.noise_cu8(n, 4100)
+    offs = [(k - 199.5) * 25000.0 for k in (0, 150, 399)]
+    bd = BatchDemodulator(10e6, n, len(offs), "cu8")
+    hards, softs, bp, mm = bd.process(u8, pre_shifts=offs, freq_offsets=[0.0, 1171.875, -500.0], shared_input=True)
+    x = synth.cu8_to_c128(u8)
+    for i, f in enumerate(offs):
+        o = OracleSignalProcessor(10e6)
+        ref = o.process(o.frequency_shift(x, f), [0.0, 1171.875, -500.0][i])
+        assert bp[i] == o.best_phase and len(ref) == 1966
+        np.testing.assert_array_equal(hards[i], ref)
+        assert np.max(np.abs(softs[i] - o.symbols)) <= SOFT_TOL * np.max(np.abs(o.symbols))
+    bd.close()
