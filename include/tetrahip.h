@@ -117,6 +117,16 @@ TDM_API int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_s
                        double *soft, int32_t *n_soft, int32_t *best_phase, double *min_margin,
                        void *stream);
 TDM_API int tdm_plan_sync(tdm_plan *plan);
+/* Host-fed streaming: n_batches consecutive batches, each laid out like one
+ * tdm_process call (n_carriers x n_samples back to back; outputs [n_batches][n_carriers][max_soft]...).
+ * The host->device copy of batch i+1 and the device->host copy of batch i-1 overlap the kernels of
+ * batch i (two device slots, three streams; the caller's buffers are pinned in place for the call).
+ * freq_offset_hz is per carrier and applies to every batch.  Consecutive 256 Ki-sample chunks of one
+ * recording are independent (the reference is stateless per read, processor.py:221-273), so a long
+ * capture is simply fed as rows of successive batches.                                              */
+TDM_API int tdm_process_pipelined(tdm_plan *plan, const void *iq, int64_t n_batches, const double *freq_offset_hz,
+                                  uint8_t *hard, void *soft, int32_t *n_soft, int32_t *best_phase,
+                                  double *min_margin);
 
 /* ---- the other public methods of SignalProcessor, one call each (host pointers, blocking) ---
  * All take/return c128 host arrays.                                                          */

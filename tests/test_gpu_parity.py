@@ -266,3 +266,22 @@ def test_config5_10Msps_q41_channels_vs_oracle():
         np.testing.assert_array_equal(hards[i], ref)
         assert np.max(np.abs(softs[i] - o.symbols)) <= SOFT_TOL * np.max(np.abs(o.symbols))
     bd.close()
+
+
+def test_recorded_file_ingest_pipelined(tmp_path):
+    """BASELINE config 1 shape: a cu8 'recording' cut into 262144-sample reads; every read must equal
+    the oracle's process() of that read (chunks are stateless), through the copy/compute pipeline."""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    from tetraear_amd.ingest import demodulate_recording
+    chunk, n_chunks, tail = 65536, 11, 30011
+    u8 = synth.noise_cu8(chunk * n_chunks + tail, 606)
+    path = tmp_path / "capture.cu8"
+    u8.tofile(path)
+    outs = demodulate_recording(str(path), 2.4e6, chunk=chunk, freq_offset=1171.875, rows_per_batch=4)
+    assert len(outs) == n_chunks + 1
+    for i in (0, 3, 4, 7, 8, 10, 11):
+        lo = 2 * chunk * i
+        hi = lo + 2 * (chunk if i < n_chunks else tail)
+        ref = OracleSignalProcessor(2.4e6).process(synth.cu8_to_c128(u8[lo:hi]), 1171.875)
+        np.testing.assert_array_equal(outs[i], ref)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "tdm_process": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_process_device": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_plan_sync": (C.c_int, [_vp]),
+    "tdm_process_pipelined": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_filter_signal": (C.c_int, [_vp, _i64, _f64, _f64, _vp, _P(_i32), _i32]),
     "tdm_frequency_shift": (C.c_int, [_vp, _i64, _f64, _f64, _vp, _i32]),
     "tdm_extract_symbols": (C.c_int, [_vp, _i64, _f64, _f64, _vp, _P(_i64), _P(_i32), _i32]),

@@ -86,6 +86,24 @@ class BatchDemodulator:
         softs = [soft[r, :int(n_soft[r])].copy() for r in range(rows)]
         return hards, softs, bp, mm
 
+    def process_stream(self, iq, n_batches, freq_offsets=None):
+        """n_batches batches back to back in host memory, copies overlapped with compute
+        (tdm_process_pipelined).  Returns arrays shaped [n_batches][n_carriers]..."""
+        rows, ms = self.n_carriers, self.info.max_soft
+        iq = np.ascontiguousarray(iq)
+        need = n_batches * rows * self.n_samples * FMT_BYTES[self.fmt]
+        if iq.nbytes < need:
+            raise ValueError(f"iq holds {iq.nbytes} bytes, {need} needed")
+        fo = None if freq_offsets is None else np.ascontiguousarray(freq_offsets, dtype=np.float64)
+        hard = np.zeros((n_batches, rows, ms), dtype=np.uint8)
+        soft = np.zeros((n_batches, rows, ms), dtype=self.soft_dtype)
+        n_soft = np.zeros((n_batches, rows), dtype=np.int32)
+        bp = np.zeros((n_batches, rows), dtype=np.int32)
+        mm = np.zeros((n_batches, rows), dtype=np.float64)
+        check(self.lib.tdm_process_pipelined(self.handle, ptr(iq), int(n_batches), ptr(fo), ptr(hard), ptr(soft),
+                                             ptr(n_soft), ptr(bp), ptr(mm)))
+        return hard, soft, n_soft, bp, mm
+
     # ---- device-resident path (bench, streaming pipelines) -------------------------------------
     def alloc_device_io(self, shared_input=False):
         rows, ms = self.n_carriers, self.info.max_soft

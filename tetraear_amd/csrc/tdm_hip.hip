@@ -613,6 +613,99 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
     return TDM_OK;
 }
 
+// ---- host-fed pipeline: H2D of batch i+1 and D2H of batch i-1 overlap the kernels of batch i ----------
+int tdm_process_pipelined(tdm_plan *plan, const void *iq, int64_t n_batches, const double *freq_offset_hz, uint8_t *hard,
+                          void *soft, int32_t *n_soft, int32_t *best_phase, double *min_margin)
+{
+    if (!plan || !iq || !hard || !soft || !n_soft || n_batches < 1) return fail(TDM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(plan->device));
+    const RefPlanHost &h = plan->h;
+    const int rows = plan->rows;
+    const size_t in_bytes = (size_t)rows * h.n * fmt_bytes(plan->fmt);
+    const size_t soft_elem = plan->mode == TDM_MODE_TETRA ? 2 * sizeof(float) : 2 * sizeof(double);
+    const size_t hard_bytes = (size_t)rows * h.max_soft, soft_bytes = (size_t)rows * h.max_soft * soft_elem;
+    // pin the caller's buffers in place so the copies are truly asynchronous (best effort)
+    const bool pin_in = hipHostRegister((void *)iq, in_bytes * n_batches, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_h = hipHostRegister(hard, hard_bytes * n_batches, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_s = hipHostRegister(soft, soft_bytes * n_batches, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    struct Slot {
+        void *iq = nullptr; uint8_t *hard = nullptr; void *soft = nullptr; int32_t *ns = nullptr, *bp = nullptr; double *mm = nullptr;
+        hipEvent_t in_done{}, comp_done{}, out_done{};
+    } sl[2];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    double *d_fo = nullptr;
+    int rc = TDM_OK;
+    auto cleanup = [&]() {
+        for (auto &x : sl) {
+            void *ps[] = {x.iq, x.hard, x.soft, x.ns, x.bp, x.mm};
+            for (void *q : ps) if (q) (void)hipFree(q);
+            if (x.in_done) (void)hipEventDestroy(x.in_done);
+            if (x.comp_done) (void)hipEventDestroy(x.comp_done);
+            if (x.out_done) (void)hipEventDestroy(x.out_done);
+        }
+        if (d_fo) (void)hipFree(d_fo);
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_out) (void)hipStreamDestroy(s_out);
+        if (pin_in) (void)hipHostUnregister((void *)iq);
+        if (pin_h) (void)hipHostUnregister(hard);
+        if (pin_s) (void)hipHostUnregister(soft);
+    };
+#define PIPE_TRY(expr)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            rc = fail(TDM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+            cleanup();                                                                     \
+            return rc;                                                                     \
+        }                                                                                  \
+    } while (0)
+    PIPE_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+    PIPE_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+    for (auto &x : sl) {
+        PIPE_TRY(hipMalloc(&x.iq, in_bytes));
+        PIPE_TRY(hipMalloc(&x.hard, hard_bytes));
+        PIPE_TRY(hipMalloc(&x.soft, soft_bytes));
+        PIPE_TRY(hipMalloc(&x.ns, rows * sizeof(int32_t)));
+        PIPE_TRY(hipMalloc(&x.bp, rows * sizeof(int32_t)));
+        PIPE_TRY(hipMalloc(&x.mm, rows * sizeof(double)));
+        PIPE_TRY(hipEventCreateWithFlags(&x.in_done, hipEventDisableTiming));
+        PIPE_TRY(hipEventCreateWithFlags(&x.comp_done, hipEventDisableTiming));
+        PIPE_TRY(hipEventCreateWithFlags(&x.out_done, hipEventDisableTiming));
+    }
+    if (freq_offset_hz) {
+        PIPE_TRY(hipMalloc(&d_fo, rows * sizeof(double)));
+        PIPE_TRY(hipMemcpy(d_fo, freq_offset_hz, rows * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const char *src = (const char *)iq;
+    for (int64_t b = 0; b < n_batches; ++b) {
+        Slot &x = sl[b & 1];
+        if (b >= 2) {
+            PIPE_TRY(hipStreamWaitEvent(s_in, x.comp_done, 0));        // slot's input consumed
+            PIPE_TRY(hipStreamWaitEvent(plan->stream, x.out_done, 0)); // slot's outputs copied out
+        }
+        PIPE_TRY(hipMemcpyAsync(x.iq, src + (size_t)b * in_bytes, in_bytes, hipMemcpyHostToDevice, s_in));
+        PIPE_TRY(hipEventRecord(x.in_done, s_in));
+        PIPE_TRY(hipStreamWaitEvent(plan->stream, x.in_done, 0));
+        PIPE_TRY(hipMemsetAsync(x.hard, 0, hard_bytes, plan->stream));
+        rc = tdm_process_device(plan, x.iq, h.n, nullptr, d_fo, x.hard, (double *)x.soft, x.ns, x.bp, x.mm, nullptr);
+        if (rc) { cleanup(); return rc; }
+        PIPE_TRY(hipEventRecord(x.comp_done, plan->stream));
+        PIPE_TRY(hipStreamWaitEvent(s_out, x.comp_done, 0));
+        PIPE_TRY(hipMemcpyAsync(hard + (size_t)b * hard_bytes, x.hard, hard_bytes, hipMemcpyDeviceToHost, s_out));
+        PIPE_TRY(hipMemcpyAsync((char *)soft + (size_t)b * soft_bytes, x.soft, soft_bytes, hipMemcpyDeviceToHost, s_out));
+        PIPE_TRY(hipMemcpyAsync(n_soft + (size_t)b * rows, x.ns, rows * sizeof(int32_t), hipMemcpyDeviceToHost, s_out));
+        if (best_phase) PIPE_TRY(hipMemcpyAsync(best_phase + (size_t)b * rows, x.bp, rows * sizeof(int32_t), hipMemcpyDeviceToHost, s_out));
+        if (min_margin) PIPE_TRY(hipMemcpyAsync(min_margin + (size_t)b * rows, x.mm, rows * sizeof(double), hipMemcpyDeviceToHost, s_out));
+        PIPE_TRY(hipEventRecord(x.out_done, s_out));
+    }
+    PIPE_TRY(hipStreamSynchronize(s_out));
+    PIPE_TRY(hipStreamSynchronize(plan->stream));
+#undef PIPE_TRY
+    cleanup();
+    return TDM_OK;
+}
+
 // ---- timing -----------------------------------------------------------------------------------
 int tdm_plan_time_begin(tdm_plan *plan)
 {
