@@ -149,6 +149,18 @@ TDM_API int tdm_decimate(const double *x, int64_t n, int32_t q, double *y, int64
 /* resample (processor.py:35-49): scipy.signal.resample (FFT method) to `num` points */
 TDM_API int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t device);
 
+/* ---- spectrum / AFC / signal gate in front of process() -----------------------
+ * The block of CaptureThread.run (tetraear/ui/modern.py:1921-2021) that decides whether process() is
+ * called and with which freq_offset: 2048-point Hann FFT of the first 2048 samples of each row, dBFS,
+ * +-12.5 kHz band mean / peak / peak bin, out-of-band noise floor, SNR rule.
+ *  out [rows][8] = peak_freq_offset_hz, signal_power_db, peak_power_db, noise_floor_db, snr_db,
+ *                  strong (0/1), afc_offset_hz, 0        afc [rows] (may be NULL) = afc_offset_hz
+ * With device pointers the launch is asynchronous on the default stream and `afc` can be passed
+ * straight to tdm_process_device as freq_offset_hz.                                                 */
+TDM_API int tdm_spectrum_gate(const void *iq, int32_t in_fmt, int64_t row_stride, int64_t n_samples, int32_t rows,
+                              double sample_rate, double *out, double *afc, int32_t device_pointers,
+                              int32_t device);
+
 /* ---- burst synchronisation, the immediate consumer of process() -------------
  * TetraDecoder.symbols_to_bits + TetraDecoder.find_sync (tetraear/core/decoder.py:140-169, :171-295),
  * batched over rows.  units = hard symbols 0..3 (from_bits = 0; bit stream = (s>>1, s&1) per symbol) or

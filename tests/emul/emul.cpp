@@ -16,6 +16,7 @@
 #include "../../tetraear_amd/csrc/ref_pipeline.hpp"
 #include "../../tetraear_amd/csrc/resample_plan.hpp"
 #include "../../tetraear_amd/csrc/sync_kernels.hpp"
+#include "../../tetraear_amd/csrc/gate_kernels.hpp"
 
 using namespace tdm;
 
@@ -25,7 +26,7 @@ struct Group {
     int nt;
     std::barrier<> bar;
     std::vector<double> slots;
-    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024 + 2 * 2200) {}
+    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024 + 2 * 2200 + 4 * 2048) {}
 };
 
 struct EmuWaveComm {
@@ -57,6 +58,7 @@ struct EmuBlockComm {
     int nthreads() const { return g->nt; }
     void sync() { g->bar.arrive_and_wait(); }
     double &lds(int i) { return g->slots[(size_t)g->nt * 2 + i]; }
+    double *smem() { return &g->slots[(size_t)g->nt * 16 + 1024 + 2 * 2200]; }
     template <class F>
     double reduce(double v, F f)
     {
@@ -241,6 +243,17 @@ int emu_find_sync(const uint8_t *units, int64_t n_units, int from_bits, double t
     std::vector<uint16_t> counts((size_t)n_bits + 1, 0xffff);
     for (int64_t pos = 0; pos < n_bits; ++pos) sync_count_body(units, n_bits, pos, from_bits, counts.data());
     *n_pos = sync_walk_body(counts.data(), n_bits, threshold, positions, max_pos, max_corr);
+    return 0;
+}
+
+int emu_gate(const void *iq, int64_t n, int rows, int fmt, double fs, double *out, double *afc)
+{
+    GateArgs A{iq, n, n, fmt, 0, fs, out, afc};
+    for (int row = 0; row < rows; ++row)
+        run_group(32, [&](int t, Group *g) {
+            EmuBlockComm cm{g, t};
+            gate_body(A, cm, row);
+        });
     return 0;
 }
 

@@ -73,3 +73,13 @@ def find_sync(units, from_bits, threshold, max_pos=64):
     L.emu_find_sync(u.ctypes.data_as(C.c_void_p), C.c_int64(len(u)), int(from_bits), C.c_double(threshold), max_pos,
                     pos.ctypes.data_as(C.c_void_p), C.byref(n), C.byref(mc))
     return list(pos[:min(n.value, max_pos)]), mc.value
+
+
+def gate(iq, fmt, n, rows, fs):
+    L = lib()
+    iq = np.ascontiguousarray(iq)
+    out = np.zeros((rows, 8))
+    afc = np.zeros(rows)
+    L.emu_gate(iq.ctypes.data_as(C.c_void_p), C.c_int64(n), rows, FMT[fmt], C.c_double(fs),
+               out.ctypes.data_as(C.c_void_p), afc.ctypes.data_as(C.c_void_p))
+    return out, afc

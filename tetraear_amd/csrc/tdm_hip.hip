@@ -20,6 +20,7 @@
 #include "sync_kernels.hpp"
 #include "tetra_kernels.hpp"
 #include "pfb_kernels.hpp"
+#include "gate_kernels.hpp"
 
 using namespace tdm;
 
@@ -80,6 +81,8 @@ constexpr int kFinishThreads = 256;
 struct BlockComm {
     double *sm;  // [kFinishThreads / 64] LDS (reductions)
     double *buf; // [kPowThreads] LDS (power_fixup scratch) or null
+    double *big = nullptr;  // large workgroup scratch (gate FFT) or null
+    __device__ __forceinline__ double *smem() { return big; }
     __device__ __forceinline__ double &lds(int i) { return buf[i]; }
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
     __device__ __forceinline__ int nthreads() const { return blockDim.x; }
@@ -177,6 +180,14 @@ __global__ __launch_bounds__(kFinishThreads) void k_dft_terms(const int64_t *o_l
     __shared__ double sm[kFinishThreads / 64];
     BlockComm cm{sm, nullptr};
     dft_terms_body(cm, (int64_t)blockIdx.x, o_list, in, n_terms, src, freq, weight, n, sign, scale, out);
+}
+
+__global__ __launch_bounds__(kFinishThreads) void k_gate(const GateArgs A)
+{
+    __shared__ double sm[kFinishThreads / 64];
+    __shared__ double big[4 * kGateFft];
+    BlockComm cm{sm, nullptr, big};
+    gate_body(A, cm, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_sync_count(const uint8_t *sym, int64_t row_stride, const int32_t *n_units,
@@ -977,6 +988,47 @@ int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t dev
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(y, dy.p, (size_t)num * 16, hipMemcpyDeviceToHost));
+    return TDM_OK;
+}
+
+// ---- spectrum / AFC / signal gate in front of process() ----------------------------------
+int tdm_spectrum_gate(const void *iq, int32_t in_fmt, int64_t row_stride, int64_t n_samples, int32_t rows,
+                      double sample_rate, double *out, double *afc, int32_t device_pointers, int32_t device)
+{
+    if (!iq || !out || rows < 1 || n_samples < 0 || in_fmt < 0 || in_fmt > 3 || !(sample_rate > 0))
+        return fail(TDM_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf din, dout, dafc;
+    GateArgs A{};
+    A.iq = iq;
+    A.row_stride = row_stride;
+    A.n = n_samples;
+    A.fmt = in_fmt;
+    A.fs = sample_rate;
+    A.out = out;
+    A.afc = afc;
+    const int64_t used = n_samples < kGateFft ? n_samples : kGateFft;  // only the first 2048 samples of a row matter
+    if (!device_pointers) {
+        // upload just the leading samples of every row
+        const size_t eb = fmt_bytes(in_fmt);
+        if ((rc = din.alloc((size_t)rows * (used ? used : 1) * eb)) || (rc = dout.alloc((size_t)rows * kGateOut * 8)) ||
+            (rc = dafc.alloc((size_t)rows * 8)))
+            return rc;
+        if (used)
+            HIP_TRY(hipMemcpy2D(din.p, used * eb, iq, row_stride * eb, used * eb, rows, hipMemcpyHostToDevice));
+        A.iq = din.p;
+        A.row_stride = used;
+        A.out = dout.as<double>();
+        A.afc = dafc.as<double>();
+    }
+    hipLaunchKernelGGL(k_gate, dim3(rows), dim3(kFinishThreads), 0, 0, A);
+    HIP_TRY(hipGetLastError());
+    if (!device_pointers) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, dout.p, (size_t)rows * kGateOut * 8, hipMemcpyDeviceToHost));
+        if (afc) HIP_TRY(hipMemcpy(afc, dafc.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
+    }
     return TDM_OK;
 }
 

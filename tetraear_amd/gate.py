@@ -1,0 +1,26 @@
+"""Spectrum / AFC / signal gate on the GPU: the decision
+`CaptureThread.run` makes before calling process() (tetraear/ui/modern.py:1921-2021)."""
+import numpy as np
+
+from tetraear_amd import _lib
+from tetraear_amd._lib import FMT_BYTES, check, ptr
+
+_FMT_OF = {"cu8": 0, "cs8": 1, "cf32": 2, "cf64": 3}
+FIELDS = ("peak_freq_offset", "signal_power", "peak_power", "noise_floor", "snr", "strong", "afc")
+
+
+def spectrum_gate(iq, fmt, n_samples, rows=1, sample_rate=2.4e6, device=0):
+    """iq: `rows` streams of n_samples back to back.  Returns (list of dicts per row, afc array)."""
+    f = _FMT_OF[fmt]
+    iq = np.ascontiguousarray(iq)
+    assert iq.nbytes >= rows * n_samples * FMT_BYTES[f]
+    out = np.zeros((rows, 8))
+    afc = np.zeros(rows)
+    check(_lib.load().tdm_spectrum_gate(ptr(iq), f, n_samples, n_samples, rows, float(sample_rate), ptr(out), ptr(afc),
+                                        0, device))
+    res = []
+    for r in range(rows):
+        d = {k: float(out[r, i]) for i, k in enumerate(FIELDS)}
+        d["strong"] = bool(out[r, 5] != 0.0)
+        res.append(d)
+    return res, afc
