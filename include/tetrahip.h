@@ -161,6 +161,12 @@ TDM_API int tdm_spectrum_gate(const void *iq, int32_t in_fmt, int64_t row_stride
                               double sample_rate, double *out, double *afc, int32_t device_pointers,
                               int32_t device);
 
+/* ---- scanner heuristics: TetraSignalDetector.calculate_power,
+ * detect_tetra_modulation, detect_sync_pattern (tetraear/signal/scanner.py:42-147), `rows` rows of n
+ * complex128 host samples.  out [rows][8] = power_db, is_tetra (0/1), confidence, found_sync (0/1),
+ * max_correlation, 0, 0, 0.                                                                          */
+TDM_API int tdm_detect(const double *x, int64_t n, int32_t rows, double sample_rate, double *out, int32_t device);
+
 /* ---- burst synchronisation, the immediate consumer of process() -------------
  * TetraDecoder.symbols_to_bits + TetraDecoder.find_sync (tetraear/core/decoder.py:140-169, :171-295),
  * batched over rows.  units = hard symbols 0..3 (from_bits = 0; bit stream = (s>>1, s&1) per symbol) or

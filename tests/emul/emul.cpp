@@ -17,6 +17,7 @@
 #include "../../tetraear_amd/csrc/resample_plan.hpp"
 #include "../../tetraear_amd/csrc/sync_kernels.hpp"
 #include "../../tetraear_amd/csrc/gate_kernels.hpp"
+#include "../../tetraear_amd/csrc/detect_kernels.hpp"
 
 using namespace tdm;
 
@@ -254,6 +255,18 @@ int emu_gate(const void *iq, int64_t n, int rows, int fmt, double fs, double *ou
             EmuBlockComm cm{g, t};
             gate_body(A, cm, row);
         });
+    return 0;
+}
+
+int emu_detect(const double *x, int64_t n, double fs, double *out)
+{
+    std::vector<double> ang((size_t)n + 1);
+    std::vector<uint8_t> bits((size_t)n + 1);
+    DetectArgs A{x, n, fs, -85.0, ang.data(), bits.data(), out};
+    run_group(16, [&](int t, Group *g) {
+        EmuBlockComm cm{g, t};
+        detect_body(A, cm, 0);
+    });
     return 0;
 }
 

@@ -83,3 +83,11 @@ def gate(iq, fmt, n, rows, fs):
     L.emu_gate(iq.ctypes.data_as(C.c_void_p), C.c_int64(n), rows, FMT[fmt], C.c_double(fs),
                out.ctypes.data_as(C.c_void_p), afc.ctypes.data_as(C.c_void_p))
     return out, afc
+
+
+def detect(x, fs):
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    out = np.zeros(8)
+    L.emu_detect(x.ctypes.data_as(C.c_void_p), C.c_int64(len(x)), C.c_double(fs), out.ctypes.data_as(C.c_void_p))
+    return out

@@ -21,6 +21,7 @@
 #include "tetra_kernels.hpp"
 #include "pfb_kernels.hpp"
 #include "gate_kernels.hpp"
+#include "detect_kernels.hpp"
 
 using namespace tdm;
 
@@ -188,6 +189,13 @@ __global__ __launch_bounds__(kFinishThreads) void k_gate(const GateArgs A)
     __shared__ double big[4 * kGateFft];
     BlockComm cm{sm, nullptr, big};
     gate_body(A, cm, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(kFinishThreads) void k_detect(const DetectArgs A)
+{
+    __shared__ double sm[kFinishThreads / 64];
+    BlockComm cm{sm, nullptr, nullptr};
+    detect_body(A, cm, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_sync_count(const uint8_t *sym, int64_t row_stride, const int32_t *n_units,
@@ -1029,6 +1037,26 @@ int tdm_spectrum_gate(const void *iq, int32_t in_fmt, int64_t row_stride, int64_
         HIP_TRY(hipMemcpy(out, dout.p, (size_t)rows * kGateOut * 8, hipMemcpyDeviceToHost));
         if (afc) HIP_TRY(hipMemcpy(afc, dafc.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
     }
+    return TDM_OK;
+}
+
+// ---- scanner heuristics: TetraSignalDetector.calculate_power / detect_tetra_modulation /
+// detect_sync_pattern (tetraear/signal/scanner.py:42-147) on rows of complex128 host samples
+int tdm_detect(const double *x, int64_t n, int32_t rows, double sample_rate, double *out, int32_t device)
+{
+    if (!out || rows < 1 || n < 0 || (n > 0 && !x) || !(sample_rate > 0)) return fail(TDM_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf dx, dang, dbits, dout;
+    const size_t nn = (size_t)rows * (n ? n : 1);
+    if ((rc = dx.alloc(nn * 16)) || (rc = dang.alloc(nn * 8)) || (rc = dbits.alloc(nn)) || (rc = dout.alloc((size_t)rows * kDetectOut * 8)))
+        return rc;
+    if (n) HIP_TRY(hipMemcpy(dx.p, x, (size_t)rows * n * 16, hipMemcpyHostToDevice));
+    DetectArgs A{dx.as<double>(), n, sample_rate, -85.0, dang.as<double>(), dbits.as<uint8_t>(), dout.as<double>()};
+    hipLaunchKernelGGL(k_detect, dim3(rows), dim3(kFinishThreads), 0, 0, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)rows * kDetectOut * 8, hipMemcpyDeviceToHost));
     return TDM_OK;
 }
 
