@@ -9,11 +9,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-sys.path.insert(0, "/root/reference")
 sys.dont_write_bytecode = True
 
-from tetraear.signal.scanner import TetraSignalDetector  # noqa: E402
-from tetraear_amd import synth  # noqa: E402
+from tetraear_amd import synth  # noqa: E402   (the reference itself is imported inside main() only)
 
 CASES = [("noise", 7, 30000), ("noise", 8, 999), ("noise", 9, 1300), ("dqpsk", 1, 40000), ("dqpsk", 2, 131072),
          ("dc", 0, 5000), ("noise", 10, 90), ("dqpsk", 3, 2600)]
@@ -30,6 +28,8 @@ def make(kind, seed, n):
 
 
 def main():
+    sys.path.insert(0, "/root/reference")
+    from tetraear.signal.scanner import TetraSignalDetector
     det = TetraSignalDetector(2.4e6)
     out = {}
     for i, (kind, seed, n) in enumerate(CASES):
