@@ -510,7 +510,6 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
         }
     }
     // ---------------- backward: same cascade, time reversed ----------------
-    double last_sr[K] = {0, 0}, last_sq[K] = {0, 0};
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
         static_assert(K == 2, "device sections are biquads with numerator [1,2,1]");
@@ -551,17 +550,10 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (lane == kWave - 1) { sr[k] = 0; sq[k] = 0; }
-        if (!Loader::kStaged && s == NSEC - 1) {
-            // last section of a decimating stage: only every out_stride-th sample leaves the kernel,
-            // so its zero-input correction is applied at those samples only (below)
 #pragma unroll
-            for (int k = 0; k < K; ++k) { last_sr[k] = sr[k]; last_sq[k] = sq[k]; }
-        } else {
-#pragma unroll
-            for (int i = L - 1; i >= 0; --i) {
-                xr[i] += zir_step<K>(a, sr);
-                xi[i] += zir_step<K>(a, sq);
-            }
+        for (int i = L - 1; i >= 0; --i) {
+            xr[i] += zir_step<K>(a, sr);
+            xi[i] += zir_step<K>(a, sq);
         }
     }
     // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------
@@ -585,16 +577,10 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
         int64_t j = rel0 <= 0 ? 0 : (rel0 + q - 1) / q;
         int64_t next = j * q - rel0;  // position inside this segment
         double *y0 = P.y0 + (int64_t)row * P.n_out * 2;
-        // zero-input response of the last section at backward step t = L-1-i: c_t . S (table csec_last)
-        const double *ct = P.csec_last;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             if (i == next) {
-                if (j < P.n_out) {
-                    const f64x2 c = *(const f64x2 *)(ct + (size_t)(L - 1 - (int)next) * K);  // per-lane index
-                    y0[j * 2] = xr[i] + (c.x * last_sr[0] + c.y * last_sr[1]);
-                    y0[j * 2 + 1] = xi[i] + (c.x * last_sq[0] + c.y * last_sq[1]);
-                }
+                if (j < P.n_out) { y0[j * 2] = xr[i]; y0[j * 2 + 1] = xi[i]; }
                 ++j;
                 next += q;
             }
