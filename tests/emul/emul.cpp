@@ -86,14 +86,14 @@ void run_group(int nt, F fn)
 }
 
 struct EmuBackend {
-    template <int K, int NSEC, int L, int EDGE, bool UNI, class Loader>
+    template <int K, int NSEC, int L, int EDGE, class Loader>
     void zp_block(const ZpParams &P, Loader ld, int nb, int rows)
     {
         for (int row = 0; row < rows; ++row)
             for (int b = 0; b < nb; ++b)
                 run_group(kWave, [&](int lane, Group *g) {
                     EmuWaveComm cm{g, lane};
-                    zp_block_body<K, NSEC, L, EDGE, UNI>(P, ld, cm, lane, b, row);
+                    zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, lane, b, row);
                 });
     }
     template <int K, int NSEC>
@@ -203,7 +203,7 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         int64_t n_out = (n + q - 1) / q;
         hz.t = build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, n_out, q);
         hz.bind(1);
-        be.zp_block<2, 4, kLDec, kEdgeSos, false>(hz.t.p, ld, hz.t.p.nb, 1);
+        be.zp_block<2, 4, kLDec, kEdgeSos>(hz.t.p, ld, hz.t.p.nb, 1);
         be.zp_carry<2, 4>(hz.t.p, hz.t.p.nb, 1);
         be.zp_fixup<8, kLDec>(hz.t.p, hz.t.p.nb, 1, y, n_out, nullptr, fs);
     } else {
@@ -212,7 +212,7 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         hz.t = build_zp_tables(desc_from_tf(t), n, kEdgeTf, kLLpf, n, 1);
         hz.bind(1);
         StagedLoader<PlainC128Src> ls{{x, n}};
-        be.zp_block<2, 2, kLLpf, kEdgeTf, false>(hz.t.p, ls, hz.t.p.nb, 1);
+        be.zp_block<2, 2, kLLpf, kEdgeTf>(hz.t.p, ls, hz.t.p.nb, 1);
         be.zp_carry<2, 2>(hz.t.p, hz.t.p.nb, 1);
         be.zp_fixup<4, kLLpf>(hz.t.p, hz.t.p.nb, 1, y, n, nullptr, fs);
     }

@@ -4,7 +4,7 @@
 //
 // Backend concept (all calls enqueue asynchronously on the backend's stream):
 //   (ZpParams are passed by value with their pointers already valid where the kernels run)
-//   template<int K,int NSEC,int L,int EDGE,bool UNI,class Loader> void zp_block(const ZpParams&, Loader, int nb, int rows);
+//   template<int K,int NSEC,int L,int EDGE,class Loader> void zp_block(const ZpParams&, Loader, int nb, int rows);
 //   template<int K,int NSEC> void zp_carry(const ZpParams&, int nb, int rows);
 //   template<int D,int L> void zp_fixup(const ZpParams&, int nb, int rows, double* out,
 //                                       int64_t out_row_stride, const double* freq_offset, double fs_out);
@@ -45,17 +45,10 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
     if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
-        if (h.ldec == kLDecUni)
-            be.template zp_block<2, 4, kLDecUni, kEdgeSos, true>(B.dec_params, ld, h.dec.p.nb, rows);
-        else
-            be.template zp_block<2, 4, kLDec, kEdgeSos, false>(B.dec_params, ld, h.dec.p.nb, rows);
+        be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
         be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
-        if (!h.lpf) {  // (n_dec <= 15) nothing downstream finishes the decimator output: do it here
-            if (h.ldec == kLDecUni)
-                be.template zp_fixup<8, kLDecUni>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
-            else
-                be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
-        }
+        if (!h.lpf)  // (n_dec <= 15) nothing downstream finishes the decimator output: do it here
+            be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
     } else {
         be.convert(ld, rows, h.n, B.y, io.freq_offset, h.sample_rate);
     }
@@ -66,15 +59,12 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         // filter_signal(samples, 25000, current_rate)  (processor.py:264).  When decimated, the
         // loader finishes the decimator output (carry responses) and applies
         // frequency_shift(samples, freq_offset, current_rate) (processor.py:260-261) on the fly.
-        if (h.decimated && h.ldec == kLDecUni) {
-            StagedLoader<DecFixSrc<kLDecUni>> l2{{B.dec_params, io.freq_offset, h.rate_dec}};
-            be.template zp_block<2, 2, kLLpf, kEdgeTf, false>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
-        } else if (h.decimated) {
+        if (h.decimated) {
             StagedLoader<DecFixSrc<kLDec>> l2{{B.dec_params, io.freq_offset, h.rate_dec}};
-            be.template zp_block<2, 2, kLLpf, kEdgeTf, false>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
+            be.template zp_block<2, 2, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
         } else {
             StagedLoader<PlainC128Src> l2{{B.y, h.n_dec}};
-            be.template zp_block<2, 2, kLLpf, kEdgeTf, false>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
+            be.template zp_block<2, 2, kLLpf, kEdgeTf>(B.lpf_params, l2, h.lpf_t.p.nb, rows);
         }
         be.template zp_carry<2, 2>(B.lpf_params, h.lpf_t.p.nb, rows);
         if (h.sps > 1 && h.sps <= kMaxSps) {

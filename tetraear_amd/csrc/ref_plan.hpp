@@ -13,7 +13,6 @@ namespace tdm {
 #define TDM_LDEC 32
 #endif
 constexpr int kLDec = TDM_LDEC;  // samples per lane, decimator stage (4 biquads)
-constexpr int kLDecUni = 40;  // used when q | 40 (q = 2, 4, 5, 8, 10, 20, 40): uniform output positions
 constexpr int kLLpf = 16;  // samples per lane, channel-filter stage (order 4 = 2 biquads; LDS-staged I/O)
 constexpr int kEdgeSos = 27;  // sosfiltfilt pad for 4 sections: 3*(2*4+1)
 constexpr int kEdgeTf = 15;   // filtfilt pad for order 4: 3*5
@@ -26,7 +25,6 @@ struct RefPlanHost {
     bool decimated = false; // false also when decimate raises (n <= 27, processor.py:253-257)
     double rate_dec = 0;    // current_rate after the decimation step
     int64_t n_dec = 0;
-    int ldec = kLDec;       // samples per lane of the decimator kernel: kLDecUni when q divides it
     bool lpf = false;       // false when filtfilt raises (n_dec <= 15, processor.py:81-83)
     int sps = 0;            // int(rate_dec / 18000)
     int phase_step = 1;
@@ -88,10 +86,7 @@ inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidt
     if (h.q > 1) h.sos = design_cheby1_8(0.05, 0.8 / h.q);
     h.tf = design_butter4(butter_cutoff(bandwidth, h.rate_dec));
     if (h.decimated)
-    {
-        h.ldec = (h.q > 1 && kLDecUni % h.q == 0) ? kLDecUni : kLDec;
-        h.dec = build_zp_tables(desc_from_sos(h.sos), n, kEdgeSos, h.ldec, h.n_dec, h.q);
-    }
+        h.dec = build_zp_tables(desc_from_sos(h.sos), n, kEdgeSos, kLDec, h.n_dec, h.q);
     if (h.lpf)
         h.lpf_t = build_zp_tables(desc_from_tf(h.tf), h.n_dec, kEdgeTf, kLLpf, h.n_dec, 1);
     return h;

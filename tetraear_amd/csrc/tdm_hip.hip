@@ -109,18 +109,15 @@ struct BlockComm {
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-#ifndef TDM_UNI_WAVES
-#define TDM_UNI_WAVES 2   // waves per SIMD budget of the L = 40 decimator variant
-#endif
 #ifndef TDM_BLOCK_WAVES
 #define TDM_BLOCK_WAVES 2  // waves per SIMD the block kernel is register-budgeted for
 #endif
-template <int K, int NSEC, int L, int EDGE, bool UNI, class Loader>
-__global__ __launch_bounds__(64, (L <= 16 ? 4 : (L <= 24 ? 3 : (L > 32 ? TDM_UNI_WAVES : TDM_BLOCK_WAVES)))) void k_zp_block(const ZpParams P, const Loader ld)
+template <int K, int NSEC, int L, int EDGE, class Loader>
+__global__ __launch_bounds__(64, (L <= 16 ? 4 : (L <= 24 ? 3 : TDM_BLOCK_WAVES))) void k_zp_block(const ZpParams P, const Loader ld)
 {
     __shared__ __attribute__((aligned(16))) double stg[Loader::kStaged ? StageGeom<L>::kDoubles : 2];
     WaveComm cm{stg};
-    zp_block_body<K, NSEC, L, EDGE, UNI>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
+    zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 template <int K, int NSEC, bool FWD>
@@ -280,11 +277,11 @@ struct HipBackend {
         }
     };
 
-    template <int K, int NSEC, int L, int EDGE, bool UNI, class Loader>
+    template <int K, int NSEC, int L, int EDGE, class Loader>
     void zp_block(const ZpParams &P, Loader ld, int nb, int rows)
     {
         Scope s(*this, NSEC == 4 ? ST_DEC_BLOCK : ST_LPF_BLOCK);
-        hipLaunchKernelGGL((k_zp_block<K, NSEC, L, EDGE, UNI, Loader>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
+        hipLaunchKernelGGL((k_zp_block<K, NSEC, L, EDGE, Loader>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
     }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
@@ -840,11 +837,11 @@ int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, do
     RawLoader<FMT_CF64, false> ld{dx.p, n, nullptr, fs};
     StagedLoader<PlainC128Src> ls{{dx.as<double>(), n}};
     if (sos) {
-        be.zp_block<2, 4, kLDec, kEdgeSos, false>(dz.params, ld, t.p.nb, 1);
+        be.zp_block<2, 4, kLDec, kEdgeSos>(dz.params, ld, t.p.nb, 1);
         be.zp_carry<2, 4>(dz.params, t.p.nb, 1);
         be.zp_fixup<8, kLDec>(dz.params, t.p.nb, 1, dy.as<double>(), n_out, nullptr, fs);
     } else {
-        be.zp_block<2, 2, kLLpf, kEdgeTf, false>(dz.params, ls, t.p.nb, 1);
+        be.zp_block<2, 2, kLLpf, kEdgeTf>(dz.params, ls, t.p.nb, 1);
         be.zp_carry<2, 2>(dz.params, t.p.nb, 1);
         be.zp_fixup<4, kLLpf>(dz.params, t.p.nb, 1, dy.as<double>(), n_out, nullptr, fs);
     }

@@ -428,10 +428,7 @@ struct StagedLoader {
 //   wave_sync(); shfl_up2<K>(a, b, outa, outb, d) / shfl_down2<K>: out[lane] = in[lane -/+ d] for two
 //   K-vectors of doubles across the 64 lanes (own value where the source lane does not exist).
 // ------------------------------------------------------------------------------------------
-// UNI: the stage decimates by a factor that divides L (and k0L, 64L), so every lane's outputs sit
-// at the same in-segment positions i = 0, q, 2q, ...: the output stores are uniform and the last
-// backward section's zero-input correction is needed at those positions only.
-template <int K, int NSEC, int L, int EDGE, bool UNI, class Loader, class Comm>
+template <int K, int NSEC, int L, int EDGE, class Loader, class Comm>
 TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lane, int blk, int row)
 {
     constexpr int D = K * NSEC;
@@ -513,7 +510,6 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
         }
     }
     // ---------------- backward: same cascade, time reversed ----------------
-    double last_sr[K] = {0, 0}, last_sq[K] = {0, 0};
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
         static_assert(K == 2, "device sections are biquads with numerator [1,2,1]");
@@ -554,36 +550,14 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (lane == kWave - 1) { sr[k] = 0; sq[k] = 0; }
-        if (UNI && s == NSEC - 1) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) { last_sr[k] = sr[k]; last_sq[k] = sq[k]; }
-        } else {
-#pragma unroll
-            for (int i = L - 1; i >= 0; --i) {
-                xr[i] += zir_step<K>(a, sr);
-                xi[i] += zir_step<K>(a, sq);
-            }
+        for (int i = L - 1; i >= 0; --i) {
+            xr[i] += zir_step<K>(a, sr);
+            xi[i] += zir_step<K>(a, sq);
         }
     }
     // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------
-    if (UNI) {
-        // seg, k0L and L are multiples of q: outputs at i = 0, q, 2q, ... for every lane
-        const int q = P.out_stride;
-        int64_t j = (seg - P.k0L) / q;  // exact; negative only in the lead pad of block 0
-        double *y0 = P.y0 + (int64_t)row * P.n_out * 2;
-        const auto ct = TDM_CPTR(P.csec_last);
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            if (i % q == 0) {  // wave-uniform
-                if (j >= 0 && j < P.n_out) {
-                    const double c0 = ct[(L - 1 - i) * K], c1 = ct[(L - 1 - i) * K + 1];
-                    y0[j * 2] = xr[i] + (c0 * last_sr[0] + c1 * last_sr[1]);
-                    y0[j * 2 + 1] = xi[i] + (c0 * last_sq[0] + c1 * last_sq[1]);
-                }
-                ++j;
-            }
-        }
-    } else if (Loader::kStaged) {
+    if (Loader::kStaged) {
         // stride-1 stage: transpose back through LDS and store 16 B per lane, coalesced
         f64x2 *lds = (f64x2 *)cm.stage();
 #pragma unroll
