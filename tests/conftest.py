@@ -14,6 +14,15 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Built artefacts are git-ignored: on a fresh checkout compile them once (hipcc cross-compiles
+    # without a GPU; the oracle and the CPU emulation harness need only gcc/g++).
+    import shutil
+    import subprocess
+    lib = os.path.join(REPO, "tetraear_amd", "libtetrahip.so")
+    if not os.path.exists(lib) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.run(["make", "-C", os.path.join(REPO, "tetraear_amd", "csrc"), "-s"], check=False)
+    if not os.path.exists(os.path.join(REPO, "oracle", "liboracle.so")):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "-s"], check=False)
 
 
 @pytest.fixture(scope="session")
