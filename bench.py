@@ -83,6 +83,30 @@ def cpu_baseline(chunk, budget_s=10.0):
                       f"{dt:.1f} s on 1 thread of {os.cpu_count()} host CPUs"}
 
 
+def _cpu_worker(args):
+    chunk, budget_s = args
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    x = synth.cu8_to_c128(synth.noise_cu8(chunk, 99))
+    o = OracleSignalProcessor(SAMPLE_RATE)
+    o.process(x, 117.1875)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        n += len(o.process(x, 117.1875))
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline_allcore(chunk, budget_s=5.0):
+    """Same oracle, one process per host CPU (the path is single-threaded; carriers are independent)."""
+    import multiprocessing as mp
+    procs = os.cpu_count() or 1
+    with mp.get_context("fork").Pool(procs) as pool:
+        res = pool.map(_cpu_worker, [(chunk, budget_s)] * procs)
+    rate = sum(n / dt for n, dt in res) / 1e6
+    return {"value": rate, "unit": "Msym/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} processes x {budget_s:.0f} s of {chunk}-sample chunks, C oracle"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +222,10 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.chunk)
+            try:
+                out["cpu_baseline_allcore"] = cpu_baseline_allcore(args.chunk)
+            except Exception as e:  # never let the side measurement break the bench line
+                out["cpu_baseline_allcore"] = {"error": str(e)}
         print(json.dumps(out))
     bd.close()
     if dist is not None:
