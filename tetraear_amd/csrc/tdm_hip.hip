@@ -115,7 +115,7 @@ struct BlockComm {
 template <int K, int NSEC, int L, int EDGE, class Loader>
 __global__ __launch_bounds__(64, (L <= 16 ? 4 : (L <= 24 ? 3 : TDM_BLOCK_WAVES))) void k_zp_block(const ZpParams P, const Loader ld)
 {
-    __shared__ __attribute__((aligned(16))) double stg[Loader::kStaged ? StageGeom<L>::kDoubles : (Loader::kLut ? 256 : 2)];
+    __shared__ __attribute__((aligned(16))) double stg[Loader::kStaged ? StageGeom<L>::kDoubles : 2];
     WaveComm cm{stg};
     zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
 }

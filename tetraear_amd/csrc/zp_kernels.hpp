@@ -108,9 +108,6 @@ struct RawLoader {
 
     static constexpr int kBytes = (FMT == FMT_CU8 || FMT == FMT_CS8) ? 2 : (FMT == FMT_CF32 ? 8 : 16);
     static constexpr bool kStaged = false;  // lanes load their own segment straight from memory
-    // 8-bit formats without an input-rate shift: the 256 possible sample values, converted exactly
-    // as convert_one does and already multiplied by the stage's input gain, sit in an LDS table
-    static constexpr bool kLut = (FMT == FMT_CU8 || FMT == FMT_CS8) && !SHIFT;
 
     TDM_HD const void *row_ptr(int row) const
     {
@@ -124,27 +121,10 @@ struct RawLoader {
     }
 
     template <int L>
-    TDM_HD void fast(const void *rowp, int64_t k, double f, double *xr, double *xi, const double *lut) const
+    TDM_HD void fast(const void *rowp, int64_t k, double f, double *xr, double *xi) const
     {
         const char *p = (const char *)rowp + k * kBytes;
         const bool aligned = (((uintptr_t)p) & 15) == 0;
-        if (kLut && aligned) {
-            const u32x4 *v = (const u32x4 *)p;
-#pragma unroll
-            for (int c = 0; c < L / 8; ++c) {
-                const u32x4 w = v[c];
-                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t s = ww[d] >> (16 * h);
-                        xr[c * 8 + d * 2 + h] = lut[s & 255u];
-                        xi[c * 8 + d * 2 + h] = lut[(s >> 8) & 255u];
-                    }
-            }
-            return;
-        }
         if ((FMT == FMT_CU8 || FMT == FMT_CS8) && aligned) {
             const u32x4 *v = (const u32x4 *)p;
 #pragma unroll
@@ -217,36 +197,23 @@ struct RawLoader {
 
     // x[i] = padded-ext sample seg+i (zero outside [P0, Ne))
     template <int L, class Comm>
-    TDM_HD void load(Comm &cm, int row, int blk, int lane, const ZpParams &P, double *xr, double *xi) const
+    TDM_HD void load(Comm &, int row, int blk, int lane, const ZpParams &P, double *xr, double *xi) const
     {
         const int64_t seg = (int64_t)blk * (kWave * L) + (int64_t)lane * L;
-        const double g = P.in_gain;  // total gain of both passes, applied once (see ZpFilterDesc)
-        const double *lut = nullptr;
-        if (kLut) {
-            double *t = cm.stage();
-            for (int u = lane; u < 256; u += kWave) {
-                // same arithmetic as convert_one followed by the gain
-                const double v = FMT == FMT_CU8 ? sub_rn(mul_rn((double)u, 1.0 / 127.5), 1.0)
-                                                : (double)(int8_t)u * (1.0 / 128.0);
-                t[u] = v * g;
-            }
-            cm.wave_sync();
-            lut = t;
-        }
         const void *rowp = row_ptr(row);
         const double f = row_shift(row);
         const int64_t n = P.n;
         const int edge = P.edge;
         const int64_t e0 = seg - P.P0;  // ext index of x[0]
         if (e0 >= edge && e0 + L <= edge + n) {
-            fast<L>(rowp, e0 - edge, f, xr, xi, lut);
-            if (kLut && ((((uintptr_t)((const char *)rowp + (e0 - edge) * kBytes)) & 15) == 0)) return;  // gain is in the table
+            fast<L>(rowp, e0 - edge, f, xr, xi);
         } else {
             double tmp[2 * L];
             slow(rowp, f, e0, n, edge, L, tmp);
 #pragma unroll
             for (int i = 0; i < L; ++i) { xr[i] = tmp[2 * i]; xi[i] = tmp[2 * i + 1]; }
         }
+        const double g = P.in_gain;  // total gain of both passes, applied once (see ZpFilterDesc)
 #pragma unroll
         for (int i = 0; i < L; ++i) { xr[i] *= g; xi[i] *= g; }
     }
@@ -402,7 +369,6 @@ template <class Src>
 struct StagedLoader {
     Src src;
     static constexpr bool kStaged = true;
-    static constexpr bool kLut = false;
 
     template <int L, class Comm>
     TDM_HD void load(Comm &cm, int row, int blk, int lane, const ZpParams &P, double *xr, double *xi) const
