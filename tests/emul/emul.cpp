@@ -18,6 +18,7 @@
 #include "../../tetraear_amd/csrc/sync_kernels.hpp"
 #include "../../tetraear_amd/csrc/gate_kernels.hpp"
 #include "../../tetraear_amd/csrc/detect_kernels.hpp"
+#include "../../tetraear_amd/csrc/small_dft.hpp"
 
 using namespace tdm;
 
@@ -165,6 +166,20 @@ struct HostZp {
 
 }  // namespace
 
+
+// register-resident small DFTs of the channeliser (small_dft.hpp); in/out interleaved float re,im
+template <int N>
+static void small_dft_host(const float *in, float *out)
+{
+    cf32v x[N];
+    for (int i = 0; i < N; ++i) x[i] = cv(in[2 * i], in[2 * i + 1]);
+    SmallDft<N>::run(x);
+    for (int i = 0; i < N; ++i) {
+        out[2 * i] = x[i].x;
+        out[2 * i + 1] = x[i].y;
+    }
+}
+
 extern "C" {
 
 // whole pipeline == tdm_process with host pointers
@@ -276,6 +291,24 @@ int emu_carry_terms(double sample_rate, int64_t n, int32_t *dec_terms, int32_t *
     *dec_terms = h.decimated ? h.dec.p.carry_terms : 0;
     *lpf_terms = h.lpf ? h.lpf_t.p.carry_terms : 0;
     *nb_dec = h.decimated ? h.dec.p.nb : 0;
+    return 0;
+}
+int emu_small_dft(int n, const float *in, float *out)
+{
+    switch (n) {
+    case 2: small_dft_host<2>(in, out); break;
+    case 3: small_dft_host<3>(in, out); break;
+    case 4: small_dft_host<4>(in, out); break;
+    case 5: small_dft_host<5>(in, out); break;
+    case 8: small_dft_host<8>(in, out); break;
+    case 9: small_dft_host<9>(in, out); break;
+    case 10: small_dft_host<10>(in, out); break;
+    case 12: small_dft_host<12>(in, out); break;
+    case 16: small_dft_host<16>(in, out); break;
+    case 20: small_dft_host<20>(in, out); break;
+    case 25: small_dft_host<25>(in, out); break;
+    default: return -1;
+    }
     return 0;
 }
 }

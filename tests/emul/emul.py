@@ -91,3 +91,13 @@ def detect(x, fs):
     out = np.zeros(8)
     L.emu_detect(x.ctypes.data_as(C.c_void_p), C.c_int64(len(x)), C.c_double(fs), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def small_dft(x):
+    """SmallDft<N> of small_dft.hpp on the host (sign +, unnormalised)."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    out = np.empty_like(x)
+    rc = lib().emu_small_dft(len(x), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError(f"no SmallDft<{len(x)}>")
+    return out

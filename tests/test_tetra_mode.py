@@ -123,6 +123,29 @@ def test_gpu_channeliser_matches_definition():
 
 
 @pytest.mark.gpu
+def test_gpu_channeliser_batch_and_general_decimation():
+    """grid.y batching gives the single-stream result per stream; a decimation that does not satisfy
+    M | TB*D (register-FFT kernel's condition) takes the direct-DFT kernel and still matches."""
+    from oracle import pfb_np
+    from tetraear_amd.channeliser import channelise, channelise_batch
+    M, D, fs, n = 400, 125, 10e6, 5000
+    xs = [(_wideband(n, fs, [3, 77, 391], M, seed0=400 + 10 * i)[0] / 4).astype(np.complex64) for i in range(3)]
+    yb = channelise_batch(np.concatenate(xs), "cf32", 3, M, D)
+    yp = channelise_batch(np.concatenate(xs), "cf32", 3, M, D, pitch=48)
+    for i in range(3):
+        np.testing.assert_array_equal(yb[i], channelise(xs[i], "cf32", M, D))
+        np.testing.assert_array_equal(yp[i], yb[i])
+    for M, D, n in ((80, 27, 4000), (128, 40, 4100), (80, 25, 3000), (128, 36, 3000)):
+        x, _ = _wideband(n, 2e6, [2, M // 2 + 3], M)
+        x32 = (x / 4).astype(np.complex64)
+        y = channelise(x32, "cf32", M, D)
+        probe = [0, 2, M // 2 + 3, M - 1]
+        ref = pfb_np.channelise(x32.astype(np.complex128), M, D, channels=probe)
+        for i, k in enumerate(probe):
+            assert np.max(np.abs(y[k] - ref[i])) < 2e-5 * np.max(np.abs(ref)), (M, D, k)
+
+
+@pytest.mark.gpu
 def test_gpu_wideband_to_symbols():
     """2.4 MS/s wideband -> 96-channel filter bank (75 kS/s per channel) -> TETRA-mode demodulation;
     every occupied channel must give back the transmitted dibits."""

@@ -6,11 +6,19 @@
 // One workgroup produces T consecutive output times of all M channels:
 //   stage 0  coalesced load + format conversion of (T-1)D + MP input samples into LDS
 //   stage A  polyphase branch sums v, written circularly shifted (u)
-//   stage B  M-point DFT as M1 x M2 Cooley-Tukey with direct small DFTs, twiddles from LDS
+//   stage B  M-point DFT as M1 x M2 Cooley-Tukey
 // Output layout [M][n_out] cf32 (channel-major), which is the [carriers][n] input of TETRA mode.
+// Two kernels: k_pfb_fft (register-resident mixed-radix small DFTs, per-thread constant branch
+// set; needs M | TB*D) and k_pfb (direct small DFTs, any D) as the general fallback.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "small_dft.hpp"
+
+#ifndef TDM_PFB_STORE
+#define TDM_PFB_STORE 2
+#endif
 
 namespace tdm {
 
@@ -26,7 +34,23 @@ struct PfbParams {
     const float2 *W1;     // [M1][M1]  exp(+2 pi i k1 n1 / M1)
     const float2 *WM;     // [M1][M2]  exp(+2 pi i k1 n2 / M)
     const float2 *W2;     // [M2][M2]  exp(+2 pi i k2 n2 / M2)
+    int32_t G;            // k_pfb_fft: rounds of TB output times per workgroup
+    int32_t pad2_;
+    int64_t in_stride;    // bytes between the input streams of a batch (grid.y)
+    int64_t out_batch;    // float2 elements between the outputs of a batch
+    unsigned long long *dbg;  // TDM_PFB_TIMING builds: per-phase cycle sums
 };
+
+#ifdef TDM_PFB_TIMING
+#define PFB_T(i)                                                                         \
+    do {                                                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+        if (threadIdx.x == 0) atomicAdd(&Q.dbg[i], t_ - tprev_);                         \
+        tprev_ = t_;                                                                     \
+    } while (0)
+#else
+#define PFB_T(i)
+#endif
 
 __device__ __forceinline__ float2 pfb_load(const void *iq, int fmt, int64_t n)
 {
@@ -67,6 +91,8 @@ __global__ __launch_bounds__(kPfbThreads) void k_pfb(const void *__restrict__ iq
     float2 *w2 = wm + M;               // [M2*M2]
     const int tid = threadIdx.x;
     const int64_t m0 = (int64_t)blockIdx.x * T;
+    iq = (const char *)iq + (int64_t)blockIdx.y * Q.in_stride;
+    out += (int64_t)blockIdx.y * Q.out_batch;
     // ---- stage 0: inputs n = m0*D - (L-1) + i
     const int64_t nbase = m0 * D - (L - 1);
     for (int i = tid; i < nxs; i += kPfbThreads) {
@@ -124,6 +150,294 @@ __global__ __launch_bounds__(kPfbThreads) void k_pfb(const void *__restrict__ iq
             for (int n2 = 0; n2 < M2; ++n2) acc = cfma(a[n2], w2[k2 * M2 + n2], acc);
             if (m < Q.n_out) out[(int64_t)(k1 + M1 * k2) * out_stride + m] = acc;
         }
+    }
+}
+
+// ---- register-FFT variant ---------------------------------------------------------------------
+// Workgroup = TB*M2 threads, TB consecutive output times per round, G rounds, any decimation D.
+//   load     the round's input window arrives as 4-sample units prefetched into registers during
+//            the previous round (one 8-byte load per unit for cu8/cs8, two 16-byte loads for cf32),
+//            converted and written to LDS with 16-byte stores
+//   stage A  item = (branch r, group of 4 output times): the P taps of the branch stay in registers,
+//            lanes walk consecutive r (conflict-free LDS reads and writes); the circular shift
+//            (m*D) mod M of each output time is applied to the write index
+//   pass 1   thread (mi, n2): SmallDft<M1> over n1 in place in the exchange tile, times the middle twiddle
+//   pass 2   thread (k1, mi): SmallDft<M2> over n2, stores channels k1 + M1*k2; consecutive lanes hold
+//            consecutive output times, so each channel row receives TB*8 contiguous bytes.
+// OVL: the exchange tile overlays the input window (stage A keeps its sums in registers across a
+// barrier), which brings the tile of M = 400 under a third of the LDS: three workgroups per CU.
+template <int FMT>
+struct PfbUnit;   // four consecutive input samples in wire format + validity
+template <>
+struct PfbUnit<2> {
+    float4 a, b;
+    uint32_t ok;
+    __device__ __forceinline__ void load(const char *base, int64_t n0, int64_t n_in)
+    {
+        ok = 0;
+        a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 >= 0 && n0 + 3 < n_in) {
+            const float4 *p = (const float4 *)(base + n0 * 8);   // cf32 streams are 8-byte aligned
+            __builtin_memcpy(&a, p, 16);
+            __builtin_memcpy(&b, p + 1, 16);
+            ok = 15u;
+        } else {
+            float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < 4; ++c)
+                if (n0 + c >= 0 && n0 + c < n_in) {
+                    const float2 v = ((const float2 *)base)[n0 + c];
+                    t[2 * c] = v.x;
+                    t[2 * c + 1] = v.y;
+                }
+            a = make_float4(t[0], t[1], t[2], t[3]);
+            b = make_float4(t[4], t[5], t[6], t[7]);
+            ok = 15u;   // zeros already in place
+        }
+    }
+    __device__ __forceinline__ void store(cf32v *dst) const
+    {
+        ((float4 *)dst)[0] = a;
+        ((float4 *)dst)[1] = b;
+    }
+};
+template <int FMT>
+struct PfbUnit {   // cu8 (FMT 0) / cs8 (FMT 1): 8 bytes
+    uint2 v;
+    uint32_t ok;
+    __device__ __forceinline__ void load(const char *base, int64_t n0, int64_t n_in)
+    {
+        v = make_uint2(0u, 0u);
+        if (n0 >= 0 && n0 + 3 < n_in) {
+            __builtin_memcpy(&v, base + n0 * 2, 8);
+            ok = 15u;
+        } else {
+            ok = 0;
+            uint32_t w[2] = {0u, 0u};
+            for (int c = 0; c < 4; ++c)
+                if (n0 + c >= 0 && n0 + c < n_in) {
+                    const uint32_t h = ((const uint16_t *)base)[n0 + c];
+                    w[c >> 1] |= h << (16 * (c & 1));
+                    ok |= 1u << c;
+                }
+            v = make_uint2(w[0], w[1]);
+        }
+    }
+    __device__ __forceinline__ static cf32v conv(uint32_t h)   // low 16 bits: I, Q
+    {
+        if (FMT == 0) return cv((float)(h & 255u), (float)((h >> 8) & 255u)) * (1.f / 127.5f) - cv(1.f, 1.f);
+        return cv((float)(int8_t)(h & 255u), (float)(int8_t)((h >> 8) & 255u)) * (1.f / 128.f);
+    }
+    __device__ __forceinline__ void store(cf32v *dst) const
+    {
+        cf32v s[4] = {conv(v.x), conv(v.x >> 16), conv(v.y), conv(v.y >> 16)};
+        if (ok != 15u) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (!((ok >> c) & 1u)) s[c] = cv(0.f, 0.f);
+        }
+        float4 lo, hi;
+        lo.x = s[0].x; lo.y = s[0].y; lo.z = s[1].x; lo.w = s[1].y;
+        hi.x = s[2].x; hi.y = s[2].y; hi.z = s[3].x; hi.w = s[3].y;
+        ((float4 *)dst)[0] = lo;
+        ((float4 *)dst)[1] = hi;
+    }
+};
+
+// waves per SIMD that let `wgs` workgroups of nt threads share a CU
+constexpr int pfb_waves_per_simd(int nt, int wgs) { return (wgs * ((nt + 63) / 64) + 3) / 4; }
+
+template <int M1, int M2>
+struct PfbFftGeom {
+    static constexpr int FS = (M1 * M2) | 1;      // odd stride between output times of the exchange tile
+};
+// LDS footprint in float2 elements
+template <int M1, int M2, int P, int TB, bool OVL>
+constexpr size_t pfb_fft_lds(int D)
+{
+    const size_t xs = ((size_t)(TB - 1) * D + (size_t)M1 * M2 * P + 3) / 4 * 4;
+    const size_t A = (size_t)TB * PfbFftGeom<M1, M2>::FS;
+    return (OVL ? (xs > A ? xs : A) : xs + A) + (size_t)M1 * M2;   // + middle twiddles
+}
+
+// NPF: 4-sample units per thread held in registers for the next round; WGS: workgroups per CU aimed at
+template <int M1, int M2, int P, int TB, int FMT, bool OVL, int NPF, int WGS>
+__global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb_fft(
+    const void *__restrict__ iq_, cf32v *__restrict__ out_, int64_t out_stride, const PfbParams Q)
+{
+    static_assert(M1 <= M2, "pass 2 uses the first TB*M1 threads");
+    static_assert(TB % 4 == 0 && M1 % 4 == 0, "stage A: M1/4 items of four output times per thread");
+    constexpr int M = M1 * M2, L = M * P, NT = TB * M2;
+    constexpr int FS = PfbFftGeom<M1, M2>::FS;
+    constexpr int FG = 4, NI = M1 / 4;   // M*(TB/FG) items over NT threads
+    extern __shared__ cf32v smem_v[];
+    const int D = Q.D;
+    const int nxs = (TB - 1) * D + L;
+    const int nu = (nxs + 3) >> 2;
+    const int dmod = D % M;
+    cf32v *xs = smem_v;                              // [4*nu]
+    cf32v *A = OVL ? smem_v : smem_v + 4 * nu;       // [TB][FS]: row k1 (or n1) of an output time at k1*M2
+    cf32v *wml = smem_v + (pfb_fft_lds<M1, M2, P, TB, OVL>(D) - M);   // [M1][M2] middle twiddles
+    // (in LDS rather than re-read from memory: vmcnt retires in order, so a global load issued after
+    //  pass 2's stores would wait for their write acknowledgements)
+    const char *iq = (const char *)iq_ + (int64_t)blockIdx.y * Q.in_stride;
+    cf32v *out = out_ + (int64_t)blockIdx.y * Q.out_batch;
+    const int tid = threadIdx.x;
+    const int mi = tid / M2, n2 = tid - mi * M2;
+    const int k1b = tid / TB, mib = tid - k1b * TB;
+    // stage-A items of this thread (the same in every round): item = tid + it*NT -> (group of 4 times, branch r)
+    float hv[NI][P];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int item = tid + it * NT;
+        const int r = item - (item / M) * M;
+#pragma unroll
+        for (int p = 0; p < P; ++p) hv[it][p] = Q.h[r + p * M];
+    }
+    for (int i = tid; i < M; i += NT) {
+        const float2 w = Q.WM[i];
+        wml[i] = cv(w.x, w.y);
+    }
+    const int64_t round0 = (int64_t)blockIdx.x * Q.G;
+    PfbUnit<FMT> pf[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+        if (tid + k * NT < nu) pf[k].load(iq, round0 * TB * D - (L - 1) + 4 * (int64_t)(tid + k * NT), Q.n_in);
+    for (int g = 0; g < Q.G; ++g) {
+        const int64_t m0 = (round0 + g) * TB;
+        if (m0 >= Q.n_out) break;
+        const int64_t nbase = m0 * D - (L - 1);
+#ifdef TDM_PFB_TIMING
+        unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
+        if (OVL || g == 0) {
+#pragma unroll
+            for (int k = 0; k < NPF; ++k)
+                if (tid + k * NT < nu) pf[k].store(xs + 4 * (tid + k * NT));
+            for (int u = tid + NPF * NT; u < nu; u += NT) {   // windows longer than the prefetch depth
+                PfbUnit<FMT> t;
+                t.load(iq, nbase + 4 * (int64_t)u, Q.n_in);
+                t.store(xs + 4 * u);
+            }
+        }
+        PFB_T(0);
+        __syncthreads();
+        PFB_T(1);
+        if (g + 1 < Q.G) {
+#pragma unroll
+            for (int k = 0; k < NPF; ++k)
+                if (tid + k * NT < nu) pf[k].load(iq, nbase + (int64_t)TB * D + 4 * (int64_t)(tid + k * NT), Q.n_in);
+        }
+        // ---- stage A (all LDS reads of an item before its writes: both live in the same LDS array,
+        //      so the compiler keeps their order; the opaque copy of tid keeps the per-item address
+        //      arithmetic inside the round instead of hoisted into spilled registers)
+        int tid_v = tid;
+        asm volatile("" : "+v"(tid_v));
+        const int s0 = (int)((m0 * (int64_t)D) % M);   // uniform: shift of the round's first output time
+        cf32v acc[NI][FG];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int item = tid_v + it * NT;
+            const int f = (item / M) * FG, r = item - (item / M) * M;
+            const cf32v *px = xs + f * D + (L - 1) - r;
+#pragma unroll
+            for (int j = 0; j < FG; ++j) {
+                acc[it][j] = px[j * D] * hv[it][0];
+#pragma unroll
+                for (int p = 1; p < P; ++p) acc[it][j] += px[j * D - p * M] * hv[it][p];
+            }
+            if constexpr (!OVL) {
+                int sft = (int)(((uint32_t)s0 + (uint32_t)f * (uint32_t)dmod) % (uint32_t)M);
+                cf32v *pa = A + f * FS;
+#pragma unroll
+                for (int j = 0; j < FG; ++j) {
+                    int rp = r - sft;
+                    rp += rp < 0 ? M : 0;
+                    pa[j * FS + rp] = acc[it][j];
+                    sft += dmod;
+                    sft -= sft >= M ? M : 0;
+                }
+            }
+        }
+        if constexpr (OVL) {
+            __syncthreads();   // every read of the window is done: the tile may overwrite it
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int item = tid_v + it * NT;
+                const int f = (item / M) * FG, r = item - (item / M) * M;
+                int sft = (int)(((uint32_t)s0 + (uint32_t)f * (uint32_t)dmod) % (uint32_t)M);
+                cf32v *pa = A + f * FS;
+#pragma unroll
+                for (int j = 0; j < FG; ++j) {
+                    int rp = r - sft;
+                    rp += rp < 0 ? M : 0;
+                    pa[j * FS + rp] = acc[it][j];
+                    sft += dmod;
+                    sft -= sft >= M ? M : 0;
+                }
+            }
+        }
+        PFB_T(2);
+        __syncthreads();
+        PFB_T(3);
+        // ---- pass 1 (in place: a thread owns column n2 of its output time)
+        {
+            cf32v x[M1];
+            cf32v *col = A + mi * FS + n2;
+#pragma unroll
+            for (int n1 = 0; n1 < M1; ++n1) x[n1] = col[n1 * M2];
+            SmallDft<M1>::run(x);
+#pragma unroll
+            for (int k1 = 0; k1 < M1; ++k1) col[k1 * M2] = cmulv(x[k1], wml[k1 * M2 + n2]);
+        }
+        PFB_T(4);
+        __syncthreads();
+        PFB_T(5);
+        // ---- pass 2
+        cf32v a[M2];
+        const bool act2 = tid < TB * M1;
+        if (act2) {
+            const cf32v *row = A + mib * FS + k1b * M2;
+#pragma unroll
+            for (int j = 0; j < M2; ++j) a[j] = row[j];
+        }
+        if constexpr (OVL) {
+            if (g + 1 < Q.G) __syncthreads();   // tile consumed: the next round's window may land on it
+        }
+        if constexpr (!OVL) {
+            // The next round's window lands in LDS here, BEFORE this round's stores are issued: loads
+            // and stores share vmcnt and retire out of order with respect to each other, so waiting for
+            // a load while stores are in flight means waiting for every store acknowledgement.
+            if (g + 1 < Q.G) {
+#pragma unroll
+                for (int k = 0; k < NPF; ++k)
+                    if (tid + k * NT < nu) pf[k].store(xs + 4 * (tid + k * NT));
+                for (int u = tid + NPF * NT; u < nu; u += NT) {
+                    PfbUnit<FMT> t;
+                    t.load(iq, nbase + (int64_t)TB * D + 4 * (int64_t)u, Q.n_in);
+                    t.store(xs + 4 * u);
+                }
+            }
+        }
+        if (act2) {
+            SmallDft<M2>::run(a);
+            const int64_t m = m0 + mib;
+            if (m < Q.n_out) {
+                cf32v *po = out + (int64_t)k1b * out_stride + m;
+                const int64_t step = (int64_t)M1 * out_stride;
+#pragma unroll
+                for (int k2 = 0; k2 < M2; ++k2) {
+#if TDM_PFB_STORE == 2
+                    __builtin_nontemporal_store(a[k2], po);
+#elif TDM_PFB_STORE == 1
+                    *po = a[k2];
+#else
+                    if (a[k2].x == 1.2345e30f) *po = a[k2];
+#endif
+                    po += step;
+                }
+            }
+        }
+        PFB_T(6);
     }
 }
 

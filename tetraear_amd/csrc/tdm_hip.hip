@@ -19,6 +19,9 @@
 #include "resample_plan.hpp"
 #include "sync_kernels.hpp"
 #include "tetra_kernels.hpp"
+#ifndef TDM_PFB_OVL
+#define TDM_PFB_OVL false
+#endif
 #include "pfb_kernels.hpp"
 #include "gate_kernels.hpp"
 #include "detect_kernels.hpp"
@@ -1151,9 +1154,9 @@ struct PfbTables {
 static std::mutex g_pfb_mu;
 static std::map<std::tuple<int, int, int, int>, PfbTables> g_pfb_cache;  // (device, M1, M2, D) -> tables (kept)
 
-template <int M1, int M2, int P>
-int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 *out, int64_t n_out, hipStream_t st,
-               bool sync)
+template <int M1, int M2, int P, int TB, int WGS, bool kOvl>
+int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 *out, int64_t n_out, int64_t pitch,
+               int n_streams, hipStream_t st, bool sync)
 {
     constexpr int M = M1 * M2, L = M * P;
     PfbTables tb;
@@ -1190,7 +1193,6 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
     }
     PfbParams Q{};
     Q.D = D;
-    Q.T = M <= 128 ? 32 : 8;
     Q.fmt = fmt;
     Q.n_in = n_in;
     Q.n_out = n_out;
@@ -1198,11 +1200,53 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
     Q.W1 = tb.tw;
     Q.WM = Q.W1 + M1 * M1;
     Q.W2 = Q.WM + M;
+    Q.in_stride = n_in * (int64_t)fmt_bytes(fmt);
+    Q.out_batch = (int64_t)M * pitch;
+    const bool force_direct = std::getenv("TDM_PFB_DIRECT") != nullptr;
+    if (!force_direct && D <= 4 * M) {
+        const int64_t rounds = (n_out + TB - 1) / TB;
+        Q.G = (int)std::min<int64_t>(8, std::max<int64_t>(1, rounds * n_streams / 2048));
+        if (const char *e = std::getenv("TDM_PFB_G")) Q.G = std::max(1, std::atoi(e));   // experiments
+        const size_t lds = pfb_fft_lds<M1, M2, P, TB, kOvl>(D) * sizeof(float2);
+        if (lds <= 160 * 1024) {
+            void (*kern)(const void *, cf32v *, int64_t, const PfbParams) = nullptr;
+            const int nu = ((TB - 1) * D + L + 3) / 4;
+            const bool one = nu <= TB * M2;   // one prefetched unit per thread covers the window
+            switch (fmt) {
+            case TDM_CU8: kern = one ? k_pfb_fft<M1, M2, P, TB, 0, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 0, kOvl, 3, WGS>; break;
+            case TDM_CS8: kern = one ? k_pfb_fft<M1, M2, P, TB, 1, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 1, kOvl, 3, WGS>; break;
+            default: kern = one ? k_pfb_fft<M1, M2, P, TB, 2, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 2, kOvl, 3, WGS>; break;
+            }
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const unsigned blocks = (unsigned)((rounds + Q.G - 1) / Q.G);
+#ifdef TDM_PFB_TIMING
+            static unsigned long long *dbg = nullptr;
+            if (!dbg) HIP_TRY(hipMalloc(&dbg, 64));
+            HIP_TRY(hipMemset(dbg, 0, 64));
+            Q.dbg = dbg;
+#endif
+            hipLaunchKernelGGL(kern, dim3(blocks, n_streams), dim3(TB * M2), lds, st, iq, (cf32v *)out, pitch, Q);
+            HIP_TRY(hipGetLastError());
+#ifdef TDM_PFB_TIMING
+            {
+                unsigned long long hdbg[8];
+                HIP_TRY(hipMemcpy(hdbg, dbg, 64, hipMemcpyDeviceToHost));
+                const double rounds_total = (double)rounds * n_streams;
+                fprintf(stderr, "pfb phases (memtime ticks/round): load %.0f bar %.0f A %.0f bar %.0f p1 %.0f bar %.0f p2 %.0f\n",
+                        hdbg[0] / rounds_total, hdbg[1] / rounds_total, hdbg[2] / rounds_total, hdbg[3] / rounds_total,
+                        hdbg[4] / rounds_total, hdbg[5] / rounds_total, hdbg[6] / rounds_total);
+            }
+#endif
+            if (sync) HIP_TRY(hipStreamSynchronize(st));
+            return TDM_OK;
+        }
+    }
+    Q.T = M <= 128 ? 32 : 8;
     const size_t lds = ((size_t)(Q.T - 1) * D + L + 2 * (size_t)Q.T * (M + 1) + M1 * M1 + M + M2 * M2) * sizeof(float2);
     if (lds > 160 * 1024) return fail(TDM_ERR_UNSUPPORTED, "channeliser tile does not fit LDS");
     HIP_TRY(hipFuncSetAttribute((const void *)k_pfb<M1, M2, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned blocks = (unsigned)((n_out + Q.T - 1) / Q.T);
-    hipLaunchKernelGGL((k_pfb<M1, M2, P>), dim3(blocks), dim3(kPfbThreads), lds, st, iq, out, n_out, Q);
+    hipLaunchKernelGGL((k_pfb<M1, M2, P>), dim3(blocks, n_streams), dim3(kPfbThreads), lds, st, iq, out, pitch, Q);
     HIP_TRY(hipGetLastError());
     if (sync) HIP_TRY(hipStreamSynchronize(st));
     return TDM_OK;
@@ -1211,37 +1255,47 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
 
 extern "C" {
 
-int tdm_channelise(const void *iq, int32_t in_fmt, int64_t n_in, int32_t M, int32_t D, float *out, int64_t *n_out,
-                   int32_t device_pointers, int32_t device)
+int tdm_channelise_batch(const void *iq, int32_t in_fmt, int64_t n_in, int32_t n_streams, int32_t M, int32_t D,
+                          float *out, int64_t out_pitch, int64_t *n_out, int32_t device_pointers, int32_t device)
 {
-    if (!iq || !out || !n_out || n_in < 1 || D < 1 || (in_fmt != TDM_CU8 && in_fmt != TDM_CS8 && in_fmt != TDM_CF32))
+    if (!iq || !out || !n_out || n_in < 1 || D < 1 || n_streams < 1 || n_streams > 65535 ||
+        (out_pitch != 0 && out_pitch < (n_in + D - 1) / D) ||
+        (in_fmt != TDM_CU8 && in_fmt != TDM_CS8 && in_fmt != TDM_CF32))
         return fail(TDM_ERR_INVALID, "bad argument");
     int rc = use_device(device);
     if (rc) return rc;
     const int64_t no = (n_in + D - 1) / D;
     *n_out = no;
+    const int64_t pitch = out_pitch ? out_pitch : no;
     DevBuf din, dout;
     const void *src = iq;
     float2 *dst = (float2 *)out;
+    const size_t ib = (size_t)n_streams * n_in * fmt_bytes(in_fmt), ob = (size_t)n_streams * M * pitch * sizeof(float2);
     if (!device_pointers) {
-        const size_t ib = (size_t)n_in * fmt_bytes(in_fmt), ob = (size_t)M * no * sizeof(float2);
         if ((rc = din.alloc(ib)) || (rc = dout.alloc(ob))) return rc;
         HIP_TRY(hipMemcpy(din.p, iq, ib, hipMemcpyHostToDevice));
         src = din.p;
         dst = dout.as<float2>();
     }
+    const bool sync = !device_pointers;
     switch (M) {
     // device pointers: enqueue on the default stream and return (tdm_dev_sync waits)
-    case 96: rc = launch_pfb<8, 12, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
-    case 72: rc = launch_pfb<8, 9, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
-    case 80: rc = launch_pfb<8, 10, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
-    case 128: rc = launch_pfb<8, 16, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
-    case 400: rc = launch_pfb<20, 20, 3>(device, src, in_fmt, n_in, D, dst, no, 0, !device_pointers); break;
+    case 96: rc = launch_pfb<8, 12, 3, 24, 3, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 72: rc = launch_pfb<8, 9, 3, 48, 2, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 80: rc = launch_pfb<8, 10, 3, 32, 3, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 128: rc = launch_pfb<8, 16, 3, 16, 4, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 400: rc = launch_pfb<20, 20, 3, 16, (TDM_PFB_OVL ? 3 : 2), TDM_PFB_OVL>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
     default: return fail(TDM_ERR_UNSUPPORTED, "channeliser built for M in {72, 80, 96, 128, 400}");
     }
     if (rc) return rc;
-    if (!device_pointers) HIP_TRY(hipMemcpy(out, dout.p, (size_t)M * no * sizeof(float2), hipMemcpyDeviceToHost));
+    if (!device_pointers) HIP_TRY(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
     return TDM_OK;
+}
+
+int tdm_channelise(const void *iq, int32_t in_fmt, int64_t n_in, int32_t M, int32_t D, float *out, int64_t *n_out,
+                   int32_t device_pointers, int32_t device)
+{
+    return tdm_channelise_batch(iq, in_fmt, n_in, 1, M, D, out, 0, n_out, device_pointers, device);
 }
 
 // ---- introspection (no device needed) -----------------------------------------------------------
