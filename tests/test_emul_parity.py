@@ -126,3 +126,14 @@ def test_emul_resample(gold_stages):
         ref = resample_np(x[:n], 1.0, num / n + 1e-12)
         assert len(ref) == num
         assert np.max(np.abs(emul.resample(x[:n], num) - ref)) < 1e-13, (n, num)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 8, 9, 10, 12, 16, 20, 25])
+def test_small_dft_templates_match_numpy(n):
+    """Register-resident DFTs of the channeliser (small_dft.hpp: radix 2/3/4/5 butterflies, Cooley-Tukey
+    and Good-Thomas composites, constexpr twiddles) against numpy, sign +, unnormalised."""
+    rng = np.random.default_rng(n)
+    for _ in range(4):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        ref = np.fft.ifft(x.astype(np.complex128)) * n
+        assert np.max(np.abs(emul.small_dft(x) - ref)) < 4e-7 * np.max(np.abs(ref)) * np.sqrt(n)

@@ -392,19 +392,8 @@ __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb
         PFB_T(4);
         __syncthreads();
         PFB_T(5);
-        // ---- pass 2
-        cf32v a[M2];
-        const bool act2 = tid < TB * M1;
-        if (act2) {
-            const cf32v *row = A + mib * FS + k1b * M2;
-#pragma unroll
-            for (int j = 0; j < M2; ++j) a[j] = row[j];
-        }
-        if constexpr (OVL) {
-            if (g + 1 < Q.G) __syncthreads();   // tile consumed: the next round's window may land on it
-        }
         if constexpr (!OVL) {
-            // The next round's window lands in LDS here, BEFORE this round's stores are issued: loads
+            // The next round's window lands in LDS here (start of pass 2), BEFORE this round's stores are issued: loads
             // and stores share vmcnt and retire out of order with respect to each other, so waiting for
             // a load while stores are in flight means waiting for every store acknowledgement.
             if (g + 1 < Q.G) {
@@ -418,15 +407,33 @@ __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb
                 }
             }
         }
+        PFB_T(8);
+        // ---- pass 2
+        cf32v a[M2];
+        const bool act2 = tid < TB * M1;
+        if (act2) {
+            const cf32v *row = A + mib * FS + k1b * M2;
+#pragma unroll
+            for (int j = 0; j < M2; ++j) a[j] = row[j];
+        }
+        if constexpr (OVL) {
+            if (g + 1 < Q.G) __syncthreads();   // tile consumed: the next round's window may land on it
+        }
+        PFB_T(7);
         if (act2) {
             SmallDft<M2>::run(a);
             const int64_t m = m0 + mib;
             if (m < Q.n_out) {
+#if TDM_PFB_STORE == 3   // experiment: contiguous 512 B per wave-instruction (wrong layout)
+                cf32v *po = out + ((int64_t)(blockIdx.x * Q.G + g) * (NT / 64) + tid / 64) * (M2 * 64) + (tid & 63);
+                const int64_t step = 64;
+#else
                 cf32v *po = out + (int64_t)k1b * out_stride + m;
                 const int64_t step = (int64_t)M1 * out_stride;
+#endif
 #pragma unroll
                 for (int k2 = 0; k2 < M2; ++k2) {
-#if TDM_PFB_STORE == 2
+#if TDM_PFB_STORE >= 2
                     __builtin_nontemporal_store(a[k2], po);
 #elif TDM_PFB_STORE == 1
                     *po = a[k2];

@@ -1213,28 +1213,29 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
             const int nu = ((TB - 1) * D + L + 3) / 4;
             const bool one = nu <= TB * M2;   // one prefetched unit per thread covers the window
             switch (fmt) {
-            case TDM_CU8: kern = one ? k_pfb_fft<M1, M2, P, TB, 0, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 0, kOvl, 3, WGS>; break;
-            case TDM_CS8: kern = one ? k_pfb_fft<M1, M2, P, TB, 1, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 1, kOvl, 3, WGS>; break;
-            default: kern = one ? k_pfb_fft<M1, M2, P, TB, 2, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 2, kOvl, 3, WGS>; break;
+            case TDM_CU8: kern = one ? k_pfb_fft<M1, M2, P, TB, 0, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 0, kOvl, 2, WGS>; break;
+            case TDM_CS8: kern = one ? k_pfb_fft<M1, M2, P, TB, 1, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 1, kOvl, 2, WGS>; break;
+            default: kern = one ? k_pfb_fft<M1, M2, P, TB, 2, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 2, kOvl, 2, WGS>; break;
             }
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const unsigned blocks = (unsigned)((rounds + Q.G - 1) / Q.G);
 #ifdef TDM_PFB_TIMING
             static unsigned long long *dbg = nullptr;
-            if (!dbg) HIP_TRY(hipMalloc(&dbg, 64));
-            HIP_TRY(hipMemset(dbg, 0, 64));
+            if (!dbg) HIP_TRY(hipMalloc(&dbg, 128));
+            HIP_TRY(hipMemset(dbg, 0, 128));
             Q.dbg = dbg;
 #endif
             hipLaunchKernelGGL(kern, dim3(blocks, n_streams), dim3(TB * M2), lds, st, iq, (cf32v *)out, pitch, Q);
             HIP_TRY(hipGetLastError());
 #ifdef TDM_PFB_TIMING
             {
-                unsigned long long hdbg[8];
-                HIP_TRY(hipMemcpy(hdbg, dbg, 64, hipMemcpyDeviceToHost));
+                unsigned long long hdbg[16];
+                HIP_TRY(hipMemcpy(hdbg, dbg, 128, hipMemcpyDeviceToHost));
                 const double rounds_total = (double)rounds * n_streams;
-                fprintf(stderr, "pfb phases (memtime ticks/round): load %.0f bar %.0f A %.0f bar %.0f p1 %.0f bar %.0f p2 %.0f\n",
+                fprintf(stderr, "pfb phases (memtime ticks/round): load %.0f bar %.0f A %.0f bar %.0f p1 %.0f bar %.0f p2: lds %.0f land %.0f fft+st %.0f\n",
                         hdbg[0] / rounds_total, hdbg[1] / rounds_total, hdbg[2] / rounds_total, hdbg[3] / rounds_total,
-                        hdbg[4] / rounds_total, hdbg[5] / rounds_total, hdbg[6] / rounds_total);
+                        hdbg[4] / rounds_total, hdbg[5] / rounds_total, hdbg[7] / rounds_total, hdbg[8] / rounds_total,
+                        hdbg[6] / rounds_total);
             }
 #endif
             if (sync) HIP_TRY(hipStreamSynchronize(st));
@@ -1284,7 +1285,12 @@ int tdm_channelise_batch(const void *iq, int32_t in_fmt, int64_t n_in, int32_t n
     case 72: rc = launch_pfb<8, 9, 3, 48, 2, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
     case 80: rc = launch_pfb<8, 10, 3, 32, 3, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
     case 128: rc = launch_pfb<8, 16, 3, 16, 4, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 400: rc = launch_pfb<20, 20, 3, 16, (TDM_PFB_OVL ? 3 : 2), TDM_PFB_OVL>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 400:
+        if (std::getenv("TDM_PFB_TB16"))
+            rc = launch_pfb<20, 20, 3, 16, (TDM_PFB_OVL ? 3 : 2), TDM_PFB_OVL>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync);
+        else
+            rc = launch_pfb<20, 20, 3, 32, 1, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync);
+        break;
     default: return fail(TDM_ERR_UNSUPPORTED, "channeliser built for M in {72, 80, 96, 128, 400}");
     }
     if (rc) return rc;

@@ -16,7 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 find $OUT -name "*.csv" | head -20
 # tetra-mode legs (no reference oracle): RRC stage HBM roofline, channeliser
 python bench.py --mode tetra --carriers 4096 --steps 20 --warmup 3 > $OUT/bench_tetra.json 2> $OUT/bench_tetra.err
-python bench.py --mode pfb --carriers 3200 --steps 10 --warmup 2 > $OUT/bench_pfb.json 2> $OUT/bench_pfb.err
+python bench.py --mode pfb --carriers 12800 --steps 20 --warmup 3 > $OUT/bench_pfb.json 2> $OUT/bench_pfb.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tetra -o tetra -- python bench.py --mode tetra --carriers 4096 --steps 5 --warmup 2 > /dev/null 2> $OUT/trace_tetra.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_fetch -o fetch -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_write -o write -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_write.err
