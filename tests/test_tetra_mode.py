@@ -163,3 +163,30 @@ def test_gpu_wideband_to_symbols():
         ber, lag = best_ber(hards[i], dibs[k], edge=8)
         assert len(hards[i]) > 900 and ber == 0.0, (k, ber, lag)
     bd.close()
+
+
+@pytest.mark.gpu
+def test_gpu_pitched_rows_and_odd_chunk_lengths():
+    """TETRA-mode plans read carriers at any row stride >= n (the channeliser's pitched output) and
+    handle odd chunk lengths; results equal the dense even-length call on the same samples."""
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    fs, rows = 80000.0, 3
+    for n, pitch in ((8389, 8400), (8389, 8389), (8192, 8200), (4097, 4101)):
+        xs = [make_signal(n, fs, 900 + r, 0.1 * r, 30.0 * r, 20.0)[0] for r in range(rows)]
+        dense = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA)
+        h0, s0, t0, m0 = dense.process(np.concatenate(xs))
+        padded = np.zeros((rows, pitch), dtype=np.complex64)
+        for r in range(rows):
+            padded[r, :n] = xs[r]
+            padded[r, n:] = 7.0   # must never be read
+        hard = np.zeros((rows, dense.info.max_soft), dtype=np.uint8)
+        soft = np.zeros((rows, dense.info.max_soft), dtype=np.complex64)
+        n_soft = np.zeros(rows, dtype=np.int32)
+        from tetraear_amd._lib import check, ptr
+        check(dense.lib.tdm_process(dense.handle, ptr(padded), pitch, None, None, ptr(hard), ptr(soft), ptr(n_soft), None, None))
+        for r in range(rows):
+            np.testing.assert_array_equal(hard[r, :n_soft[r] - 1], h0[r])
+            np.testing.assert_array_equal(soft[r, :n_soft[r]], s0[r])
+            assert best_ber(h0[r], make_signal(n, fs, 900 + r, 0.1 * r, 30.0 * r, 20.0)[1], edge=8)[0] == 0.0
+        dense.close()

@@ -132,10 +132,13 @@ class BatchDemodulator:
         if pre_shifts is not None:
             d["pre"].upload(np.ascontiguousarray(pre_shifts, dtype=np.float64))
 
-    def enqueue(self):
-        """One pass of the hot path over the resident batch (asynchronous)."""
+    def enqueue(self, iq_ptr=None, stride=None):
+        """One pass of the hot path over the resident batch (asynchronous).  `iq_ptr` / `stride`
+        (samples between carriers) let the pass read another device buffer, e.g. the channeliser's
+        pitched [channels][pitch] output."""
         d = self._dev
-        check(self.lib.tdm_process_device(self.handle, d["iq"].ptr, 0 if d["shared"] else self.n_samples,
+        check(self.lib.tdm_process_device(self.handle, iq_ptr if iq_ptr is not None else d["iq"].ptr,
+                                          (0 if d["shared"] else self.n_samples) if stride is None else int(stride),
                                           d["pre"].ptr if d["use_pre"] else None,
                                           d["foff"].ptr if d["use_foff"] else None, d["hard"].ptr, d["soft"].ptr,
                                           d["n_soft"].ptr, d["bp"].ptr, d["mm"].ptr, None))

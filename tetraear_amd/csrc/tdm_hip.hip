@@ -471,6 +471,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         TetraParams &tp = p->tp;
         tp.n = (int32_t)n_samples;
         tp.ntaps = (int32_t)h.size();
+        tp.ystride = (int32_t)((n_samples + 1) & ~(int64_t)1);
         tp.sps = sps;
         tp.inv_sps = 1.0 / sps;
         tp.step_c = (float)std::cos(-2.0 * M_PI / sps);
@@ -487,7 +488,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&p->ev0));
         HIP_TRY(hipEventCreate(&p->ev1));
-        HIP_TRY(hipMalloc(&p->d_ty, (size_t)n_carriers * n_samples * sizeof(float2)));
+        HIP_TRY(hipMalloc(&p->d_ty, (size_t)n_carriers * tp.ystride * sizeof(float2)));
         HIP_TRY(hipMalloc(&p->d_tsym, (size_t)n_carriers * tp.max_soft * sizeof(float2)));
         HIP_TRY(hipMalloc(&p->d_tstat, (size_t)n_carriers * kMaxTimingBlocks * sizeof(float2)));
         *out = p.release();
@@ -548,14 +549,15 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     if (plan->mode == TDM_MODE_TETRA) {
         if (pre_shift_hz || freq_offset_hz)
             return fail(TDM_ERR_UNSUPPORTED, "TETRA mode: carrier offsets are estimated, not supplied");
-        if (carrier_stride_samples != plan->tp.n) return fail(TDM_ERR_INVALID, "TETRA mode: carriers must be contiguous");
+        if (carrier_stride_samples < plan->tp.n)
+            return fail(TDM_ERR_INVALID, "TETRA mode: carrier stride shorter than the chunk");
         const TetraParams &tp = plan->tp;
         const dim3 grid((tp.n + kRrcTile - 1) / kRrcTile, plan->rows);
         {
             HipBackend::Scope s(be, ST_TETRA_RRC);
             const float2 *x = (const float2 *)iq;
             switch (tp.ntaps) {
-#define TDM_RRC_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_rrc<NT>), grid, dim3(kRrcThreads), 0, be.stream, x, plan->d_ty, plan->d_tstat, tp); break;
+#define TDM_RRC_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_rrc<NT>), grid, dim3(kRrcThreads), 0, be.stream, x, carrier_stride_samples, plan->d_ty, plan->d_tstat, tp); break;
                 TDM_RRC_CASE(17) TDM_RRC_CASE(25) TDM_RRC_CASE(33) TDM_RRC_CASE(35) TDM_RRC_CASE(41) TDM_RRC_CASE(49) TDM_RRC_CASE(57) TDM_RRC_CASE(65)
 #undef TDM_RRC_CASE
             default: return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");

@@ -26,7 +26,7 @@ struct TetraParams {
     int32_t n;          // samples per carrier chunk
     int32_t ntaps;      // odd
     int32_t max_soft;   // capacity of per-carrier symbol outputs
-    int32_t pad_;
+    int32_t ystride;    // row stride of the matched-filter output (n rounded up to even: 16-byte rows)
     double sps;         // samples per symbol (sample_rate / 18000)
     double inv_sps;
     float step_c, step_s;  // exp(-2 pi i / sps): symbol-clock phasor advance per sample
@@ -41,8 +41,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int rrc_slot(int s) { return s + (s >> 3); }
 
 template <int NT>
-__global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restrict__ x, float2 *__restrict__ y,
-                                                            float2 *__restrict__ tstat, const TetraParams P)
+__global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restrict__ x, int64_t in_stride,
+                                                            float2 *__restrict__ y, float2 *__restrict__ tstat,
+                                                            const TetraParams P)
 {
     static_assert(kTimingBlock == 32 * kRrcPerThread, "one timing sub-block = 32 threads x 8 outputs");
     constexpr int HALO = NT - 1;
@@ -51,18 +52,24 @@ __global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restr
     const int row = blockIdx.y;
     const int n = P.n;
     const int64_t base = (int64_t)blockIdx.x * kRrcTile;          // first output of the tile
-    const float2 *xr = x + (int64_t)row * n;
-    float2 *yr = y + (int64_t)row * n;
+    const float2 *xr = x + (int64_t)row * in_stride;   // rows of the channeliser may carry a pitch
+    float2 *yr = y + (int64_t)row * P.ystride;
     const int t = threadIdx.x;
     // stage inputs base - HALO/2 .. base + tile + HALO/2 (zero outside the chunk), coalesced;
     // 16 bytes per lane (two samples) when the tile start is 16-byte aligned in the row
-    if (((HALO / 2) & 1) == 0 && (n & 1) == 0) {
+    if (((HALO / 2) & 1) == 0 && (in_stride & 1) == 0) {
         const f32x4 *x4 = (const f32x4 *)xr;
         for (int s2 = t; s2 < NS / 2; s2 += kRrcThreads) {
             const int s = 2 * s2;
             const int64_t g = base + s - HALO / 2;  // even
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g >= 0 && g + 1 < n) v = __builtin_nontemporal_load(x4 + (g >> 1));
+            if (g >= 0 && g + 1 < n) {
+                v = __builtin_nontemporal_load(x4 + (g >> 1));
+            } else if (g >= 0 && g < n) {   // last sample of an odd-length chunk
+                const float2 q = xr[g];
+                v.x = q.x;
+                v.y = q.y;
+            }
             lds[rrc_slot(s)] = make_float2(v.x, v.y);
             lds[rrc_slot(s + 1)] = make_float2(v.z, v.w);
         }
@@ -130,21 +137,16 @@ __global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restr
 #pragma unroll
     for (int v = 0; v < kRrcPerThread; ++v) lds[rrc_slot(kRrcPerThread * t + v)] = make_float2(acc[v].x, acc[v].y);
     __syncthreads();
-    if ((n & 1) == 0) {
-        f32x4 *y4 = (f32x4 *)yr;
-        for (int s2 = t; s2 < kRrcTile / 2; s2 += kRrcThreads) {
-            const int s = 2 * s2;
-            const int64_t g = base + s;
-            if (g + 1 < n) {
-                const float2 a = lds[rrc_slot(s)], b = lds[rrc_slot(s + 1)];
-                const f32x4 o = {a.x, a.y, b.x, b.y};
-                __builtin_nontemporal_store(o, y4 + (g >> 1));
-            }
-        }
-    } else {
-        for (int s = t; s < kRrcTile; s += kRrcThreads) {
-            const int64_t g = base + s;
-            if (g < n) yr[g] = lds[rrc_slot(s)];
+    f32x4 *y4 = (f32x4 *)yr;
+    for (int s2 = t; s2 < kRrcTile / 2; s2 += kRrcThreads) {
+        const int s = 2 * s2;
+        const int64_t g = base + s;
+        if (g + 1 < n) {
+            const float2 a = lds[rrc_slot(s)], b = lds[rrc_slot(s + 1)];
+            const f32x4 o = {a.x, a.y, b.x, b.y};
+            __builtin_nontemporal_store(o, y4 + (g >> 1));
+        } else if (g < n) {
+            yr[g] = lds[rrc_slot(s)];
         }
     }
 }
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
     const int row = blockIdx.x;
     const int n = P.n;
     const double sps = P.sps;
-    const float2 *yr = y + (int64_t)row * n;
+    const float2 *yr = y + (int64_t)row * P.ystride;
     float2 *sr = soft + (int64_t)row * P.max_soft;  // soft symbols (cf32) double as the scratch of step 4
     const int tid = threadIdx.x;
     const int nb = (n + kTimingBlock - 1) / kTimingBlock;
