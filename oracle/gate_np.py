@@ -1,8 +1,9 @@
 """ORACLE (test infrastructure): numpy restatement of the spectrum / AFC / signal gate that sits in
 front of process() in the reference's capture loop, tetraear/ui/modern.py:1921-2021 (inside
 CaptureThread.run; the module needs PyQt6 and cannot be imported here, and the block is inline code,
-not a function -- so this restatement is "parity unpinned": it follows the source line by line but no
-golden vector from the reference itself backs it)."""
+not a function).  Pinned by tests/golden/gate.npz: tests/golden/make_golden_gate.py takes the block's
+statements out of the reference's AST and executes them unchanged; this restatement reproduces those
+outputs bit for bit (tests/test_gate.py::test_oracle_matches_reference_block)."""
 import numpy as np
 
 

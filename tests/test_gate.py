@@ -1,6 +1,9 @@
-"""Spectrum / AFC / signal gate: kernel body (CPU emulation) and GPU path against the
-numpy restatement of tetraear/ui/modern.py:1921-2021 (oracle/gate_np.py; parity unpinned: the block is
-inline GUI-thread code that cannot be imported)."""
+"""Spectrum / AFC / signal gate: the numpy restatement (oracle/gate_np.py), the kernel
+body (CPU emulation) and the GPU path against tests/golden/gate.npz -- outputs of the reference's own
+statements (tetraear/ui/modern.py:1919-2021, :2032), executed from its AST by
+tests/golden/make_golden_gate.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +12,56 @@ from tetraear_amd import synth
 
 FS = 2.4e6
 SPECS = [(0.0, 30.0), (3000.0, 30.0), (-2500.0, 5.0), (9000.0, 30.0), (-11000.0, 25.0), (500.0, -5.0)]
+
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gate.npz"))
+KEYS = ("peak_freq_offset", "signal_power", "peak_power", "noise_floor", "snr")
+
+
+def test_oracle_matches_reference_block():
+    """bit-identical: the restatement performs the reference's numpy operations in the reference's order"""
+    n_strong = 0
+    for name in GOLD["names"]:
+        x = synth.cu8_to_c128(GOLD[f"in_{name}"])
+        ref, fs = GOLD[f"out_{name}"], float(GOLD[f"fs_{name}"][0])
+        got = gate_np.gate(x, fs)
+        for i, k in enumerate(KEYS):
+            assert got[k] == ref[i], (name, k)
+        assert got["strong"] == bool(ref[5]) and got["afc"] == ref[6], name
+        n_strong += int(ref[5])
+    assert 0 < n_strong < len(GOLD["names"])
+
+
+def _golden_groups():
+    """golden cases grouped by (sample rate, length) so that one batched call covers a group"""
+    groups = {}
+    for name in GOLD["names"]:
+        u8 = GOLD[f"in_{name}"]
+        groups.setdefault((float(GOLD[f"fs_{name}"][0]), len(u8) // 2), []).append(str(name))
+    return groups
+
+
+def test_emul_gate_matches_reference_block():
+    from tests.emul import emul
+    for (fs, n), names in _golden_groups().items():
+        out, afc = emul.gate(np.concatenate([GOLD[f"in_{m}"] for m in names]), "cu8", n, len(names), fs)
+        for r, m in enumerate(names):
+            ref = GOLD[f"out_{m}"]
+            for i in range(5):
+                assert abs(out[r][i] - ref[i]) <= 1e-9 * max(1.0, abs(ref[i])), (m, KEYS[i])
+            assert bool(out[r][5]) == bool(ref[5]) and out[r][6] == ref[6] == afc[r], m
+
+
+@pytest.mark.gpu
+def test_gpu_gate_matches_reference_block():
+    from tetraear_amd.gate import spectrum_gate
+    for (fs, n), names in _golden_groups().items():
+        res, afc = spectrum_gate(np.concatenate([GOLD[f"in_{m}"] for m in names]), "cu8", n, len(names), fs)
+        for r, m in enumerate(names):
+            ref = GOLD[f"out_{m}"]
+            for i, k in enumerate(KEYS):
+                assert abs(res[r][k] - ref[i]) <= 1e-9 * max(1.0, abs(ref[i])), (m, k)
+            assert bool(res[r]["strong"]) == bool(ref[5]) and res[r]["afc"] == ref[6] == afc[r], m
 
 
 def _rows(n):

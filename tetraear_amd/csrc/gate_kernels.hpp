@@ -122,7 +122,9 @@ TDM_HD void gate_body(const GateArgs &A, Comm &cm, int row)
         for (int p = start + tid; p < end; p += nt)
             if (power[p] == peak) cand = fmin(cand, (double)p);   // np.argmax: first maximum
         const int peak_idx = (int)cm.reduce_min(cand);
-        peak_off = (double)(peak_idx - center) * freq_res;       // fftshift(fftfreq)[peak_idx]
+        // fftshift(fftfreq(N, 1/fs))[peak_idx]: numpy forms k * (1.0 / (N * d)) with d = 1/fs rounded first
+        const double d = 1.0 / A.fs;
+        peak_off = (double)(peak_idx - center) * (1.0 / ((double)N * d));
         int n1 = start - 10;
         if (n1 < 0) n1 = 0;
         int s2 = end + 10;
