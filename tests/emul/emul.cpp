@@ -127,11 +127,11 @@ struct EmuBackend {
     void power_fixup(const ZpParams &P, int rows, int64_t n, double *z, int sps, double *partials, int n_pblk)
     {
         for (int row = 0; row < rows; ++row)
-            for (int b = 0; b < n_pblk; ++b)
+            for (int b = 0; b < (n_pblk + kPowSub - 1) / kPowSub; ++b)
                 run_group(kPowThreads, [&](int t, Group *g) {
                     EmuBlockComm cm{g, t};
-                    power_fixup_body<D, L>(P, cm, row, b, z + (int64_t)row * n * 2, n, sps,
-                                           partials + (int64_t)row * n_pblk * kMaxSps);
+                    power_fixup_body<D, L>(P, cm, row, b, z ? z + (int64_t)row * n * 2 : nullptr, n, sps,
+                                           partials + (int64_t)row * n_pblk * kMaxSps, n_pblk);
                 });
     }
     void finish(const FinishArgs &fa, int rows)

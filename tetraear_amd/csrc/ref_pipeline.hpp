@@ -55,6 +55,7 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     const double *zin = B.y;
     const double *partials = nullptr;
     int n_pblk = 0;
+    bool fix_in_finish = false;
     if (h.lpf) {
         // filter_signal(samples, 25000, current_rate)  (processor.py:264).  When decimated, the
         // loader finishes the decimator output (carry responses) and applies
@@ -69,8 +70,10 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         be.template zp_carry<2, 2>(B.lpf_params, h.lpf_t.p.nb, rows);
         if (h.sps > 1 && h.sps <= kMaxSps) {
             n_pblk = h.lpf_t.p.nb * (kWave * kLLpf / kPowThreads);
-            be.template power_fixup<4, kLLpf>(B.lpf_params, rows, h.n_dec, B.z, h.sps, B.partials, n_pblk);
+            // z itself is not written: the finish stage evaluates it at the symbols it gathers
+            be.template power_fixup<4, kLLpf>(B.lpf_params, rows, h.n_dec, nullptr, h.sps, B.partials, n_pblk);
             partials = B.partials;
+            fix_in_finish = true;
         } else {
             be.template zp_fixup<4, kLLpf>(B.lpf_params, h.lpf_t.p.nb, rows, B.z, h.n_dec, nullptr, h.rate_dec);
         }
@@ -92,6 +95,9 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     fa.min_margin = io.min_margin;
     fa.partials = partials;
     fa.n_pblk = n_pblk;
+    fa.use_fix = fix_in_finish;
+    if (fix_in_finish) fa.fix = B.lpf_params;
+    static_assert(kFixBn == kWave * kLLpf, "finish evaluates the channel filter's fix-up with its block length");
     be.finish(fa, rows);
 }
 

@@ -169,11 +169,12 @@ template <int D, int L>
 __global__ __launch_bounds__(kPowThreads) void k_power_fixup(const ZpParams P, int64_t n, double *z, int sps,
                                                             double *partials, int n_pblk)
 {
-    __shared__ double buf[kPowThreads];
+    static_assert(kPowSub * kMaxSps <= kPowThreads, "one thread per (power block, phase)");
+    __shared__ double buf[kPowSub * kPowThreads];
     BlockComm cm{nullptr, buf};
     const int row = blockIdx.y;
-    power_fixup_body<D, L>(P, cm, row, (int)blockIdx.x, z + (int64_t)row * n * 2, n, sps,
-                           partials + (int64_t)row * n_pblk * kMaxSps);
+    power_fixup_body<D, L>(P, cm, row, (int)blockIdx.x, z ? z + (int64_t)row * n * 2 : nullptr, n, sps,
+                           partials + (int64_t)row * n_pblk * kMaxSps, n_pblk);
 }
 
 __global__ __launch_bounds__(kFinishThreads) void k_dft_terms(const int64_t *o_list, const double *in, int64_t n_terms,
@@ -314,8 +315,8 @@ struct HipBackend {
     void power_fixup(const ZpParams &P, int rows, int64_t n, double *z, int sps, double *partials, int n_pblk)
     {
         Scope s(*this, ST_LPF_FIXUP);
-        hipLaunchKernelGGL((k_power_fixup<D, L>), dim3(n_pblk, rows), dim3(kPowThreads), 0, stream, P, n, z, sps,
-                           partials, n_pblk);
+        hipLaunchKernelGGL((k_power_fixup<D, L>), dim3((n_pblk + kPowSub - 1) / kPowSub, rows), dim3(kPowThreads), 0,
+                           stream, P, n, z, sps, partials, n_pblk);
     }
     void finish(const FinishArgs &fa, int rows)
     {

@@ -758,10 +758,16 @@ struct FinishArgs {
     // optional per-block partial phase powers made by power_fixup_body (deterministic order):
     const double *partials;  // [rows][n_pblk][kMaxSps] or null -> powers are computed here
     int32_t n_pblk;
+    // use_fix != 0: z is not materialised; sample j is the channel filter's block-local output plus its
+    // carry responses, evaluated where it is gathered (zp_fixup_at<4> on `fix`, block length kFixBn)
+    int32_t use_fix;
+    ZpParams fix;
 };
 
 constexpr int kMaxSps = 32;       // phases a partial-power record holds
 constexpr int kPowThreads = 256;  // threads (= samples) per partial-power block
+constexpr int kPowSub = 8;        // partial-power blocks per workgroup
+constexpr int kFixBn = kWave * 16;  // block length of the channel filter (ref_plan.hpp kLLpf)
 
 TDM_HD uint8_t dqpsk_decide(double cr, double ci, double pr, double pi_, double &margin)
 {
@@ -848,23 +854,32 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
     const int64_t stride = (A.do_extract && sps > 1) ? sps : 1;
     double mx = 0;
     for (int64_t k = tid; k < ns; k += nt) {
-        const double *s = z + (best + k * stride) * 2;
-        soft[k * 2] = s[0];
-        soft[k * 2 + 1] = s[1];
-        mx = fmax(mx, hypot(s[0], s[1]));
+        const int64_t j = best + k * stride;
+        double re, im;
+        if (A.use_fix) {
+            const int64_t pos = j + A.fix.k0L;
+            const int b = (int)(pos / kFixBn);
+            zp_fixup_at<4>(A.fix, row, b, (int)(pos - (int64_t)b * kFixBn), j, re, im);
+        } else {
+            re = z[j * 2];
+            im = z[j * 2 + 1];
+        }
+        soft[k * 2] = re;
+        soft[k * 2 + 1] = im;
+        mx = fmax(mx, hypot(re, im));
     }
     if (tid == 0) {
         A.n_soft[row] = (int32_t)ns;
         if (A.best_phase) A.best_phase[row] = (int32_t)best;
     }
     if (!A.do_demod) return;
-    mx = cm.reduce_max(mx);
+    mx = cm.reduce_max(mx);   // (its barriers also make the soft symbols of other threads visible)
     double margin = INFINITY;
     if (ns >= 2) {
         const double scl = mx > 0 ? 1.0 / mx : 1.0;  // samples / max_power == samples * fl(1/max)
         for (int64_t k = 1 + tid; k < ns; k += nt) {
-            const double *c = z + (best + k * stride) * 2;
-            const double *p = z + (best + (k - 1) * stride) * 2;
+            const double *c = soft + k * 2;
+            const double *p = soft + (k - 1) * 2;
             double mg;
             hard[k - 1] = dqpsk_decide(mul_rn(c[0], scl), mul_rn(c[1], scl), mul_rn(p[0], scl),
                                        mul_rn(p[1], scl), mg);
@@ -882,38 +897,51 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
 //   Comm: tid(), sync(), lds(i) -> double& (workgroup-shared scratch of kPowThreads doubles)
 // ------------------------------------------------------------------------------------------
 template <int D, int L, class Comm>
-TDM_HD void power_fixup_body(const ZpParams &P, Comm &cm, int row, int blk, double *z_row, int64_t n, int sps,
-                             double *partials_row /* [n_pblk][kMaxSps] */)
+TDM_HD void power_fixup_body(const ZpParams &P, Comm &cm, int row, int wg, double *z_row /* or null */, int64_t n,
+                             int sps, double *partials_row /* [n_pblk][kMaxSps] */, int n_pblk)
 {
     constexpr int Bn = kWave * L;
-    constexpr int kSub = Bn / kPowThreads;  // workgroups per filter block (out_stride == 1 here)
-    static_assert(Bn % kPowThreads == 0, "block must be a whole number of power workgroups");
+    constexpr int kSub = Bn / kPowThreads;  // partial-power blocks per filter block (out_stride == 1 here)
+    static_assert(Bn % kPowThreads == 0, "block must be a whole number of power blocks");
     const int t = cm.tid();
-    const int b = blk / kSub;
-    const int m = (blk % kSub) * kPowThreads + t;
-    const int64_t j0 = (int64_t)b * Bn + (blk % kSub) * kPowThreads - P.k0L;  // may be negative
-    const int64_t j = j0 + t;
-    double sq = 0;
-    if (j >= 0 && j < n) {
-        double re, im;
-        zp_fixup_at<D>(P, row, b, m, j, re, im);
-        z_row[j * 2] = re;
-        z_row[j * 2 + 1] = im;
-        const double mg = hypot(re, im);
-        sq = mg * mg;
-    }
-    cm.lds(t) = sq;
-    cm.sync();
-    if (t < kMaxSps) {
-        double acc = 0;
-        if (t < sps) {
-            const int64_t np_ = (n - t) / sps;           // samples phase t owns: j = t + k*sps, k < np_
-            const int64_t lim = t + np_ * (int64_t)sps;  // first j NOT owned
-            const int64_t first = (((int64_t)t - j0) % sps + sps) % sps;  // (j0 + first) % sps == t
-            for (int64_t i = first; i < kPowThreads; i += sps)
-                if (j0 + i >= 0 && j0 + i < lim) acc += cm.lds((int)i);
+    // |z|^2 of kPowSub x kPowThreads samples: independent chains per thread
+#pragma unroll
+    for (int u = 0; u < kPowSub; ++u) {
+        const int blk = wg * kPowSub + u;
+        double sq = 0;
+        if (blk < n_pblk) {
+            const int b = blk / kSub;
+            const int m = (blk % kSub) * kPowThreads + t;
+            const int64_t j = (int64_t)b * Bn + (blk % kSub) * kPowThreads - P.k0L + t;  // may be negative
+            if (j >= 0 && j < n) {
+                double re, im;
+                zp_fixup_at<D>(P, row, b, m, j, re, im);
+                if (z_row) {
+                    z_row[j * 2] = re;
+                    z_row[j * 2 + 1] = im;
+                }
+                const double mg = hypot(re, im);
+                sq = mg * mg;
+            }
         }
-        partials_row[(int64_t)blk * kMaxSps + t] = acc;
+        cm.lds(u * kPowThreads + t) = sq;
+    }
+    cm.sync();
+    // one thread per (power block, phase): the block's samples of that phase, summed in index order
+    const int u = t / kMaxSps, ph = t % kMaxSps;
+    const int blk = wg * kPowSub + u;
+    if (u < kPowSub && blk < n_pblk) {
+        double acc = 0;
+        if (ph < sps) {
+            const int b = blk / kSub;
+            const int64_t j0 = (int64_t)b * Bn + (blk % kSub) * kPowThreads - P.k0L;
+            const int64_t np_ = (n - ph) / sps;            // samples phase ph owns: j = ph + k*sps, k < np_
+            const int64_t lim = ph + np_ * (int64_t)sps;   // first j NOT owned
+            const int64_t first = (((int64_t)ph - j0) % sps + sps) % sps;  // (j0 + first) % sps == ph
+            for (int64_t i = first; i < kPowThreads; i += sps)
+                if (j0 + i >= 0 && j0 + i < lim) acc += cm.lds(u * kPowThreads + (int)i);
+        }
+        partials_row[(int64_t)blk * kMaxSps + ph] = acc;
     }
 }
 
