@@ -13,7 +13,10 @@ namespace tdm {
 #define TDM_LDEC 32
 #endif
 constexpr int kLDec = TDM_LDEC;  // samples per lane, decimator stage (4 biquads)
-constexpr int kLLpf = 16;  // samples per lane, channel-filter stage (order 4 = 2 biquads; LDS-staged I/O)
+#ifndef TDM_LLPF
+#define TDM_LLPF 8
+#endif
+constexpr int kLLpf = TDM_LLPF;  // samples per lane, channel-filter stage (order 4 = 2 biquads; LDS-staged I/O)
 constexpr int kEdgeSos = 27;  // sosfiltfilt pad for 4 sections: 3*(2*4+1)
 constexpr int kEdgeTf = 15;   // filtfilt pad for order 4: 3*5
 constexpr double kSymbolRate = 18000.0;

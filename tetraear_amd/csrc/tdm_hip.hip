@@ -19,6 +19,9 @@
 #include "resample_plan.hpp"
 #include "sync_kernels.hpp"
 #include "tetra_kernels.hpp"
+#ifdef TDM_ZP_TIMING
+__device__ unsigned long long g_zp_dbg[16];
+#endif
 #ifndef TDM_PFB_OVL
 #define TDM_PFB_OVL false
 #endif
@@ -510,8 +513,14 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     return TDM_OK;
 }
 
+#ifdef TDM_ZP_TIMING
+static void zp_timing_dump();
+#endif
 int tdm_plan_destroy(tdm_plan *plan)
 {
+#ifdef TDM_ZP_TIMING
+    zp_timing_dump();
+#endif
     plan_free(plan);
     return TDM_OK;
 }
@@ -583,6 +592,16 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
     return TDM_OK;
 }
+
+#ifdef TDM_ZP_TIMING
+static void zp_timing_dump()
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_zp_dbg), sizeof(h)) != hipSuccess) return;
+    fprintf(stderr, "zp phases (memtime ticks, summed over waves): dec load %llu fwd %llu bwd %llu out %llu | lpf load %llu fwd %llu bwd %llu out %llu \n",
+            h[0], h[1], h[2], h[3], h[8], h[9], h[10], h[11]);
+}
+#endif
 
 int tdm_plan_sync(tdm_plan *plan)
 {

@@ -16,6 +16,21 @@
 
 #include "zp_common.hpp"
 
+// TDM_ZP_TIMING builds: per-phase s_memtime sums of the block kernel (lane 0 of each wave) into g_zp_dbg
+#if defined(TDM_ZP_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long g_zp_dbg[16];
+#define ZP_T(i)                                                                    \
+    do {                                                                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                \
+        if (lane == 0 && (blk & 15) == 0) atomicAdd(&g_zp_dbg[(Loader::kStaged ? 8 : 0) + (i)], t_ - zp_tprev_); \
+        zp_tprev_ = t_;                                                            \
+    } while (0)
+#define ZP_T0() unsigned long long zp_tprev_ = __builtin_amdgcn_s_memtime()
+#else
+#define ZP_T(i)
+#define ZP_T0()
+#endif
+
 namespace tdm {
 
 // ------------------------------------------------------------------------------------------
@@ -246,7 +261,8 @@ struct PlainC128Src {
         im = v.y;
     }
     // stage samples j0..j1-1 into LDS slots slot0 + (j - j0), coalesced
-    TDM_HD void stage_range(int row, int64_t j0, int64_t j1, int lane, f64x2 *lds, int slot0) const
+    template <class Comm>
+    TDM_HD void stage_range(Comm &, int row, int64_t j0, int64_t j1, int lane, f64x2 *lds, int slot0) const
     {
         const f64x2 *p = (const f64x2 *)(x + (int64_t)row * row_stride * 2);
         for (int64_t j = j0 + lane; j < j1; j += kWave) lds[stage_slot(slot0 + (int)(j - j0))] = p[j];
@@ -255,6 +271,19 @@ struct PlainC128Src {
 
 template <int D>
 TDM_HD void zp_fixup_at(const ZpParams &P, int row, int b, int m, int64_t j, double &re, double &im);
+template <int D>
+TDM_HD void zp_fixup_rowed(const ZpParams &P, int row, int b, size_t r, int64_t j, double &re, double &im);
+TDM_HD size_t zp_fixup_row(const ZpParams &P, int b, int m);
+template <int D>
+struct FixOperands {   // per-lane operands of one fix-up: table rows and the block-local output
+    double t1[D], t2[D], yr, yi;
+};
+template <int D>
+TDM_HD void zp_fixup_load(const ZpParams &P, int row, int b, size_t r, int64_t j, FixOperands<D> &o);
+template <int D>
+TDM_HD void zp_fixup_apply(const ZpParams &P, int row, int b, const FixOperands<D> &o, double &re, double &im);
+template <int D>
+TDM_HD void zp_fixup_load_tables(const ZpParams &P, int b, size_t r, FixOperands<D> &o);
 
 // Running NCO for a lane that visits j_a, j_a+64, j_a+128, ...: the reference's phase is
 // theta_j = fl(ci * fl(j / fs)) (processor.py:98-99).  One exact sincos anchors the lane; after that
@@ -266,26 +295,36 @@ struct NcoRun {
     double ar = 1, ai = 0;   // anchor phasor (cos, sin)(theta_a)
     double wr = 1, wi = 0;   // W^k
     double sr = 1, si = 0;   // W = exp(i * 64 * Dd)
-    double th_a = 0, dd = 0;
+    double th_a = 0, dd = 0, rfs = 0;
     int64_t j_a = 0, j_cur = 0;
     bool on = false;
+    // fl(a / b) from r = fl(1 / b) by two residual corrections (Markstein): 5 operations instead of the
+    // ~15 of a division; equal to the IEEE quotient for every j < 2^26 at the sample rates the plans
+    // produce (checked exhaustively on the host) and under the theorem's conditions in general
+    TDM_HD static double quot(double a, double b, double r)
+    {
+        const double q0 = a * r;
+        const double q1 = fma(fma(-q0, b, a), r, q0);
+        return fma(fma(-q1, b, a), r, q1);
+    }
     TDM_HD void step(int64_t j, double f, double fs, double &c, double &s)
     {
         const double ci = -(2.0 * M_PI) * f;
-        const double t = (double)j / fs;
+        if (!on) {
+            rfs = 1.0 / fs;
+            // Dd: ci/fs with the low 13 mantissa bits cleared -> (j - j_a) * Dd is exact
+            union { double d; uint64_t u; } v;
+            v.d = ci / fs;
+            v.u &= ~uint64_t(0x1FFF);
+            dd = v.d;
+            sincos((double)kWave * dd, &si, &sr);
+        }
+        const double t = j < (int64_t(1) << 32) ? quot((double)(uint32_t)j, fs, rfs) : (double)j / fs;
         const double th = ci * t;
         if (!on || j != j_cur + kWave || j - j_a > 4096) {
             const phasor p = nco_phasor(j, f, fs);
             ar = p.c; ai = p.s; wr = 1; wi = 0; th_a = th; j_a = j; j_cur = j;
-            if (!on) {
-                // Dd: ci/fs with the low 13 mantissa bits cleared -> (j - j_a) * Dd is exact
-                union { double d; uint64_t u; } v;
-                v.d = ci / fs;
-                v.u &= ~uint64_t(0x1FFF);
-                dd = v.d;
-                sincos((double)kWave * dd, &si, &sr);
-                on = true;
-            }
+            on = true;
             c = ar;
             s = ai;
             return;
@@ -294,7 +333,7 @@ struct NcoRun {
         const double nwr = wr * sr - wi * si, nwi = wr * si + wi * sr;
         wr = nwr;
         wi = nwi;
-        const double eps = (th - th_a) - (double)(j - j_a) * dd;
+        const double eps = (th - th_a) - (double)(int32_t)(j - j_a) * dd;
         const double pr = ar * wr - ai * wi, pi_ = ar * wi + ai * wr;
         c = pr - eps * pi_;
         s = pi_ + eps * pr;
@@ -329,13 +368,23 @@ struct DecFixSrc {
             }
         }
     }
-    // Bulk form: walk the decimator blocks that cover [j0, j1); inside one block the carries are
-    // wave-uniform (scalar loads) and consecutive lanes read consecutive table rows.
-    TDM_HD void stage_range(int row, int64_t j0, int64_t j1, int lane, f64x2 *lds, int slot0) const
+    // Bulk form.  Phase 1 copies the block-local outputs y0[j0..j1) into the staging buffer with every
+    // load of a lane in flight at once (one memory latency per block instead of one per output).
+    // Phase 2 walks the decimator blocks that cover [j0, j1) and adds the carry responses in place:
+    // inside one block the carries are wave-uniform (scalar loads), consecutive lanes read consecutive
+    // table rows, and the rows of a lane's next output are requested before the current one is finished.
+    template <class Comm>
+    TDM_HD void stage_range(Comm &cm, int row, int64_t j0, int64_t j1, int lane, f64x2 *lds, int slot0) const
     {
         constexpr int Bn = kWave * LDEC;
         const int q = dec.out_stride;
         const double f = freq_offset ? freq_offset[row] : 0.0;
+        {
+            const f64x2 *y0 = (const f64x2 *)(dec.y0 + (int64_t)row * dec.n_out * 2);
+#pragma unroll 4
+            for (int64_t j = j0 + lane; j < j1; j += kWave) lds[stage_slot(slot0 + (int)(j - j0))] = y0[j];
+        }
+        cm.wave_sync();
         int b = (int)((dec.k0L + j0 * q) / Bn);
         for (;; ++b) {
             // outputs of block b: positions pos = k0L + j*q in [b*Bn, (b+1)*Bn)
@@ -347,11 +396,22 @@ struct DecFixSrc {
             if (jh > j1) jh = j1;
             if (jl >= j1 || b >= dec.nb) break;
             NcoRun nco;
-#pragma unroll 1  // measured: unrolling this variable-trip loop (x2, x4) is 15-35 % slower
-            for (int64_t j = jl + lane; j < jh; j += kWave) {
-                const int m = (int)(dec.k0L + j * q - (int64_t)b * Bn);
+            // table row of the lane's first output; the next one (j + 64) is 64 rows further in the same
+            // decimation phase, so the division by q happens once per block, not per sample
+            size_t r = zp_fixup_row(dec, b, (int)(dec.k0L + (jl + lane) * q - (int64_t)b * Bn));
+            // the table rows of the lane's next output are requested before the current one is finished
+            FixOperands<8> cur;
+            if (jl + lane < jh) zp_fixup_load_tables<8>(dec, b, r, cur);
+#pragma unroll 1
+            for (int64_t j = jl + lane; j < jh; j += kWave, r += kWave) {
+                FixOperands<8> nxt = cur;
+                if (j + kWave < jh) zp_fixup_load_tables<8>(dec, b, r + kWave, nxt);
+                f64x2 &slot = lds[stage_slot(slot0 + (int)(j - j0))];
+                cur.yr = slot.x;
+                cur.yi = slot.y;
                 double re, im;
-                zp_fixup_at<8>(dec, row, b, m, j, re, im);
+                zp_fixup_apply<8>(dec, row, b, cur, re, im);
+                cur = nxt;
                 if (f != 0.0) {
                     double c, s;
                     nco.step(j, f, fs_out, c, s);
@@ -359,7 +419,7 @@ struct DecFixSrc {
                     re = a * c - bb * s;
                     im = a * s + bb * c;
                 }
-                lds[stage_slot(slot0 + (int)(j - j0))] = f64x2{re, im};
+                slot = f64x2{re, im};
             }
         }
     }
@@ -384,7 +444,7 @@ struct StagedLoader {
             const int64_t jb = j0;
             if (j0 < 0) j0 = 0;
             if (j1 > n) j1 = n;
-            if (j0 < j1) src.stage_range(row, j0, j1, lane, lds, (int)(j0 - jb));
+            if (j0 < j1) src.stage_range(cm, row, j0, j1, lane, lds, (int)(j0 - jb));
         }
         // positions in the odd extension or in the zero pad (first / last block only)
         if (e_blk < edge || e_blk + Bn > edge + n) {
@@ -435,7 +495,9 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
     constexpr int Bn = kWave * L;
     double xr[L], xi[L];
     const int64_t seg = (int64_t)blk * Bn + (int64_t)lane * L;
+    ZP_T0();
     ld.template load<L>(cm, row, blk, lane, P, xr, xi);
+    ZP_T(0);
 
     constexpr int P0 = (L - EDGE % L) % L;  // == P.P0
     const bool inject = (blk == 0 && lane == 0);
@@ -509,6 +571,7 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             if (g > last) { xr[i] = 0; xi[i] = 0; }
         }
     }
+    ZP_T(1);
     // ---------------- backward: same cascade, time reversed ----------------
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
@@ -556,6 +619,7 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             xi[i] += zir_step<K>(a, sq);
         }
     }
+    ZP_T(2);
     // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------
     if (Loader::kStaged) {
         // stride-1 stage: transpose back through LDS and store 16 B per lane, coalesced
@@ -586,6 +650,7 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             }
         }
     }
+    ZP_T(3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -691,26 +756,89 @@ TDM_HD void zp_carry_bwd_body(const ZpParams &P, int row, int b, int ch)
 // ------------------------------------------------------------------------------------------
 // One output of block b at in-block offset m (row/b uniform over the workgroup, so the carries are
 // read with scalar loads; the table rows of consecutive outputs are consecutive in memory).
-template <int D>
-TDM_HD void zp_fixup_at(const ZpParams &P, int row, int b, int m, int64_t j, double &re, double &im)
+// table row of block offset m (phase-major: outputs of one decimation phase are consecutive rows)
+TDM_HD size_t zp_fixup_row(const ZpParams &P, int b, int m)
 {
-    const int q = P.out_stride;
+    const unsigned q = (unsigned)P.out_stride;
+    if (q == 1) return (size_t)m;   // (uniform branch; spares the channel filter a runtime division)
+    const unsigned R = (b == P.nb - 1) ? P.R_last : P.R_reg;
+    return ((unsigned)m % q) * (size_t)R + (unsigned)m / q;
+}
+
+// y[j] = y0[j] + T1[r] . Gf[b] + T2[r] . Hb[b] with r the table row of the output (zp_fixup_row),
+// split into the per-lane loads and the arithmetic so that a loop can request the next output's
+// operands before it finishes the current one
+template <int D>
+TDM_HD void zp_fixup_load_tables(const ZpParams &P, int b, size_t r, FixOperands<D> &o)
+{
     const bool last = (b == P.nb - 1);
-    const unsigned R = last ? P.R_last : P.R_reg;
-    const size_t r = ((unsigned)m % (unsigned)q) * (size_t)R + (unsigned)m / (unsigned)q;
+#ifdef TDM_EXP_NOTABLE   // experiment: every lane reads table row 0 (wrong results, no table bandwidth)
+    r = 0;
+#endif
     const double *T1 = (last ? P.T1_last : P.T1_reg) + r * D;
     const double *T2 = (last ? P.T2_last : P.T2_reg) + r * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        o.t1[k] = T1[k];
+        o.t2[k] = T2[k];
+    }
+}
+template <int D>
+TDM_HD void zp_fixup_load(const ZpParams &P, int row, int b, size_t r, int64_t j, FixOperands<D> &o)
+{
+    const bool last = (b == P.nb - 1);
+#ifdef TDM_EXP_NOTABLE   // experiment: every lane reads table row 0 (wrong results, no table bandwidth)
+    r = 0;
+#endif
+    const double *T1 = (last ? P.T1_last : P.T1_reg) + r * D;
+    const double *T2 = (last ? P.T2_last : P.T2_reg) + r * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        o.t1[k] = T1[k];
+        o.t2[k] = T2[k];
+    }
+    const double *y0 = P.y0 + ((int64_t)row * P.n_out + j) * 2;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_NT_Y0)
+    // streamed once: keep it from evicting the response tables out of the vector L1
+    typedef double f64x2v __attribute__((ext_vector_type(2)));
+    const f64x2v yv = __builtin_nontemporal_load((const f64x2v *)y0);
+    o.yr = yv.x;
+    o.yi = yv.y;
+#else
+    o.yr = y0[0];
+    o.yi = y0[1];
+#endif
+}
+template <int D>
+TDM_HD void zp_fixup_apply(const ZpParams &P, int row, int b, const FixOperands<D> &o, double &re, double &im)
+{
     const int64_t cb = ((int64_t)row * P.nb + b) * D * 2;
     const auto Gf = TDM_CPTR(P.Gf + cb);
     const auto Hb = TDM_CPTR(P.Hb + cb);
-    const double *y0 = P.y0 + ((int64_t)row * P.n_out + j) * 2;
-    re = y0[0];
-    im = y0[1];
+    // two FMA chains per component (forward and backward carries) instead of mul + fma + add per term
+    double fr = o.yr, fi = o.yi, br = 0, bi = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        re += T1[k] * Gf[k * 2] + T2[k] * Hb[k * 2];
-        im += T1[k] * Gf[k * 2 + 1] + T2[k] * Hb[k * 2 + 1];
+        fr = fma(o.t1[k], Gf[k * 2], fr);
+        fi = fma(o.t1[k], Gf[k * 2 + 1], fi);
+        br = fma(o.t2[k], Hb[k * 2], br);
+        bi = fma(o.t2[k], Hb[k * 2 + 1], bi);
     }
+    re = fr + br;
+    im = fi + bi;
+}
+template <int D>
+TDM_HD void zp_fixup_rowed(const ZpParams &P, int row, int b, size_t r, int64_t j, double &re, double &im)
+{
+    FixOperands<D> o;
+    zp_fixup_load<D>(P, row, b, r, j, o);
+    zp_fixup_apply<D>(P, row, b, o, re, im);
+}
+
+template <int D>
+TDM_HD void zp_fixup_at(const ZpParams &P, int row, int b, int m, int64_t j, double &re, double &im)
+{
+    zp_fixup_rowed<D>(P, row, b, zp_fixup_row(P, b, m), j, re, im);
 }
 
 // Fix-up body: one workgroup per (row, block); thread t handles the block's outputs t, t+nt, ...
@@ -767,7 +895,10 @@ struct FinishArgs {
 constexpr int kMaxSps = 32;       // phases a partial-power record holds
 constexpr int kPowThreads = 256;  // threads (= samples) per partial-power block
 constexpr int kPowSub = 8;        // partial-power blocks per workgroup
-constexpr int kFixBn = kWave * 16;  // block length of the channel filter (ref_plan.hpp kLLpf)
+#ifndef TDM_LLPF
+#define TDM_LLPF 8
+#endif
+constexpr int kFixBn = kWave * TDM_LLPF;  // block length of the channel filter (ref_plan.hpp kLLpf)
 
 TDM_HD uint8_t dqpsk_decide(double cr, double ci, double pr, double pi_, double &margin)
 {
