@@ -62,6 +62,7 @@ struct ZpParams {
     int32_t carry_terms; // series length of the cross-block carries (see zp_kernels.hpp)
     // ---- tables (pointers valid where the kernels run)
     const double *Mpow;     // [nsec][6][K*K]   A_s^(L*2^j), row-major
+    const double *zirh;     // [nsec][L][K]     zero-input response of section s from unit states
     // carry-response tables, one row of D doubles per in-block offset m, stored PHASE-MAJOR:
     // row(m) = (m % out_stride) * R + m / out_stride, so that consecutive outputs (m advancing by
     // out_stride) read consecutive rows.  "reg" = full 64L-sample block, "last" = the last block.

@@ -554,12 +554,24 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (lane == 0) { sr[k] = 0; sq[k] = 0; }
-        // add the zero-input response of the start state (run the section on zero input)
+        // add the zero-input response of the start state
+#ifdef TDM_ZIR_TABLE
+        {   // from the precomputed response of unit states: K FMAs per component with wave-uniform
+            // coefficients (scalar loads) instead of K + 1 operations of the recurrence
+            const auto H = TDM_CPTR(P.zirh + (size_t)s * L * K);
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { xr[i] = fma(H[i * K + k], sr[k], xr[i]); xi[i] = fma(H[i * K + k], sq[k], xi[i]); }
+            }
+        }
+#else
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             xr[i] += zir_step<K>(a, sr);
             xi[i] += zir_step<K>(a, sq);
         }
+#endif
     }
     // positions past the end of the extended signal must not feed the backward pass
     if (blk == P.nb - 1) {
@@ -613,11 +625,25 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (lane == kWave - 1) { sr[k] = 0; sq[k] = 0; }
+#ifdef TDM_ZIR_TABLE
+        {
+            const auto H = TDM_CPTR(P.zirh + (size_t)s * L * K);
+#pragma unroll
+            for (int i = L - 1; i >= 0; --i) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    xr[i] = fma(H[(L - 1 - i) * K + k], sr[k], xr[i]);
+                    xi[i] = fma(H[(L - 1 - i) * K + k], sq[k], xi[i]);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int i = L - 1; i >= 0; --i) {
             xr[i] += zir_step<K>(a, sr);
             xi[i] += zir_step<K>(a, sq);
         }
+#endif
     }
     ZP_T(2);
     // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------

@@ -26,11 +26,11 @@ struct ZpFilterDesc {
 struct ZpHostTables {
     ZpParams p;                // table/work pointers are null until patched by the owner
     std::vector<double> blob;  // all tables, concatenated
-    size_t off_Mpow, off_cflast, off_T1reg, off_T2reg, off_T1last, off_T2last, off_Mf, off_Mblast, off_Ureg, off_Ulast;
+    size_t off_Mpow, off_zirh, off_cflast, off_T1reg, off_T2reg, off_T1last, off_T2last, off_Mf, off_Mblast, off_Ureg, off_Ulast;
     // point p's table pointers into a copy of blob that lives at `base`
     void bind(ZpParams &q, const double *base) const
     {
-        q.Mpow = base + off_Mpow; q.cf_last = base + off_cflast;
+        q.Mpow = base + off_Mpow; q.zirh = base + off_zirh; q.cf_last = base + off_cflast;
         q.T1_reg = base + off_T1reg; q.T2_reg = base + off_T2reg;
         q.T1_last = base + off_T1last; q.T2_last = base + off_T2last; q.Mf = base + off_Mf;
         q.Mb_last = base + off_Mblast; q.U_reg = base + off_Ureg; q.U_last = base + off_Ulast;
@@ -59,6 +59,7 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
     std::vector<double> &blob = t.blob;
     auto reserve = [&](size_t n) { size_t o = blob.size(); blob.resize(o + n, 0.0); return o; };
     t.off_Mpow = reserve((size_t)f.nsec * kScanSteps * K * K);
+    t.off_zirh = reserve((size_t)f.nsec * L * K);
     const int qs = p.out_stride;
     p.R_reg = (Bn + qs - 1) / qs;
     p.R_last = (len_last + qs - 1) / qs;
@@ -87,6 +88,17 @@ inline void build(const ZpFilterDesc &f, ZpHostTables &t)
                 for (int r = 0; r < K; ++r)
                     blob[t.off_Mpow + (((size_t)s * kScanSteps + j) * K + r) * K + k] = (double)z[r];
             }
+        }
+    }
+    // ---- per-section zero-input response: zirh[s][i][k] = output at step i of section s started in state e_k
+    for (int s = 0; s < f.nsec; ++s) {
+        long double b[kMaxOrd + 1], a[kMaxOrd + 1];
+        for (int k = 0; k <= K; ++k) { b[k] = f.b[s][k]; a[k] = f.a[s][k]; }
+        for (int k = 0; k < K; ++k) {
+            long double z[kMaxOrd] = {0, 0, 0, 0};
+            z[k] = 1.0L;
+            for (int i = 0; i < L; ++i)
+                blob[t.off_zirh + ((size_t)s * L + i) * K + k] = (double)df2t_step<K, long double>(b, a, 0.0L, z);
         }
     }
     // ---- whole-cascade tables
