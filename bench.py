@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--mode", default="reference", choices=["reference", "tetra", "pfb", "stream", "wideband"],
                     help="reference = parity mode (the metric); tetra = RRC/timing/Farrow receiver on channelised cf32")
     ap.add_argument("--zero-foff", action="store_true", help="experiment: all freq offsets 0 (NCO skipped)")
+    ap.add_argument("--shared", action="store_true",
+                    help="BASELINE config 3: all carriers read ONE shared wideband stream, each shifted to baseband by its "
+                         "own offset on load (process(frequency_shift(x, f_k)) per carrier)")
     ap.add_argument("--rate", type=float, default=SAMPLE_RATE, help="sample rate (experiments; metric config is 2.4e6)")
     args = ap.parse_args()
 
@@ -143,11 +146,17 @@ def main():
     from tetraear_amd.batch import BatchDemodulator
 
     bd = BatchDemodulator(args.rate, args.chunk, args.carriers, args.fmt, device=local_rank)
-    bd.alloc_device_io()
-    iq, foffs = make_batch(args.carriers, args.chunk, args.fmt, rank)
-    if args.zero_foff:
-        foffs = foffs * 0.0
-    bd.upload(iq, freq_offsets=foffs)
+    bd.alloc_device_io(shared_input=args.shared)
+    if args.shared:
+        iq, foffs = make_batch(1, args.chunk, args.fmt, rank)
+        foffs = np.zeros(args.carriers)
+        pre = (np.arange(args.carriers) - (args.carriers - 1) / 2.0) * 25000.0 * (64.0 / max(args.carriers, 64))
+        bd.upload(iq, freq_offsets=None, pre_shifts=pre)
+    else:
+        iq, foffs = make_batch(args.carriers, args.chunk, args.fmt, rank)
+        if args.zero_foff:
+            foffs = foffs * 0.0
+        bd.upload(iq, freq_offsets=foffs)
 
     def barrier():
         bd.sync()
@@ -197,8 +206,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.carriers} independent 25 kHz carriers per GPU, "
-                                   f"{args.chunk}-sample {args.fmt} chunks @2.4 MS/s (SURVEY 8(d) C4 per-GPU share)",
+            "config": {"workload": (f"{args.carriers} carriers shifted out of ONE shared {args.chunk}-sample {args.fmt} stream "
+                                    f"@2.4 MS/s (SURVEY 8(d) C3)") if args.shared else
+                                   (f"{args.carriers} independent 25 kHz carriers per GPU, "
+                                    f"{args.chunk}-sample {args.fmt} chunks @2.4 MS/s (SURVEY 8(d) C4 per-GPU share)"),
                        "carriers_per_gpu": args.carriers, "chunk_samples": args.chunk, "in_fmt": args.fmt,
                        "mode": "reference", "parallelism": f"carriers sharded over {world} GPU(s), no data-path collective"},
             "realtime_carriers": value * 1e6 / sym_rate_per_carrier,

@@ -453,7 +453,8 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
 {
     if (!out) return fail(TDM_ERR_INVALID, "out is null");
     *out = nullptr;
-    if (!(sample_rate > 0) || n_samples < 1 || n_carriers < 1 || n_carriers > 65535 || in_fmt < 0 || in_fmt > 3)
+    if (!(sample_rate > 0) || n_samples < 1 || n_samples > (int64_t(1) << 31) || n_carriers < 1 || n_carriers > 65535 ||
+        in_fmt < 0 || in_fmt > 3)
         return fail(TDM_ERR_INVALID, "bad sample_rate / n_samples / n_carriers (1..65535) / in_fmt");
     if (mode != TDM_MODE_REFERENCE && mode != TDM_MODE_TETRA) return fail(TDM_ERR_INVALID, "bad mode");
     int rc = use_device(device);

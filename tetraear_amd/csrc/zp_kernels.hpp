@@ -84,6 +84,63 @@ TDM_HD void nco_rotate(double &re, double &im, int64_t k, double f, double fs)
     im = a * p.s + b * p.c;
 }
 
+// Running NCO for a lane that visits j_a, j_a+64, j_a+128, ...: the reference's phase is
+// theta_j = fl(ci * fl(j / fs)) (processor.py:98-99).  One exact sincos anchors the lane; after that
+// exp(i theta_j) = A * W^k * (1 + i eps_j), W = exp(i 64 Dd) advanced by complex multiplication and
+// eps_j = (theta_j - theta_a) - (j - j_a) Dd, computed exactly (Dd has 40 significant bits so the
+// product is exact; the difference of neighbouring thetas is exact), |eps| ~ 1e-11 so eps^2 drops.
+// This reproduces the reference's own rounding of theta_j, not an idealised phase ramp.
+template <int STRIDE>
+struct NcoRunT {
+    double ar = 1, ai = 0;   // anchor phasor (cos, sin)(theta_a)
+    double wr = 1, wi = 0;   // W^k
+    double sr = 1, si = 0;   // W = exp(i * STRIDE * Dd)
+    double th_a = 0, dd = 0, rfs = 0;
+    int64_t j_a = 0, j_cur = 0;
+    bool on = false;
+    // fl(a / b) from r = fl(1 / b) by two residual corrections (Markstein): 5 operations instead of the
+    // ~15 of a division; equal to the IEEE quotient for every j < 2^26 at the sample rates the plans
+    // produce (checked exhaustively on the host) and under the theorem's conditions in general
+    TDM_HD static double quot(double a, double b, double r)
+    {
+        const double q0 = a * r;
+        const double q1 = fma(fma(-q0, b, a), r, q0);
+        return fma(fma(-q1, b, a), r, q1);
+    }
+    TDM_HD void step(int64_t j, double f, double fs, double &c, double &s)
+    {
+        const double ci = -(2.0 * M_PI) * f;
+        if (!on) {
+            rfs = 1.0 / fs;
+            // Dd: ci/fs with the low 13 mantissa bits cleared -> (j - j_a) * Dd is exact
+            union { double d; uint64_t u; } v;
+            v.d = ci / fs;
+            v.u &= ~uint64_t(0x1FFF);
+            dd = v.d;
+            sincos((double)STRIDE * dd, &si, &sr);
+        }
+        const double t = quot((double)(uint32_t)j, fs, rfs);   // j < 2^32: tdm_plan_create bounds the chunk length
+        const double th = ci * t;
+        if (!on || j != j_cur + STRIDE || j - j_a > 4096) {
+            const phasor p = nco_phasor(j, f, fs);
+            ar = p.c; ai = p.s; wr = 1; wi = 0; th_a = th; j_a = j; j_cur = j;
+            on = true;
+            c = ar;
+            s = ai;
+            return;
+        }
+        j_cur = j;
+        const double nwr = wr * sr - wi * si, nwi = wr * si + wi * sr;
+        wr = nwr;
+        wi = nwi;
+        const double eps = (th - th_a) - (double)(int32_t)(j - j_a) * dd;
+        const double pr = ar * wr - ai * wi, pi_ = ar * wi + ai * wr;
+        c = pr - eps * pi_;
+        s = pi_ + eps * pr;
+    }
+};
+typedef NcoRunT<kWave> NcoRun;   // a lane of the staged loader visits j, j + 64, j + 128, ...
+
 // ------------------------------------------------------------------------------------------
 // Loaders: give a lane its L consecutive samples of the padded, odd-extended signal.
 // ------------------------------------------------------------------------------------------
@@ -175,8 +232,20 @@ struct RawLoader {
             for (int i = 0; i < L; ++i) convert_one<FMT>(rowp, k + i, xr[i], xi[i]);
         }
         if (SHIFT && f != 0.0) {
+            // frequency_shift of the shared stream (processor.py:85-100) with a running phasor over the
+            // lane's consecutive samples: one exact sincos per lane and block instead of one per sample
+            NcoRunT<1> nco;
 #pragma unroll
-            for (int i = 0; i < L; ++i) nco_rotate(xr[i], xi[i], k + i, f, fs);
+            for (int i = 0; i < L; ++i) {
+                double c, sn;
+                nco.step(k + i, f, fs, c, sn);
+                const double a = xr[i], b = xi[i];
+                xr[i] = a * c - b * sn;
+                xi[i] = a * sn + b * c;
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);   // keep the 32 steps from being interleaved (register pressure)
+#endif
+            }
         }
     }
 
@@ -285,60 +354,6 @@ TDM_HD void zp_fixup_apply(const ZpParams &P, int row, int b, const FixOperands<
 template <int D>
 TDM_HD void zp_fixup_load_tables(const ZpParams &P, int b, size_t r, FixOperands<D> &o);
 
-// Running NCO for a lane that visits j_a, j_a+64, j_a+128, ...: the reference's phase is
-// theta_j = fl(ci * fl(j / fs)) (processor.py:98-99).  One exact sincos anchors the lane; after that
-// exp(i theta_j) = A * W^k * (1 + i eps_j), W = exp(i 64 Dd) advanced by complex multiplication and
-// eps_j = (theta_j - theta_a) - (j - j_a) Dd, computed exactly (Dd has 40 significant bits so the
-// product is exact; the difference of neighbouring thetas is exact), |eps| ~ 1e-11 so eps^2 drops.
-// This reproduces the reference's own rounding of theta_j, not an idealised phase ramp.
-struct NcoRun {
-    double ar = 1, ai = 0;   // anchor phasor (cos, sin)(theta_a)
-    double wr = 1, wi = 0;   // W^k
-    double sr = 1, si = 0;   // W = exp(i * 64 * Dd)
-    double th_a = 0, dd = 0, rfs = 0;
-    int64_t j_a = 0, j_cur = 0;
-    bool on = false;
-    // fl(a / b) from r = fl(1 / b) by two residual corrections (Markstein): 5 operations instead of the
-    // ~15 of a division; equal to the IEEE quotient for every j < 2^26 at the sample rates the plans
-    // produce (checked exhaustively on the host) and under the theorem's conditions in general
-    TDM_HD static double quot(double a, double b, double r)
-    {
-        const double q0 = a * r;
-        const double q1 = fma(fma(-q0, b, a), r, q0);
-        return fma(fma(-q1, b, a), r, q1);
-    }
-    TDM_HD void step(int64_t j, double f, double fs, double &c, double &s)
-    {
-        const double ci = -(2.0 * M_PI) * f;
-        if (!on) {
-            rfs = 1.0 / fs;
-            // Dd: ci/fs with the low 13 mantissa bits cleared -> (j - j_a) * Dd is exact
-            union { double d; uint64_t u; } v;
-            v.d = ci / fs;
-            v.u &= ~uint64_t(0x1FFF);
-            dd = v.d;
-            sincos((double)kWave * dd, &si, &sr);
-        }
-        const double t = j < (int64_t(1) << 32) ? quot((double)(uint32_t)j, fs, rfs) : (double)j / fs;
-        const double th = ci * t;
-        if (!on || j != j_cur + kWave || j - j_a > 4096) {
-            const phasor p = nco_phasor(j, f, fs);
-            ar = p.c; ai = p.s; wr = 1; wi = 0; th_a = th; j_a = j; j_cur = j;
-            on = true;
-            c = ar;
-            s = ai;
-            return;
-        }
-        j_cur = j;
-        const double nwr = wr * sr - wi * si, nwi = wr * si + wi * sr;
-        wr = nwr;
-        wi = nwi;
-        const double eps = (th - th_a) - (double)(int32_t)(j - j_a) * dd;
-        const double pr = ar * wr - ai * wi, pi_ = ar * wi + ai * wr;
-        c = pr - eps * pi_;
-        s = pi_ + eps * pr;
-    }
-};
 
 // decimator output finished on the fly: block-local y0 + carry responses, then process()'s
 // freq_offset NCO (processor.py:260-261) -- the former separate fix-up pass, fused into the load

@@ -21,5 +21,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tetra -o tetr
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_fetch -o fetch -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_write -o write -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_write.err
 python bench.py --carriers 1 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_single.json 2> /dev/null
+python bench.py --shared --carriers 64 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_shared64.json 2> /dev/null
+python bench.py --mode wideband --carriers 12800 --steps 10 --warmup 2 > $OUT/bench_wideband.json 2> /dev/null
 python bench.py --carriers 256 --fmt cf64 --no-cpu-baseline > $OUT/bench_cf64_256.json 2> /dev/null
 tail -c 300 $OUT/bench_tetra.json; echo; tail -c 200 $OUT/bench_single.json
