@@ -207,9 +207,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": (f"{args.carriers} carriers shifted out of ONE shared {args.chunk}-sample {args.fmt} stream "
-                                    f"@2.4 MS/s (SURVEY 8(d) C3)") if args.shared else
+                                    f"@{args.rate / 1e6:g} MS/s (SURVEY 8(d) C3)") if args.shared else
                                    (f"{args.carriers} independent 25 kHz carriers per GPU, "
-                                    f"{args.chunk}-sample {args.fmt} chunks @2.4 MS/s (SURVEY 8(d) C4 per-GPU share)"),
+                                    f"{args.chunk}-sample {args.fmt} chunks @{args.rate / 1e6:g} MS/s (SURVEY 8(d) C4 per-GPU share)"),
                        "carriers_per_gpu": args.carriers, "chunk_samples": args.chunk, "in_fmt": args.fmt,
                        "mode": "reference", "parallelism": f"carriers sharded over {world} GPU(s), no data-path collective"},
             "realtime_carriers": value * 1e6 / sym_rate_per_carrier,

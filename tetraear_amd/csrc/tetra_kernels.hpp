@@ -184,12 +184,25 @@ __device__ __forceinline__ float block_min(float v, float *sm)
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// cubic Lagrange (Farrow) interpolation at position t (1 <= t <= n-3)
-__device__ __forceinline__ float2 farrow_at(const float2 *y, double t)
+// cubic Lagrange (Farrow) interpolation at position t (1 <= t <= n-3), split into the four loads and
+// the arithmetic so that a thread can have the loads of several symbols in flight
+struct FarrowTaps {
+    float2 ym1, y0, y1, y2;
+    float mu;
+};
+__device__ __forceinline__ void farrow_load(const float2 *y, double t, FarrowTaps &f)
 {
     const int m = (int)floor(t);
-    const float mu = (float)(t - (double)m);
-    const float2 ym1 = y[m - 1], y0 = y[m], y1 = y[m + 1], y2 = y[m + 2];
+    f.mu = (float)(t - (double)m);
+    f.ym1 = y[m - 1];
+    f.y0 = y[m];
+    f.y1 = y[m + 1];
+    f.y2 = y[m + 2];
+}
+__device__ __forceinline__ float2 farrow_eval(const FarrowTaps &f)
+{
+    const float2 ym1 = f.ym1, y0 = f.y0, y1 = f.y1, y2 = f.y2;
+    const float mu = f.mu;
     float2 r;
     {
         const float c1 = y1.x - ym1.x * (1.f / 3.f) - y0.x * 0.5f - y2.x * (1.f / 6.f);
@@ -204,6 +217,12 @@ __device__ __forceinline__ float2 farrow_at(const float2 *y, double t)
         r.y = ((c3 * mu + c2) * mu + c1) * mu + y0.y;
     }
     return r;
+}
+__device__ __forceinline__ float2 farrow_at(const float2 *y, double t)
+{
+    FarrowTaps f;
+    farrow_load(y, t, f);
+    return farrow_eval(f);
 }
 
 // piecewise-linear timing estimate at sample position pos (sub-block centres at (b+0.5)*TB)
@@ -220,9 +239,11 @@ __device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
     return (float)((double)tau[b0] * (1.0 - f) + (double)tau[b0 + 1] * f);
 }
 
+constexpr int kSymUnroll = 8;   // symbols per thread whose loads are in flight together
+
 __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restrict__ y,
                                                             const float2 *__restrict__ tstat, const TetraParams P,
-                                                            float2 *__restrict__ soft, uint8_t *hard,
+                                                            float2 *__restrict__ soft, uint8_t *__restrict__ hard,
                                                             int32_t *n_soft, int32_t *timing_milli, double *min_margin)
 {
     __shared__ float Cr[kMaxTimingBlocks + 1], Ci[kMaxTimingBlocks + 1];  // later: prefix sums
@@ -244,15 +265,29 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
         Ci[b + 1] = c.y;
     }
     __syncthreads();
-    // 2. prefix sums, vector average over +-TW sub-blocks, arg, unwrap (<= 512 terms: one thread)
+    // 2. prefix sums (one thread), vector average over +-TW sub-blocks and its argument (one thread per
+    //    sub-block), unwrap (one thread: a short chain of roundings)
     if (tid == 0) {
         Cr[0] = 0.f; Ci[0] = 0.f;
-        for (int b = 1; b <= nb; ++b) { Cr[b] += Cr[b - 1]; Ci[b] += Ci[b - 1]; }
+        float ar = 0.f, ai = 0.f;
+        for (int b = 1; b <= nb; ++b) {
+            ar += Cr[b];
+            ai += Ci[b];
+            Cr[b] = ar;
+            Ci[b] = ai;
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += kSymThreads) {
+        const int hi = min(nb, b + kTimingHalfWin + 1), lo = max(0, b - kTimingHalfWin);
+        const float cr = Cr[hi] - Cr[lo], ci = Ci[hi] - Ci[lo];
+        tau[b] = -atan2f(ci, cr) * 0.15915494309189535f;  // / (2 pi)
+    }
+    __syncthreads();
+    if (tid == 0) {
         float prev = 0.f;
         for (int b = 0; b < nb; ++b) {
-            const int hi = min(nb, b + kTimingHalfWin + 1), lo = max(0, b - kTimingHalfWin);
-            const float cr = Cr[hi] - Cr[lo], ci = Ci[hi] - Ci[lo];
-            float tb = -atan2f(ci, cr) * 0.15915494309189535f;  // / (2 pi)
+            float tb = tau[b];
             if (b > 0) tb += rintf(prev - tb);
             tau[b] = tb;
             prev = tb;
@@ -270,23 +305,47 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
     }
     __syncthreads();
     const int k_lo = k_lo_s, ns = n_sym_s;
-    // 3. interpolate the matched-filter output at the symbol instants
-    for (int i = tid; i < ns; i += kSymThreads) {
-        const int k = k_lo + i;
-        const double t = ((double)k + (double)tau_at(tau, nb, (double)k * sps)) * sps;
-        const float2 s = farrow_at(yr, t);
-        sr[i] = s;
+    // 3. interpolate the matched-filter output at the symbol instants (kSymUnroll symbols per thread with
+    //    all their loads in flight: the loops of this kernel are bound by memory latency, not bandwidth)
+    constexpr int U = kSymUnroll;
+    for (int i0 = tid; i0 < ns; i0 += kSymThreads * U) {
+        FarrowTaps f[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kSymThreads;
+            if (i < ns) {
+                const int k = k_lo + i;
+                const double t = ((double)k + (double)tau_at(tau, nb, (double)k * sps)) * sps;
+                farrow_load(yr, t, f[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kSymThreads;
+            if (i < ns) sr[i] = farrow_eval(f[u]);
+        }
     }
     __syncthreads();
-    // 4. differential products and the 4th-power carrier-offset estimate
+    // 4. differential products and the 4th-power carrier-offset estimate (per-thread sums in index order)
     float a4r = 0.f, a4i = 0.f;
-    for (int i = 1 + tid; i < ns; i += kSymThreads) {
-        const float2 c = sr[i], p = sr[i - 1];
-        const float2 d = make_float2(c.x * p.x + c.y * p.y, c.y * p.x - c.x * p.y);
-        const float2 d2 = cmulf(d, d);
-        const float2 d4 = cmulf(d2, d2);
-        a4r += d4.x;
-        a4i += d4.y;
+    for (int i0 = 1 + tid; i0 < ns; i0 += kSymThreads * U) {
+        float2 c[U], p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kSymThreads;
+            if (i < ns) { c[u] = sr[i]; p[u] = sr[i - 1]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kSymThreads;
+            if (i < ns) {
+                const float2 d = make_float2(c[u].x * p[u].x + c[u].y * p[u].y, c[u].y * p[u].x - c[u].x * p[u].y);
+                const float2 d2 = cmulf(d, d);
+                const float2 d4 = cmulf(d2, d2);
+                a4r += d4.x;
+                a4i += d4.y;
+            }
+        }
     }
     a4r = block_sum(a4r, sm);
     a4i = block_sum(a4i, sm);
@@ -296,15 +355,26 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
     sincosf(-delta_s, &rs, &rc);
     // 5. quadrant decision of d_k exp(-i delta): +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3
     float margin = 3.4e38f;
-    for (int i = 1 + tid; i < ns; i += kSymThreads) {
-        const float2 c = sr[i], p = sr[i - 1];
-        const float2 d = make_float2(c.x * p.x + c.y * p.y, c.y * p.x - c.x * p.y);
-        const float2 dd = make_float2(d.x * rc - d.y * rs, d.x * rs + d.y * rc);
-        const uint8_t h = dd.y >= 0.f ? (dd.x >= 0.f ? 0 : 1) : (dd.x >= 0.f ? 2 : 3);
-        hard[(int64_t)row * P.max_soft + i - 1] = h;
-        // angular distance to the nearest decision boundary (an axis)
-        const float ang = atan2f(fabsf(dd.y), fabsf(dd.x));      // 0 .. pi/2
-        margin = fminf(margin, fminf(ang, 1.5707963267948966f - ang));
+    for (int i0 = 1 + tid; i0 < ns; i0 += kSymThreads * U) {
+        float2 c[U], p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kSymThreads;
+            if (i < ns) { c[u] = sr[i]; p[u] = sr[i - 1]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kSymThreads;
+            if (i < ns) {
+                const float2 d = make_float2(c[u].x * p[u].x + c[u].y * p[u].y, c[u].y * p[u].x - c[u].x * p[u].y);
+                const float2 dd = make_float2(d.x * rc - d.y * rs, d.x * rs + d.y * rc);
+                const uint8_t h = dd.y >= 0.f ? (dd.x >= 0.f ? 0 : 1) : (dd.x >= 0.f ? 2 : 3);
+                hard[(int64_t)row * P.max_soft + i - 1] = h;
+                // angular distance to the nearest decision boundary (an axis)
+                const float ang = atan2f(fabsf(dd.y), fabsf(dd.x));      // 0 .. pi/2
+                margin = fminf(margin, fminf(ang, 1.5707963267948966f - ang));
+            }
+        }
     }
     margin = block_min(margin, sm);
     if (tid == 0) {
