@@ -20,6 +20,9 @@ python bench.py --mode pfb --carriers 12800 --steps 20 --warmup 3 > $OUT/bench_p
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tetra -o tetra -- python bench.py --mode tetra --carriers 4096 --steps 5 --warmup 2 > /dev/null 2> $OUT/trace_tetra.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_fetch -o fetch -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_write -o write -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pfb -o pfb -- python bench.py --mode pfb --carriers 12800 --steps 5 --warmup 2 > /dev/null 2> $OUT/trace_pfb.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pfb_fetch -o fetch -- python bench.py --mode pfb --carriers 12800 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_pfb_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pfb_write -o write -- python bench.py --mode pfb --carriers 12800 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_pfb_write.err
 python bench.py --carriers 1 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_single.json 2> /dev/null
 python bench.py --shared --carriers 64 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_shared64.json 2> /dev/null
 python bench.py --mode wideband --carriers 12800 --steps 10 --warmup 2 > $OUT/bench_wideband.json 2> /dev/null
