@@ -497,6 +497,52 @@ struct StagedLoader {
     }
 };
 
+// Zero-input response from the table of unit-state responses, four positions (8 table doubles, one
+// s_load_dwordx16) at a time.  Each chunk's pointer passes through an empty asm so that the compiler
+// cannot hoist all the loads to the top of the kernel (it then spills hundreds of SGPRs); the pointer of
+// chunk c + 1 is made before chunk c is used, which lets its load overlap chunk c's arithmetic.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TDM_OPAQUE_SPTR(p) asm volatile("" : "+s"(p))
+#else
+#define TDM_OPAQUE_SPTR(p)
+#endif
+#ifndef TDM_ZIR_CHUNK
+#define TDM_ZIR_CHUNK 2   // positions per scalar load (2 coefficients each)
+#endif
+template <int K, int L, bool REV>
+TDM_HD void zir_from_table(const double *tab, const double *sr, const double *sq, double *xr, double *xi)
+{
+    constexpr int CP = TDM_ZIR_CHUNK, CD = CP * 2;
+    static_assert(K == 2 && L % CP == 0, "chunks of whole positions of a biquad");
+    constexpr int NCH = L / CP;
+    const double *p0 = tab;
+    TDM_OPAQUE_SPTR(p0);
+    double h[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) h[k] = TDM_CPTR(p0)[k];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        double hn[CD];
+        if (c + 1 < NCH) {
+            const double *p1 = tab + (c + 1) * CD;
+            TDM_OPAQUE_SPTR(p1);
+#pragma unroll
+            for (int k = 0; k < CD; ++k) hn[k] = TDM_CPTR(p1)[k];
+        }
+#pragma unroll
+        for (int t = 0; t < CP; ++t) {
+            const int pos = c * CP + t;
+            const int i = REV ? L - 1 - pos : pos;
+            xr[i] = fma(h[t * 2], sr[0], fma(h[t * 2 + 1], sr[1], xr[i]));
+            xi[i] = fma(h[t * 2], sq[0], fma(h[t * 2 + 1], sq[1], xi[i]));
+        }
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int k = 0; k < CD; ++k) h[k] = hn[k];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Block kernel body: one wavefront filters one block forward then backward.
 //   Comm: stage() -> workgroup LDS of StageGeom<L>::kDoubles doubles (staged loaders only),
@@ -571,15 +617,7 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             if (lane == 0) { sr[k] = 0; sq[k] = 0; }
         // add the zero-input response of the start state
 #ifdef TDM_ZIR_TABLE
-        {   // from the precomputed response of unit states: K FMAs per component with wave-uniform
-            // coefficients (scalar loads) instead of K + 1 operations of the recurrence
-            const auto H = TDM_CPTR(P.zirh + (size_t)s * L * K);
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) { xr[i] = fma(H[i * K + k], sr[k], xr[i]); xi[i] = fma(H[i * K + k], sq[k], xi[i]); }
-            }
-        }
+        zir_from_table<K, L, false>(P.zirh + (size_t)s * L * K, sr, sq, xr, xi);
 #else
 #pragma unroll
         for (int i = 0; i < L; ++i) {
@@ -641,17 +679,7 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
         for (int k = 0; k < K; ++k)
             if (lane == kWave - 1) { sr[k] = 0; sq[k] = 0; }
 #ifdef TDM_ZIR_TABLE
-        {
-            const auto H = TDM_CPTR(P.zirh + (size_t)s * L * K);
-#pragma unroll
-            for (int i = L - 1; i >= 0; --i) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    xr[i] = fma(H[(L - 1 - i) * K + k], sr[k], xr[i]);
-                    xi[i] = fma(H[(L - 1 - i) * K + k], sq[k], xi[i]);
-                }
-            }
-        }
+        zir_from_table<K, L, true>(P.zirh + (size_t)s * L * K, sr, sq, xr, xi);
 #else
 #pragma unroll
         for (int i = L - 1; i >= 0; --i) {
