@@ -182,15 +182,13 @@ struct PfbUnit<2> {
             __builtin_memcpy(&b, p + 1, 16);
             ok = 15u;
         } else {
-            float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int c = 0; c < 4; ++c)
-                if (n0 + c >= 0 && n0 + c < n_in) {
-                    const float2 v = ((const float2 *)base)[n0 + c];
-                    t[2 * c] = v.x;
-                    t[2 * c + 1] = v.y;
-                }
-            a = make_float4(t[0], t[1], t[2], t[3]);
-            b = make_float4(t[4], t[5], t[6], t[7]);
+            float2 t0 = make_float2(0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
+            if (n0 >= 0 && n0 < n_in) t0 = ((const float2 *)base)[n0];
+            if (n0 + 1 >= 0 && n0 + 1 < n_in) t1 = ((const float2 *)base)[n0 + 1];
+            if (n0 + 2 >= 0 && n0 + 2 < n_in) t2 = ((const float2 *)base)[n0 + 2];
+            if (n0 + 3 >= 0 && n0 + 3 < n_in) t3 = ((const float2 *)base)[n0 + 3];
+            a = make_float4(t0.x, t0.y, t1.x, t1.y);
+            b = make_float4(t2.x, t2.y, t3.x, t3.y);
             ok = 15u;   // zeros already in place
         }
     }
@@ -212,14 +210,16 @@ struct PfbUnit {   // cu8 (FMT 0) / cs8 (FMT 1): 8 bytes
             ok = 15u;
         } else {
             ok = 0;
-            uint32_t w[2] = {0u, 0u};
+            uint32_t w0 = 0u, w1 = 0u;
+#pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (n0 + c >= 0 && n0 + c < n_in) {
                     const uint32_t h = ((const uint16_t *)base)[n0 + c];
-                    w[c >> 1] |= h << (16 * (c & 1));
+                    if (c < 2) w0 |= h << (16 * (c & 1));
+                    else w1 |= h << (16 * (c & 1));
                     ok |= 1u << c;
                 }
-            v = make_uint2(w[0], w[1]);
+            v = make_uint2(w0, w1);
         }
     }
     __device__ __forceinline__ static cf32v conv(uint32_t h)   // low 16 bits: I, Q
@@ -229,15 +229,16 @@ struct PfbUnit {   // cu8 (FMT 0) / cs8 (FMT 1): 8 bytes
     }
     __device__ __forceinline__ void store(cf32v *dst) const
     {
-        cf32v s[4] = {conv(v.x), conv(v.x >> 16), conv(v.y), conv(v.y >> 16)};
+        cf32v s0 = conv(v.x), s1 = conv(v.x >> 16), s2 = conv(v.y), s3 = conv(v.y >> 16);
         if (ok != 15u) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (!((ok >> c) & 1u)) s[c] = cv(0.f, 0.f);
+            if (!(ok & 1u)) s0 = cv(0.f, 0.f);
+            if (!(ok & 2u)) s1 = cv(0.f, 0.f);
+            if (!(ok & 4u)) s2 = cv(0.f, 0.f);
+            if (!(ok & 8u)) s3 = cv(0.f, 0.f);
         }
         float4 lo, hi;
-        lo.x = s[0].x; lo.y = s[0].y; lo.z = s[1].x; lo.w = s[1].y;
-        hi.x = s[2].x; hi.y = s[2].y; hi.z = s[3].x; hi.w = s[3].y;
+        lo.x = s0.x; lo.y = s0.y; lo.z = s1.x; lo.w = s1.y;
+        hi.x = s2.x; hi.y = s2.y; hi.z = s3.x; hi.w = s3.y;
         ((float4 *)dst)[0] = lo;
         ((float4 *)dst)[1] = hi;
     }
@@ -250,42 +251,114 @@ template <int M1, int M2>
 struct PfbFftGeom {
     static constexpr int FS = (M1 * M2) | 1;      // odd stride between output times of the exchange tile
 };
-// LDS footprint in float2 elements
-template <int M1, int M2, int P, int TB, bool OVL>
+// LDS footprint in float2 elements: input window + exchange tile + middle twiddles
+template <int M1, int M2, int P, int TB>
 constexpr size_t pfb_fft_lds(int D)
 {
     const size_t xs = ((size_t)(TB - 1) * D + (size_t)M1 * M2 * P + 3) / 4 * 4;
-    const size_t A = (size_t)TB * PfbFftGeom<M1, M2>::FS;
-    return (OVL ? (xs > A ? xs : A) : xs + A) + (size_t)M1 * M2;   // + middle twiddles
+    return xs + (size_t)TB * PfbFftGeom<M1, M2>::FS + (size_t)M1 * M2;
+}
+
+// ---- the three compute phases of a round (TB output times), shared by the kernel variants ----
+// stage A: item = tid + it*NT -> (group of 4 output times, branch r).  All LDS reads of an item come
+// before its writes (window and tile live in the same LDS array, so the compiler keeps their order);
+// the opaque copy of tid keeps the per-item address arithmetic inside the round instead of hoisted
+// into spilled registers.
+template <int M1, int M2, int P, int TB>
+__device__ __forceinline__ void pfb_stage_a(const cf32v *xs, cf32v *A, const float (*hv)[P], int tid, int D, int dmod, int s0)
+{
+    constexpr int M = M1 * M2, L = M * P, NT = TB * M2, FS = PfbFftGeom<M1, M2>::FS, FG = 4, NI = M1 / 4;
+    int tid_v = tid;
+    asm volatile("" : "+v"(tid_v));
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int item = tid_v + it * NT;
+        const int f = (item / M) * FG, r = item - (item / M) * M;
+        const cf32v *px = xs + f * D + (L - 1) - r;
+        cf32v acc[FG];
+#pragma unroll
+        for (int j = 0; j < FG; ++j) {
+            acc[j] = px[j * D] * hv[it][0];
+#pragma unroll
+            for (int p = 1; p < P; ++p) acc[j] += px[j * D - p * M] * hv[it][p];
+        }
+        int sft = (int)(((uint32_t)s0 + (uint32_t)f * (uint32_t)dmod) % (uint32_t)M);
+        cf32v *pa = A + f * FS;
+#pragma unroll
+        for (int j = 0; j < FG; ++j) {
+            int rp = r - sft;   // branch r lands at (r - shift) mod M of output time f + j
+            rp += rp < 0 ? M : 0;
+            pa[j * FS + rp] = acc[j];
+            sft += dmod;
+            sft -= sft >= M ? M : 0;
+        }
+    }
+}
+// pass 1, in place: thread (mi, n2) owns column n2 of its output time
+template <int M1, int M2>
+__device__ __forceinline__ void pfb_pass1(cf32v *A, const cf32v *wml, int mi, int n2)
+{
+    cf32v x[M1];
+    cf32v *col = A + mi * PfbFftGeom<M1, M2>::FS + n2;
+#pragma unroll
+    for (int n1 = 0; n1 < M1; ++n1) x[n1] = col[n1 * M2];
+    SmallDft<M1>::run(x);
+#pragma unroll
+    for (int k1 = 0; k1 < M1; ++k1) col[k1 * M2] = cmulv(x[k1], wml[k1 * M2 + n2]);
+}
+// pass 2: thread (k1b, mib) transforms row k1b of output time mib and stores channels k1b + M1*k2
+template <int M1, int M2>
+__device__ __forceinline__ void pfb_pass2(const cf32v *A, cf32v *out, int64_t out_stride, int64_t m0, int64_t n_out,
+                                          int k1b, int mib)
+{
+    cf32v a[M2];
+    const cf32v *row = A + mib * PfbFftGeom<M1, M2>::FS + k1b * M2;
+#pragma unroll
+    for (int j = 0; j < M2; ++j) a[j] = row[j];
+    SmallDft<M2>::run(a);
+    const int64_t m = m0 + mib;
+    if (m < n_out) {
+        cf32v *po = out + (int64_t)k1b * out_stride + m;
+        const int64_t step = (int64_t)M1 * out_stride;
+#pragma unroll
+        for (int k2 = 0; k2 < M2; ++k2) {
+#if TDM_PFB_STORE >= 2
+            __builtin_nontemporal_store(a[k2], po);
+#elif TDM_PFB_STORE == 1
+            *po = a[k2];
+#else
+            if (a[k2].x == 1.2345e30f) *po = a[k2];   // experiment: no output traffic
+#endif
+            po += step;
+        }
+    }
 }
 
 // NPF: 4-sample units per thread held in registers for the next round; WGS: workgroups per CU aimed at
-template <int M1, int M2, int P, int TB, int FMT, bool OVL, int NPF, int WGS>
+template <int M1, int M2, int P, int TB, int FMT, int NPF, int WGS>
 __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb_fft(
     const void *__restrict__ iq_, cf32v *__restrict__ out_, int64_t out_stride, const PfbParams Q)
 {
     static_assert(M1 <= M2, "pass 2 uses the first TB*M1 threads");
     static_assert(TB % 4 == 0 && M1 % 4 == 0, "stage A: M1/4 items of four output times per thread");
     constexpr int M = M1 * M2, L = M * P, NT = TB * M2;
-    constexpr int FS = PfbFftGeom<M1, M2>::FS;
-    constexpr int FG = 4, NI = M1 / 4;   // M*(TB/FG) items over NT threads
+    constexpr int NI = M1 / 4;   // M*(TB/4) items over NT threads
     extern __shared__ cf32v smem_v[];
     const int D = Q.D;
     const int nxs = (TB - 1) * D + L;
     const int nu = (nxs + 3) >> 2;
     const int dmod = D % M;
-    cf32v *xs = smem_v;                              // [4*nu]
-    cf32v *A = OVL ? smem_v : smem_v + 4 * nu;       // [TB][FS]: row k1 (or n1) of an output time at k1*M2
-    cf32v *wml = smem_v + (pfb_fft_lds<M1, M2, P, TB, OVL>(D) - M);   // [M1][M2] middle twiddles
-    // (in LDS rather than re-read from memory: vmcnt retires in order, so a global load issued after
+    cf32v *xs = smem_v;              // [4*nu]
+    cf32v *A = smem_v + 4 * nu;      // [TB][FS]: row k1 (or n1) of an output time at k1*M2
+    cf32v *wml = smem_v + (pfb_fft_lds<M1, M2, P, TB>(D) - M);   // [M1][M2] middle twiddles
+    // (in LDS rather than re-read from memory: loads and stores share vmcnt, so a global load issued after
     //  pass 2's stores would wait for their write acknowledgements)
     const char *iq = (const char *)iq_ + (int64_t)blockIdx.y * Q.in_stride;
     cf32v *out = out_ + (int64_t)blockIdx.y * Q.out_batch;
     const int tid = threadIdx.x;
     const int mi = tid / M2, n2 = tid - mi * M2;
     const int k1b = tid / TB, mib = tid - k1b * TB;
-    // stage-A items of this thread (the same in every round): item = tid + it*NT -> (group of 4 times, branch r)
-    float hv[NI][P];
+    float hv[NI][P];   // taps of this thread's stage-A branches (the same in every round)
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
         const int item = tid + it * NT;
@@ -309,7 +382,7 @@ __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb
 #ifdef TDM_PFB_TIMING
         unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
-        if (OVL || g == 0) {
+        if (g == 0) {
 #pragma unroll
             for (int k = 0; k < NPF; ++k)
                 if (tid + k * NT < nu) pf[k].store(xs + 4 * (tid + k * NT));
@@ -327,123 +400,29 @@ __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb
             for (int k = 0; k < NPF; ++k)
                 if (tid + k * NT < nu) pf[k].load(iq, nbase + (int64_t)TB * D + 4 * (int64_t)(tid + k * NT), Q.n_in);
         }
-        // ---- stage A (all LDS reads of an item before its writes: both live in the same LDS array,
-        //      so the compiler keeps their order; the opaque copy of tid keeps the per-item address
-        //      arithmetic inside the round instead of hoisted into spilled registers)
-        int tid_v = tid;
-        asm volatile("" : "+v"(tid_v));
-        const int s0 = (int)((m0 * (int64_t)D) % M);   // uniform: shift of the round's first output time
-        cf32v acc[NI][FG];
-#pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            const int item = tid_v + it * NT;
-            const int f = (item / M) * FG, r = item - (item / M) * M;
-            const cf32v *px = xs + f * D + (L - 1) - r;
-#pragma unroll
-            for (int j = 0; j < FG; ++j) {
-                acc[it][j] = px[j * D] * hv[it][0];
-#pragma unroll
-                for (int p = 1; p < P; ++p) acc[it][j] += px[j * D - p * M] * hv[it][p];
-            }
-            if constexpr (!OVL) {
-                int sft = (int)(((uint32_t)s0 + (uint32_t)f * (uint32_t)dmod) % (uint32_t)M);
-                cf32v *pa = A + f * FS;
-#pragma unroll
-                for (int j = 0; j < FG; ++j) {
-                    int rp = r - sft;
-                    rp += rp < 0 ? M : 0;
-                    pa[j * FS + rp] = acc[it][j];
-                    sft += dmod;
-                    sft -= sft >= M ? M : 0;
-                }
-            }
-        }
-        if constexpr (OVL) {
-            __syncthreads();   // every read of the window is done: the tile may overwrite it
-#pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const int item = tid_v + it * NT;
-                const int f = (item / M) * FG, r = item - (item / M) * M;
-                int sft = (int)(((uint32_t)s0 + (uint32_t)f * (uint32_t)dmod) % (uint32_t)M);
-                cf32v *pa = A + f * FS;
-#pragma unroll
-                for (int j = 0; j < FG; ++j) {
-                    int rp = r - sft;
-                    rp += rp < 0 ? M : 0;
-                    pa[j * FS + rp] = acc[it][j];
-                    sft += dmod;
-                    sft -= sft >= M ? M : 0;
-                }
-            }
-        }
+        pfb_stage_a<M1, M2, P, TB>(xs, A, hv, tid, D, dmod, (int)((m0 * (int64_t)D) % M));
         PFB_T(2);
         __syncthreads();
         PFB_T(3);
-        // ---- pass 1 (in place: a thread owns column n2 of its output time)
-        {
-            cf32v x[M1];
-            cf32v *col = A + mi * FS + n2;
-#pragma unroll
-            for (int n1 = 0; n1 < M1; ++n1) x[n1] = col[n1 * M2];
-            SmallDft<M1>::run(x);
-#pragma unroll
-            for (int k1 = 0; k1 < M1; ++k1) col[k1 * M2] = cmulv(x[k1], wml[k1 * M2 + n2]);
-        }
+        pfb_pass1<M1, M2>(A, wml, mi, n2);
         PFB_T(4);
         __syncthreads();
         PFB_T(5);
-        if constexpr (!OVL) {
-            // The next round's window lands in LDS here (start of pass 2), BEFORE this round's stores are issued: loads
-            // and stores share vmcnt and retire out of order with respect to each other, so waiting for
-            // a load while stores are in flight means waiting for every store acknowledgement.
-            if (g + 1 < Q.G) {
+        // The next round's window lands in LDS here, BEFORE this round's stores are issued: loads and stores
+        // share vmcnt and retire out of order with respect to each other, so waiting for a load while
+        // stores are in flight means waiting for every store acknowledgement.
+        if (g + 1 < Q.G) {
 #pragma unroll
-                for (int k = 0; k < NPF; ++k)
-                    if (tid + k * NT < nu) pf[k].store(xs + 4 * (tid + k * NT));
-                for (int u = tid + NPF * NT; u < nu; u += NT) {
-                    PfbUnit<FMT> t;
-                    t.load(iq, nbase + (int64_t)TB * D + 4 * (int64_t)u, Q.n_in);
-                    t.store(xs + 4 * u);
-                }
+            for (int k = 0; k < NPF; ++k)
+                if (tid + k * NT < nu) pf[k].store(xs + 4 * (tid + k * NT));
+            for (int u = tid + NPF * NT; u < nu; u += NT) {
+                PfbUnit<FMT> t;
+                t.load(iq, nbase + (int64_t)TB * D + 4 * (int64_t)u, Q.n_in);
+                t.store(xs + 4 * u);
             }
         }
         PFB_T(8);
-        // ---- pass 2
-        cf32v a[M2];
-        const bool act2 = tid < TB * M1;
-        if (act2) {
-            const cf32v *row = A + mib * FS + k1b * M2;
-#pragma unroll
-            for (int j = 0; j < M2; ++j) a[j] = row[j];
-        }
-        if constexpr (OVL) {
-            if (g + 1 < Q.G) __syncthreads();   // tile consumed: the next round's window may land on it
-        }
-        PFB_T(7);
-        if (act2) {
-            SmallDft<M2>::run(a);
-            const int64_t m = m0 + mib;
-            if (m < Q.n_out) {
-#if TDM_PFB_STORE == 3   // experiment: contiguous 512 B per wave-instruction (wrong layout)
-                cf32v *po = out + ((int64_t)(blockIdx.x * Q.G + g) * (NT / 64) + tid / 64) * (M2 * 64) + (tid & 63);
-                const int64_t step = 64;
-#else
-                cf32v *po = out + (int64_t)k1b * out_stride + m;
-                const int64_t step = (int64_t)M1 * out_stride;
-#endif
-#pragma unroll
-                for (int k2 = 0; k2 < M2; ++k2) {
-#if TDM_PFB_STORE >= 2
-                    __builtin_nontemporal_store(a[k2], po);
-#elif TDM_PFB_STORE == 1
-                    *po = a[k2];
-#else
-                    if (a[k2].x == 1.2345e30f) *po = a[k2];
-#endif
-                    po += step;
-                }
-            }
-        }
+        if (tid < TB * M1) pfb_pass2<M1, M2>(A, out, out_stride, m0, Q.n_out, k1b, mib);
         PFB_T(6);
     }
 }

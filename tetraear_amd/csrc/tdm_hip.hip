@@ -22,9 +22,6 @@
 #ifdef TDM_ZP_TIMING
 __device__ unsigned long long g_zp_dbg[16];
 #endif
-#ifndef TDM_PFB_OVL
-#define TDM_PFB_OVL false
-#endif
 #include "pfb_kernels.hpp"
 #include "gate_kernels.hpp"
 #include "detect_kernels.hpp"
@@ -1177,7 +1174,7 @@ struct PfbTables {
 static std::mutex g_pfb_mu;
 static std::map<std::tuple<int, int, int, int>, PfbTables> g_pfb_cache;  // (device, M1, M2, D) -> tables (kept)
 
-template <int M1, int M2, int P, int TB, int WGS, bool kOvl>
+template <int M1, int M2, int P, int TB, int WGS>
 int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 *out, int64_t n_out, int64_t pitch,
                int n_streams, hipStream_t st, bool sync)
 {
@@ -1230,15 +1227,18 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
         const int64_t rounds = (n_out + TB - 1) / TB;
         Q.G = (int)std::min<int64_t>(8, std::max<int64_t>(1, rounds * n_streams / 2048));
         if (const char *e = std::getenv("TDM_PFB_G")) Q.G = std::max(1, std::atoi(e));   // experiments
-        const size_t lds = pfb_fft_lds<M1, M2, P, TB, kOvl>(D) * sizeof(float2);
+        const size_t lds = pfb_fft_lds<M1, M2, P, TB>(D) * sizeof(float2);
         if (lds <= 160 * 1024) {
             void (*kern)(const void *, cf32v *, int64_t, const PfbParams) = nullptr;
             const int nu = ((TB - 1) * D + L + 3) / 4;
-            const bool one = nu <= TB * M2;   // one prefetched unit per thread covers the window
-            switch (fmt) {
-            case TDM_CU8: kern = one ? k_pfb_fft<M1, M2, P, TB, 0, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 0, kOvl, 2, WGS>; break;
-            case TDM_CS8: kern = one ? k_pfb_fft<M1, M2, P, TB, 1, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 1, kOvl, 2, WGS>; break;
-            default: kern = one ? k_pfb_fft<M1, M2, P, TB, 2, kOvl, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 2, kOvl, 2, WGS>; break;
+            const unsigned threads = TB * M2;
+            {
+                const bool one = nu <= TB * M2;   // one prefetched unit per thread covers the window
+                switch (fmt) {
+                case TDM_CU8: kern = one ? k_pfb_fft<M1, M2, P, TB, 0, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 0, 2, WGS>; break;
+                case TDM_CS8: kern = one ? k_pfb_fft<M1, M2, P, TB, 1, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 1, 2, WGS>; break;
+                default: kern = one ? k_pfb_fft<M1, M2, P, TB, 2, 1, WGS> : k_pfb_fft<M1, M2, P, TB, 2, 2, WGS>; break;
+                }
             }
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const unsigned blocks = (unsigned)((rounds + Q.G - 1) / Q.G);
@@ -1248,7 +1248,7 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
             HIP_TRY(hipMemset(dbg, 0, 128));
             Q.dbg = dbg;
 #endif
-            hipLaunchKernelGGL(kern, dim3(blocks, n_streams), dim3(TB * M2), lds, st, iq, (cf32v *)out, pitch, Q);
+            hipLaunchKernelGGL(kern, dim3(blocks, n_streams), dim3(threads), lds, st, iq, (cf32v *)out, pitch, Q);
             HIP_TRY(hipGetLastError());
 #ifdef TDM_PFB_TIMING
             {
@@ -1304,16 +1304,11 @@ int tdm_channelise_batch(const void *iq, int32_t in_fmt, int64_t n_in, int32_t n
     const bool sync = !device_pointers;
     switch (M) {
     // device pointers: enqueue on the default stream and return (tdm_dev_sync waits)
-    case 96: rc = launch_pfb<8, 12, 3, 24, 3, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 72: rc = launch_pfb<8, 9, 3, 48, 2, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 80: rc = launch_pfb<8, 10, 3, 32, 3, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 128: rc = launch_pfb<8, 16, 3, 16, 4, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 400:
-        if (std::getenv("TDM_PFB_TB16"))
-            rc = launch_pfb<20, 20, 3, 16, (TDM_PFB_OVL ? 3 : 2), TDM_PFB_OVL>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync);
-        else
-            rc = launch_pfb<20, 20, 3, 32, 1, false>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync);
-        break;
+    case 96: rc = launch_pfb<8, 12, 3, 24, 3>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 72: rc = launch_pfb<8, 9, 3, 48, 2>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 80: rc = launch_pfb<8, 10, 3, 32, 3>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 128: rc = launch_pfb<8, 16, 3, 16, 4>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 400: rc = launch_pfb<20, 20, 3, 32, 1>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
     default: return fail(TDM_ERR_UNSUPPORTED, "channeliser built for M in {72, 80, 96, 128, 400}");
     }
     if (rc) return rc;
