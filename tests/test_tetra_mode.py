@@ -190,3 +190,35 @@ def test_gpu_pitched_rows_and_odd_chunk_lengths():
             np.testing.assert_array_equal(soft[r, :n_soft[r]], s0[r])
             assert best_ber(h0[r], make_signal(n, fs, 900 + r, 0.1 * r, 30.0 * r, 20.0)[1], edge=8)[0] == 0.0
         dense.close()
+
+
+@pytest.mark.gpu
+def test_gpu_wideband_receiver_device_chain():
+    """WidebandReceiver: channeliser output handed to the TETRA-mode plan on the device (pitched rows, two
+    streams per launch); every occupied channel gives back its transmitted dibits, and the result equals
+    the host-chained path (channelise -> BatchDemodulator)."""
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    from tetraear_amd.channeliser import channelise
+    from tetraear_amd.wideband import WidebandReceiver
+    M, D, fs, n = 96, 32, 2.4e6, 65536
+    ks = [[0, 5, 47, 90], [3, 49, 95]]
+    xs, dibs = [], []
+    for si, kk in enumerate(ks):
+        x, d = _wideband(n, fs, kk, M, seed0=500 + 20 * si)
+        xs.append((x / 6).astype(np.complex64))
+        dibs.append(d)
+    rx = WidebandReceiver(fs, n, M, D, streams=2, fmt="cf32")
+    hard, n_sym, timing, margin = rx.process(np.concatenate(xs))
+    for si, kk in enumerate(ks):
+        y = channelise(xs[si], "cf32", M, D)
+        bd = BatchDemodulator(fs / D, y.shape[1], len(kk), "cf32", mode=MODE_TETRA)
+        hards, _, _, _ = bd.process(np.ascontiguousarray(y[kk]))
+        bd.close()
+        for i, k in enumerate(kk):
+            got = hard[si, k, :n_sym[si, k]]
+            np.testing.assert_array_equal(got, hards[i])
+            ber, lag = best_ber(got, dibs[si][k], edge=8)
+            assert n_sym[si, k] > 400 and ber == 0.0, (si, k, ber, lag)
+    assert rx.channel_frequency(95) == -fs / M
+    rx.close()

@@ -1,0 +1,62 @@
+"""Wideband receiver: polyphase channeliser -> TETRA-mode demodulation of every channel, with the
+channelised samples handed over on the device (pitched rows, no host round trip).
+
+BASELINE config 5 (10 MS/s -> 400 x 25 kHz carriers) and config 3's tetra-mode counterpart
+(2.4 MS/s -> 96 channels).  No counterpart in the reference: defined by
+oracle/pfb_np.py and oracle/tetra_np.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FMT_BYTES, MODE_TETRA, check
+from .batch import BatchDemodulator, DeviceBuffer
+from .channeliser import aligned_pitch
+
+_FMT_OF = {"cu8": 0, "cs8": 1, "cf32": 2}
+
+
+class WidebandReceiver:
+    """`streams` wideband streams of `n_in` samples at `sample_rate` -> M channels each, spaced
+    sample_rate/M and decimated by D (channel rate sample_rate/D), all demodulated per call."""
+
+    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0):
+        self.lib = _lib.load()
+        self.fmt = _FMT_OF[fmt]
+        self.device = device
+        self.sample_rate, self.n_in, self.M, self.D, self.streams = float(sample_rate), int(n_in), int(M), int(D), int(streams)
+        self.n_out = (self.n_in + self.D - 1) // self.D
+        self.pitch = aligned_pitch(self.n_out)
+        self.d_in = DeviceBuffer(device, self.streams * self.n_in * FMT_BYTES[self.fmt])
+        self.d_ch = DeviceBuffer(device, self.streams * self.M * self.pitch * 8)
+        self.demod = BatchDemodulator(self.sample_rate / self.D, self.n_out, self.streams * self.M, "cf32",
+                                      device=device, mode=MODE_TETRA)
+        self.demod.alloc_device_io()
+
+    def process(self, iq):
+        """iq: the streams back to back in the plan's wire format.  Returns (hard, n_sym, timing, margin):
+        hard uint8 [streams][M][max_sym] with n_sym [streams][M] valid symbols per channel."""
+        iq = np.ascontiguousarray(iq)
+        if iq.nbytes != self.d_in.nbytes:
+            raise ValueError(f"iq holds {iq.nbytes} bytes, receiver needs {self.d_in.nbytes}")
+        self.d_in.upload(iq)
+        no = C.c_int64()
+        check(self.lib.tdm_channelise_batch(self.d_in.ptr, self.fmt, self.n_in, self.streams, self.M, self.D,
+                                            self.d_ch.ptr, self.pitch, C.byref(no), 1, self.device))
+        check(self.lib.tdm_dev_sync(self.device))      # channeliser: default stream; demodulator: the plan's stream
+        self.demod.enqueue(iq_ptr=self.d_ch.ptr, stride=self.pitch)
+        self.demod.sync()
+        hard, soft, n_soft, timing, margin = self.demod.download()
+        shape = (self.streams, self.M)
+        n_sym = np.maximum(n_soft - 1, 0).reshape(shape)
+        return hard.reshape(shape + (-1,)), n_sym, timing.reshape(shape), margin.reshape(shape)
+
+    def channel_frequency(self, k):
+        """centre frequency of channel k relative to the stream's centre [Hz]"""
+        return (k if k < self.M // 2 else k - self.M) * self.sample_rate / self.M
+
+    def close(self):
+        self.demod.close()
+        self.d_in.free()
+        self.d_ch.free()
