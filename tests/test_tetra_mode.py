@@ -146,6 +146,22 @@ def test_gpu_channeliser_batch_and_general_decimation():
 
 
 @pytest.mark.gpu
+def test_gpu_channeliser_direct_kernel_agrees(monkeypatch):
+    """the general fallback kernel (direct small DFTs; taken when a window exceeds LDS) against the
+    register-FFT kernel on the same input"""
+    from tetraear_amd.channeliser import channelise
+    for M, D, fs, n in ((400, 125, 10e6, 7000), (96, 32, 2.4e6, 5000)):
+        x, _ = _wideband(n, fs, [1, M // 3, M - 2], M, seed0=700)
+        x32 = (x / 4).astype(np.complex64)
+        monkeypatch.delenv("TDM_PFB_DIRECT", raising=False)
+        y_fft = channelise(x32, "cf32", M, D)
+        monkeypatch.setenv("TDM_PFB_DIRECT", "1")
+        y_dir = channelise(x32, "cf32", M, D)
+        monkeypatch.delenv("TDM_PFB_DIRECT", raising=False)
+        assert np.max(np.abs(y_fft - y_dir)) < 2e-5 * np.max(np.abs(y_dir))
+
+
+@pytest.mark.gpu
 def test_gpu_wideband_to_symbols():
     """2.4 MS/s wideband -> 96-channel filter bank (75 kS/s per channel) -> TETRA-mode demodulation;
     every occupied channel must give back the transmitted dibits."""

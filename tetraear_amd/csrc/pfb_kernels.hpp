@@ -16,9 +16,6 @@
 
 #include "small_dft.hpp"
 
-#ifndef TDM_PFB_STORE
-#define TDM_PFB_STORE 2
-#endif
 
 namespace tdm {
 
@@ -322,13 +319,7 @@ __device__ __forceinline__ void pfb_pass2(const cf32v *A, cf32v *out, int64_t ou
         const int64_t step = (int64_t)M1 * out_stride;
 #pragma unroll
         for (int k2 = 0; k2 < M2; ++k2) {
-#if TDM_PFB_STORE >= 2
             __builtin_nontemporal_store(a[k2], po);
-#elif TDM_PFB_STORE == 1
-            *po = a[k2];
-#else
-            if (a[k2].x == 1.2345e30f) *po = a[k2];   // experiment: no output traffic
-#endif
             po += step;
         }
     }

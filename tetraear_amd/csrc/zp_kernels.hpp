@@ -841,9 +841,6 @@ template <int D>
 TDM_HD void zp_fixup_load_tables(const ZpParams &P, int b, size_t r, FixOperands<D> &o)
 {
     const bool last = (b == P.nb - 1);
-#ifdef TDM_EXP_NOTABLE   // experiment: every lane reads table row 0 (wrong results, no table bandwidth)
-    r = 0;
-#endif
     const double *T1 = (last ? P.T1_last : P.T1_reg) + r * D;
     const double *T2 = (last ? P.T2_last : P.T2_reg) + r * D;
 #pragma unroll
@@ -856,9 +853,6 @@ template <int D>
 TDM_HD void zp_fixup_load(const ZpParams &P, int row, int b, size_t r, int64_t j, FixOperands<D> &o)
 {
     const bool last = (b == P.nb - 1);
-#ifdef TDM_EXP_NOTABLE   // experiment: every lane reads table row 0 (wrong results, no table bandwidth)
-    r = 0;
-#endif
     const double *T1 = (last ? P.T1_last : P.T1_reg) + r * D;
     const double *T2 = (last ? P.T2_last : P.T2_reg) + r * D;
 #pragma unroll
@@ -867,7 +861,7 @@ TDM_HD void zp_fixup_load(const ZpParams &P, int row, int b, size_t r, int64_t j
         o.t2[k] = T2[k];
     }
     const double *y0 = P.y0 + ((int64_t)row * P.n_out + j) * 2;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_NT_Y0)
+#if defined(__HIP_DEVICE_COMPILE__)
     // streamed once: keep it from evicting the response tables out of the vector L1
     typedef double f64x2v __attribute__((ext_vector_type(2)));
     const f64x2v yv = __builtin_nontemporal_load((const f64x2v *)y0);
