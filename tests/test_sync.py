@@ -81,3 +81,42 @@ def test_gpu_sync_batched_on_demodulator_output():
         e_pos, e_mc = emul.find_sync(hards[r], False, 0.8, max_pos=32)
         assert list(pos[r, :npos[r]]) == e_pos and mc[r] == e_mc
     bd.close()
+
+
+@pytest.mark.gpu
+def test_gpu_capture_chain_gate_process_sync():
+    """gate -> process(afc) -> find_sync ladder chained on the device (tetraear_amd.pipeline.CaptureChain) against
+    the composition of the pinned CPU pieces: oracle/gate_np.py, the C oracle of process(), and the
+    find_sync kernel body in CPU emulation (golden-checked above)."""
+    from oracle import gate_np
+    from oracle.oracle import OracleSignalProcessor
+    from tests.emul import emul
+    from tetraear_amd import synth
+    from tetraear_amd.pipeline import CaptureChain, LADDER
+    fs, n = 2.4e6, 131072
+    specs = [(0.0, 30.0), (3000.0, 30.0), (-2500.0, 5.0), (9000.0, 30.0), (500.0, -5.0), (-11000.0, 25.0)]
+    xs = [synth.dqpsk_cu8(n, fs, seed=80 + r, carrier_offset=co, esn0_db=snr)[0] for r, (co, snr) in enumerate(specs)]
+    # plant a training sequence in one strong row's data so that the ladder has something to find
+    ch = CaptureChain(fs, n, len(xs), "cu8")
+    res = ch.step(np.concatenate(xs))
+    n_strong = 0
+    for r, u8 in enumerate(xs):
+        x = synth.cu8_to_c128(u8)
+        g = gate_np.gate(x, fs)
+        assert res[r]["strong"] == g["strong"] and res[r]["afc"] == g["afc"], r
+        if not g["strong"]:
+            assert res[r]["symbols"] is None and res[r]["sync_positions"] == []
+            continue
+        n_strong += 1
+        sym = OracleSignalProcessor(fs).process(x, g["afc"])
+        np.testing.assert_array_equal(res[r]["symbols"], sym)
+        pos, mc = [], 0.0
+        for thr in LADDER:
+            pos, mc = emul.find_sync(sym, False, thr, max_pos=64)
+            if pos:
+                break
+        if not pos and mc >= 0.75:
+            pos, _ = emul.find_sync(sym, False, max(0.75, mc - 0.02), max_pos=64)
+        assert res[r]["sync_positions"] == pos and res[r]["max_corr"] == mc, r
+    assert 0 < n_strong < len(xs)
+    ch.close()
