@@ -705,10 +705,25 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             if (j >= 0 && j < P.n_out) y0[j] = lds[stage_slot(s)];
         }
     } else {
-        const int64_t rel0 = seg - P.k0L;
+        // first output of the lane's segment, without a per-lane 64-bit division: the block's first output
+        // (uniform; exact in double, the quotient is far below 2^53) and a small per-lane quotient (< Bn / q)
         const int q = P.out_stride;
-        int64_t j = rel0 <= 0 ? 0 : (rel0 + q - 1) / q;
-        int64_t next = j * q - rel0;  // position inside this segment
+        const int64_t blk_rel = (int64_t)blk * Bn - P.k0L;   // block start relative to output 0
+        int64_t jb = 0;
+        int64_t o0 = -blk_rel;                                // position of output jb inside the block
+        if (blk_rel > 0) {
+            jb = (int64_t)floor((double)(blk_rel + q - 1) / (double)q);
+            o0 = jb * q - blk_rel;
+        }
+        const int64_t x = (int64_t)lane * L - o0;             // outputs of this lane: t >= ceil(x / q)
+        int t0 = 0;
+        if (x > 0) {
+            t0 = (int)((float)(x + q - 1) / (float)q);
+            if ((int64_t)t0 * q < x) ++t0;                    // (the float quotient is off by at most one)
+            if ((int64_t)(t0 - 1) * q >= x) --t0;
+        }
+        int64_t j = jb + t0;
+        int64_t next = o0 + (int64_t)t0 * q - (int64_t)lane * L;  // position inside this segment
         double *y0 = P.y0 + (int64_t)row * P.n_out * 2;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
