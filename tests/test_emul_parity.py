@@ -137,3 +137,28 @@ def test_small_dft_templates_match_numpy(n):
         x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
         ref = np.fft.ifft(x.astype(np.complex128)) * n
         assert np.max(np.abs(emul.small_dft(x) - ref)) < 4e-7 * np.max(np.abs(ref)) * np.sqrt(n)
+
+
+def test_emul_random_lengths_and_rates_vs_oracle():
+    """Block-boundary coverage: seeded random chunk lengths (incl. lengths around multiples of the block sizes
+    and the fall-back thresholds 27 / 15), sample rates and AFC offsets; kernel bodies in CPU emulation against
+    the C oracle.  (tools/sweep_emul.py / tools/sweep_gpu.py run the same sweep open-ended: 350 CPU and 19 291
+    GPU cases without a mismatch in round 1.)"""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    rng = np.random.default_rng(2026)
+    rates = [2.4e6, 2.4e6, 1.8e6, 2.048e6, 960000.0, 480000.0, 240000.0, 72000.0]
+    specials = [27, 28, 150, 160, 161, 5119, 5120, 5121, 5271, 10240, 20473, 20480, 20481, 2048, 4097, 6144]
+    for it in range(36):
+        fs = rates[rng.integers(len(rates))]
+        n = int(specials[it % len(specials)]) if it % 2 == 0 else int(rng.integers(1, 12000))
+        f = 0.0 if it % 3 == 0 else float(rng.uniform(-8000, 8000))
+        u8 = synth.noise_cu8(n, 9000 + it)
+        ref = OracleSignalProcessor(fs)
+        r = ref.process(synth.cu8_to_c128(u8), f)
+        hard, soft, n_soft, bp, mm = emul.process(fs, u8, "cu8", n, 1, freq_offset=np.array([f]))
+        ns = int(n_soft[0])
+        assert ns == len(ref.symbols), (fs, n, f)
+        np.testing.assert_array_equal(hard[0, :max(ns - 1, 0)], r)
+        if ns:
+            assert np.max(np.abs(soft[0, :ns] - ref.symbols)) <= 1e-10 * (np.max(np.abs(ref.symbols)) or 1.0), (fs, n, f)

@@ -285,3 +285,29 @@ def test_recorded_file_ingest_pipelined(tmp_path):
         hi = lo + 2 * (chunk if i < n_chunks else tail)
         ref = OracleSignalProcessor(2.4e6).process(synth.cu8_to_c128(u8[lo:hi]), 1171.875)
         np.testing.assert_array_equal(outs[i], ref)
+
+
+@pytest.mark.gpu
+def test_random_lengths_and_rates_vs_oracle():
+    """seeded random chunk lengths (1 .. 300 000, plus lengths around block multiples and the fall-back
+    thresholds), sample rates incl. 10 MS/s (q = 41) and AFC offsets: process_cu8 against the C oracle"""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    from tetraear_amd.signal.processor import SignalProcessor
+    rng = np.random.default_rng(77)
+    rates = [2.4e6, 2.4e6, 1.8e6, 2.048e6, 960000.0, 480000.0, 240000.0, 72000.0, 3.2e6, 10e6]
+    specials = [27, 28, 29, 150, 161, 5119, 5120, 5121, 20480, 20481, 6144, 131071, 131072, 262145]
+    procs = {}
+    for it in range(120):
+        fs = rates[rng.integers(len(rates))]
+        n = int(specials[it % len(specials)]) if it % 3 == 0 else int(rng.integers(1, 300000 if it % 10 == 1 else 40000))
+        f = 0.0 if it % 4 == 0 else float(rng.uniform(-8000, 8000))
+        u8 = synth.noise_cu8(n, 12000 + it)
+        ref = OracleSignalProcessor(fs)
+        r = ref.process(synth.cu8_to_c128(u8), f)
+        p = procs.setdefault(fs, SignalProcessor(fs))
+        h = p.process_cu8(u8, freq_offset=f)
+        np.testing.assert_array_equal(h, r)
+        assert len(p.symbols) == len(ref.symbols), (fs, n, f)
+        if len(ref.symbols):
+            assert np.max(np.abs(p.symbols - ref.symbols)) <= 1e-10 * (np.max(np.abs(ref.symbols)) or 1.0), (fs, n, f)
