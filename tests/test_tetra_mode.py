@@ -238,3 +238,35 @@ def test_gpu_wideband_receiver_device_chain():
             assert n_sym[si, k] > 400 and ber == 0.0, (si, k, ber, lag)
     assert rx.channel_frequency(95) == -fs / M
     rx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_channeliser_random_configurations():
+    """seeded random (M, D, length, wire format, pitch): channeliser vs the fp64 definition on probe channels
+    (tools/sweep_pfb.py runs the same sweep open-ended: 76 115 cases without a mismatch in round 1)"""
+    from oracle import pfb_np
+    from tetraear_amd.channeliser import channelise_batch
+    rng = np.random.default_rng(11)
+    for it in range(250):
+        M = int(rng.choice([72, 80, 96, 128, 400]))
+        D = int(rng.integers(max(2, M // 8), M + 1)) if it % 2 else int(rng.choice([M // 4, M // 3, M // 2]))
+        n = int(rng.integers(1, 9000))
+        fmt = ["cf32", "cu8", "cs8"][it % 3]
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.2
+        if fmt == "cf32":
+            raw = x.astype(np.complex64)
+            xd = raw.astype(np.complex128)
+        elif fmt == "cu8":
+            raw = synth.quantise_cu8(x, scale=1.0)
+            xd = synth.cu8_to_c128(raw)
+        else:
+            q = np.clip(np.round(np.stack([x.real, x.imag], -1) * 128), -128, 127).astype(np.int8)
+            raw = q.reshape(-1)
+            xd = (q[:, 0].astype(np.float64) + 1j * q[:, 1].astype(np.float64)) / 128.0
+        pitch = 0 if it % 4 < 2 else ((n + D - 1) // D + 15) // 16 * 16
+        y = channelise_batch(raw, fmt, 1, M, D, pitch=pitch)[0]
+        probe = sorted(set(int(k) for k in rng.integers(0, M, 4)) | {0, M - 1})
+        ref = pfb_np.channelise(xd, M, D, channels=probe)
+        sc = max(np.max(np.abs(ref)), 1e-30)
+        for i, k in enumerate(probe):
+            assert np.max(np.abs(y[k] - ref[i])) < 2e-5 * sc, (M, D, n, fmt, pitch, k)
