@@ -233,7 +233,7 @@ def main():
                         "peak = MI355X fp64 vector FMA rate; the HBM view of the same launch is under 'hbm'",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.chunk)
             try:
                 out["cpu_baseline_allcore"] = cpu_baseline_allcore(args.chunk)
