@@ -110,8 +110,8 @@ def cpu_baseline_allcore(chunk, budget_s=5.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--carriers", type=int, default=1024, help="carriers per GPU (SURVEY 8(d) C4: 1024)")
     ap.add_argument("--chunk", type=int, default=262144, help="samples per carrier per step")
     ap.add_argument("--fmt", default="cu8", choices=["cu8", "cf32", "cf64"])
