@@ -867,14 +867,7 @@ TDM_HD void zp_fixup_load_tables(const ZpParams &P, int b, size_t r, FixOperands
 template <int D>
 TDM_HD void zp_fixup_load(const ZpParams &P, int row, int b, size_t r, int64_t j, FixOperands<D> &o)
 {
-    const bool last = (b == P.nb - 1);
-    const double *T1 = (last ? P.T1_last : P.T1_reg) + r * D;
-    const double *T2 = (last ? P.T2_last : P.T2_reg) + r * D;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        o.t1[k] = T1[k];
-        o.t2[k] = T2[k];
-    }
+    zp_fixup_load_tables<D>(P, b, r, o);
     const double *y0 = P.y0 + ((int64_t)row * P.n_out + j) * 2;
 #if defined(__HIP_DEVICE_COMPILE__)
     // streamed once: keep it from evicting the response tables out of the vector L1
