@@ -8,14 +8,13 @@
 //   stage A  polyphase branch sums v, written circularly shifted (u)
 //   stage B  M-point DFT as M1 x M2 Cooley-Tukey
 // Output layout [M][n_out] cf32 (channel-major), which is the [carriers][n] input of TETRA mode.
-// Two kernels: k_pfb_fft (register-resident mixed-radix small DFTs, per-thread constant branch
-// set; needs M | TB*D) and k_pfb (direct small DFTs, any D) as the general fallback.
+// Two kernels: k_pfb_fft (register-resident mixed-radix small DFTs, any D whose input window fits
+// LDS) and k_pfb (direct small DFTs, T chosen to fit) as the general fallback.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "small_dft.hpp"
-
 
 namespace tdm {
 
@@ -161,8 +160,6 @@ __global__ __launch_bounds__(kPfbThreads) void k_pfb(const void *__restrict__ iq
 //   pass 1   thread (mi, n2): SmallDft<M1> over n1 in place in the exchange tile, times the middle twiddle
 //   pass 2   thread (k1, mi): SmallDft<M2> over n2, stores channels k1 + M1*k2; consecutive lanes hold
 //            consecutive output times, so each channel row receives TB*8 contiguous bytes.
-// OVL: the exchange tile overlays the input window (stage A keeps its sums in registers across a
-// barrier), which brings the tile of M = 400 under a third of the LDS: three workgroups per CU.
 template <int FMT>
 struct PfbUnit;   // four consecutive input samples in wire format + validity
 template <>
