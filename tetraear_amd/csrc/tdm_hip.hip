@@ -1304,10 +1304,22 @@ int tdm_channelise_batch(const void *iq, int32_t in_fmt, int64_t n_in, int32_t n
     const bool sync = !device_pointers;
     switch (M) {
     // device pointers: enqueue on the default stream and return (tdm_dev_sync waits)
-    case 96: rc = launch_pfb<8, 12, 3, 24, 3>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 72: rc = launch_pfb<8, 9, 3, 48, 2>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 80: rc = launch_pfb<8, 10, 3, 32, 3>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 128: rc = launch_pfb<8, 16, 3, 16, 4>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+#ifndef TDM_PFB96
+#define TDM_PFB96 16, 4
+#endif
+#ifndef TDM_PFB72
+#define TDM_PFB72 48, 2
+#endif
+#ifndef TDM_PFB128
+#define TDM_PFB128 16, 4
+#endif
+#ifndef TDM_PFB80
+#define TDM_PFB80 32, 3
+#endif
+    case 96: rc = launch_pfb<8, 12, 3, TDM_PFB96>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 72: rc = launch_pfb<8, 9, 3, TDM_PFB72>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 80: rc = launch_pfb<8, 10, 3, TDM_PFB80>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 128: rc = launch_pfb<8, 16, 3, TDM_PFB128>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
     case 400: rc = launch_pfb<20, 20, 3, 32, 1>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
     default: return fail(TDM_ERR_UNSUPPORTED, "channeliser built for M in {72, 80, 96, 128, 400}");
     }
