@@ -96,7 +96,9 @@ TDM_API int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
 
 /* ---- SignalProcessor.process (processor.py:221-273), batched over carriers ----------------
  *  iq            [n_carriers] streams of n_samples in the plan's format; carrier c starts at
- *                iq + c * carrier_stride_samples samples (0 = all carriers share one stream)
+ *                iq + c * carrier_stride_samples samples (0 = all carriers share one stream;
+ *                TDM_MODE_TETRA: any stride >= n_samples, e.g. the row pitch of tdm_channelise_batch)
+ *  n_samples     at most 2^31 per plan
  *  pre_shift_hz  per carrier, or NULL: frequency_shift(x, f) at the INPUT rate before process()
  *                (processor.py:85-100; the composition SURVEY.md 8(d) C3 uses to channelise)
  *  freq_offset_hz per carrier, or NULL: process()'s freq_offset (applied after the decimator)
