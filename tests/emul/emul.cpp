@@ -35,6 +35,7 @@ struct EmuWaveComm {
     Group *g;
     int lane;
     double *stage() { return &g->slots[(size_t)g->nt * 16 + 1024]; }
+    double *edge_slots() { return stage(); }   // (the parallel-form kernel has no staged loader)
     void wave_sync() { g->bar.arrive_and_wait(); }
     template <int K>
     void xchg(const double *a, const double *b, double *oa, double *ob, int src)
@@ -97,6 +98,16 @@ struct EmuBackend {
                     zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, lane, b, row);
                 });
     }
+    template <int Q, int S, int EDGE, class Loader>
+    void pz_block(const ZpParams &P, Loader ld, int nb, int rows)
+    {
+        for (int row = 0; row < rows; ++row)
+            for (int b = 0; b < nb; ++b)
+                run_group(kWave, [&](int lane, Group *g) {
+                    EmuWaveComm cm{g, lane};
+                    pz_block_body<Q, S, EDGE>(P, ld, cm, lane, b, row);
+                });
+    }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
     {
@@ -146,7 +157,7 @@ struct EmuBackend {
 
 struct HostZp {
     ZpHostTables t;
-    std::vector<double> y0, Ef, Eb, flast, Gf, Hb;
+    std::vector<double> y0, Ef, Eb, flast, Gf, Hb, Elast;
     void bind(int rows)
     {
         ZpParams &p = t.p;
@@ -159,8 +170,9 @@ struct HostZp {
         Gf.assign((size_t)rows * p.nb * D * 2, nan);
         Hb.assign((size_t)rows * p.nb * D * 2, nan);
         flast.assign((size_t)rows * 2, nan);
+        Elast.assign((size_t)rows * D * 2, nan);
         p.y0 = y0.data(); p.Ef = Ef.data(); p.Eb = Eb.data();
-        p.Gf = Gf.data(); p.Hb = Hb.data(); p.flast = flast.data();
+        p.Gf = Gf.data(); p.Hb = Hb.data(); p.flast = flast.data(); p.Elast = Elast.data();
     }
 };
 
@@ -180,14 +192,19 @@ static void small_dft_host(const float *in, float *out)
     }
 }
 
+static bool g_allow_pz = true;
+
 extern "C" {
+
+// tests: 0 forces the cascade engine for every decimation factor (the generic fallback of the library)
+void emu_allow_parallel_form(int on) { g_allow_pz = on != 0; }
 
 // whole pipeline == tdm_process with host pointers
 int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq, int64_t stride,
                 const double *pre_shift, const double *freq_offset, uint8_t *hard, double *soft,
                 int32_t *n_soft, int32_t *best_phase, double *min_margin, int32_t *max_soft_out)
 {
-    RefPlanHost h = build_ref_plan(sample_rate, n);
+    RefPlanHost h = build_ref_plan(sample_rate, n, 25000.0, g_allow_pz);
     if (max_soft_out) *max_soft_out = (int32_t)h.max_soft;
     if (!iq) return 0;  // query only
     HostZp dec, lpf;
@@ -216,9 +233,21 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
         if (n <= kEdgeSos) return -1;
         Sos4 s = design_cheby1_8(0.05, 0.8 / q);
         int64_t n_out = (n + q - 1) / q;
-        hz.t = build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, n_out, q);
-        hz.bind(1);
-        be.zp_block<2, 4, kLDec, kEdgeSos>(hz.t.p, ld, hz.t.p.nb, 1);
+        const int S = g_allow_pz ? pz_outputs_per_lane(q) : 0;
+        if (S) {
+            RefPlanHost h;
+            h.q = q;
+            h.dec = build_pz_tables(s.sos, 4, n, kEdgeSos, q * S, S, n_out, q);
+            hz.t = h.dec;
+            hz.bind(1);
+            h.dec.p = hz.t.p;
+            RawLoaderRT<false> lr{x, n, nullptr, fs, FMT_CF64};
+            run_pz_block(be, h, hz.t.p, lr, 1);
+        } else {
+            hz.t = build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, n_out, q);
+            hz.bind(1);
+            be.zp_block<2, 4, kLDec, kEdgeSos>(hz.t.p, ld, hz.t.p.nb, 1);
+        }
         be.zp_carry<2, 4>(hz.t.p, hz.t.p.nb, 1);
         be.zp_fixup<8, kLDec>(hz.t.p, hz.t.p.nb, 1, y, n_out, nullptr, fs);
     } else {

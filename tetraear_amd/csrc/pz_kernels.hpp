@@ -1,0 +1,421 @@
+// Parallel-form zero-phase decimator: the block kernel body of scipy.signal.decimate as the reference
+// calls it (processor.py:254: cheby1(8, 0.05, 0.8/q) run forward and backward, then [::q]).
+//
+// The composite operator H(z)H(1/z) is evaluated as its partial-fraction expansion (pz_tables.hpp):
+// per conjugate pole pair one CAUSAL and one ANTICAUSAL all-pole biquad, both fed by the input
+// samples themselves,
+//         w[n]  = x[n] - a1 w[n-1]  - a2 w[n-2]          (left to right)
+//         w'[n] = x[n] - a1 w'[n+1] - a2 w'[n+2]         (right to left)
+//         y[n]  = dx x[n] + sum_pairs  b0 (w[n] + w'[n]) + b1 (w[n-1] + w'[n+1]),
+// and y is formed only at the decimated positions.  That is 2 multiply-adds per real sample, pair and
+// direction (32 per complex sample for the order-8 filter) against 64 operations for the two cascade
+// passes, and the blocked evaluation needs its start-state corrections only at the S outputs of a lane
+// instead of at every sample.  Block structure, cross-block carries and the consumer-side fix-up
+// (y = y0 + T1.Gf + T2.Hb) are those of the cascade engine (zp_common.hpp / zp_kernels.hpp).
+//
+// Geometry: a lane owns L = S*Q consecutive samples, Q = decimation factor, so every lane's outputs sit at
+// its local positions 0, Q, 2Q, ... (compile-time); a wavefront owns a block of 64 lanes.
+#pragma once
+#include "zp_kernels.hpp"
+#include "pz_tables.hpp"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TDM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TDM_SCHED_FENCE()
+#endif
+// one sample step of all chains at a time: keeps the scheduler from hoisting the independent halves of later
+// steps (and their operands) far ahead, which costs more registers than the file has
+#ifndef TDM_STEP_FENCE
+#define TDM_STEP_FENCE() TDM_SCHED_FENCE()
+#endif
+// makes a value's computation happen here in program order (the instruction selector otherwise defers the output
+// accumulations to the end of the kernel and keeps their operands alive, which spills)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TDM_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define TDM_PIN(x)
+#endif
+
+namespace tdm {
+
+// ------------------------------------------------------------------------------------------
+// Loader with the wire format as a run-time switch (one kernel per Q instead of one per Q x format):
+// gives a lane its L samples of the padded, odd-extended signal, UNSCALED.
+//   interior lanes : dword loads (8-bit formats need only 4-byte alignment), converted in registers
+//   edge lanes     : (odd extension / zero pad; at most kSlots lanes of the first and last block) a rolled
+//                    per-sample loop through a small LDS buffer -- no stack array, no scratch
+// ------------------------------------------------------------------------------------------
+struct alignas(4) u32x4_a4 {
+    uint32_t x, y, z, w;
+};
+struct alignas(8) f64x2_a8 {
+    double x, y;
+};
+struct alignas(4) f32x2_a4 {
+    float x, y;
+};
+
+template <int L, int EDGE>
+struct PzEdgeGeom {
+    static constexpr int P0 = (L - EDGE % L) % L;
+    static constexpr int kHead = (P0 + EDGE) / L;              // lanes of block 0 before signal sample 0
+    static constexpr int kTail = 1 + (EDGE + L - 2) / L;       // lanes that hold the tail extension
+    static constexpr int kSlots = kHead + kTail;
+    static constexpr int kDoubles = kSlots * L * 2;
+};
+
+template <bool SHIFT>
+struct RawLoaderRT {
+    const void *iq;            // first sample of row 0
+    int64_t row_stride;        // samples between rows (0 = shared stream)
+    const double *pre_shift;   // per row [Hz] or null: frequency_shift of the stream on load (processor.py:85-100)
+    double fs;
+    int32_t fmt;
+
+    TDM_HD int bytes() const { return (fmt == FMT_CU8 || fmt == FMT_CS8) ? 2 : (fmt == FMT_CF32 ? 8 : 16); }
+    TDM_HD const void *row_ptr(int row) const { return (const char *)iq + (int64_t)row * row_stride * bytes(); }
+    TDM_HD double row_shift(int row) const { return (SHIFT && pre_shift) ? pre_shift[row] : 0.0; }
+
+    TDM_HD void raw(const void *rowp, int64_t k, double &re, double &im) const
+    {
+        switch (fmt) {
+        case FMT_CU8: convert_one<FMT_CU8>(rowp, k, re, im); break;
+        case FMT_CS8: convert_one<FMT_CS8>(rowp, k, re, im); break;
+        case FMT_CF32: convert_one<FMT_CF32>(rowp, k, re, im); break;
+        default: convert_one<FMT_CF64>(rowp, k, re, im); break;
+        }
+    }
+    TDM_HD void sample(const void *rowp, int64_t k, double f, double &re, double &im) const
+    {
+        raw(rowp, k, re, im);
+        if (SHIFT && f != 0.0) nco_rotate(re, im, k, f, fs);
+    }
+    // sample e of the odd extension of the row (scipy odd_ext, _arraytools.py), zero outside it
+    TDM_HD void ext_sample(const void *rowp, double f, int64_t e, int64_t n, int edge, double &re, double &im) const
+    {
+        re = 0;
+        im = 0;
+        if (e < 0 || e >= n + 2 * (int64_t)edge) return;
+        if (e < edge) {  // 2*x[0] - x[edge - e]
+            double ar, ai;
+            sample(rowp, 0, f, ar, ai);
+            sample(rowp, edge - e, f, re, im);
+            re = 2 * ar - re;
+            im = 2 * ai - im;
+        } else if (e < edge + n) {
+            sample(rowp, e - edge, f, re, im);
+        } else {  // 2*x[n-1] - x[n-2-(e-edge-n)]
+            double ar, ai;
+            sample(rowp, n - 1, f, ar, ai);
+            sample(rowp, n - 2 - (e - edge - n), f, re, im);
+            re = 2 * ar - re;
+            im = 2 * ai - im;
+        }
+    }
+
+    template <int L, int FMT>
+    TDM_HD void fast8(const char *p, double *xr, double *xi) const
+    {
+        // 8-bit pairs: 2L bytes
+        if ((((uintptr_t)p) & 3) == 0) {
+            constexpr int NQ = (2 * L) / 16, NDW = ((2 * L) % 16) / 4;
+            uint32_t w[(2 * L + 3) / 4];
+            const u32x4_a4 *v = (const u32x4_a4 *)p;
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                const u32x4_a4 t = v[c];
+                w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w;
+            }
+            const uint32_t *d = (const uint32_t *)(p + 16 * NQ);
+#pragma unroll
+            for (int c = 0; c < NDW; ++c) w[4 * NQ + c] = d[c];
+            if ((2 * L) % 4) w[(2 * L) / 4] = *(const uint16_t *)(p + (2 * L) / 4 * 4);
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const uint32_t s = w[i / 2] >> (16 * (i % 2));
+                cvt8<FMT>(s & 255u, (s >> 8) & 255u, xr[i], xi[i]);
+            }
+        } else {
+            const uint16_t *h = (const uint16_t *)p;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const uint32_t s = h[i];
+                cvt8<FMT>(s & 255u, (s >> 8) & 255u, xr[i], xi[i]);
+            }
+        }
+    }
+    template <int FMT>
+    TDM_HD static void cvt8(uint32_t a, uint32_t b, double &re, double &im)
+    {
+        if (FMT == FMT_CU8) {
+            // pyrtlsdr: bytes.astype(float64) / 127.5 - 1 with numpy's multiply by fl(1/127.5): two roundings
+            const double cc = 1.0 / 127.5;
+            re = sub_rn(mul_rn((double)a, cc), 1.0);
+            im = sub_rn(mul_rn((double)b, cc), 1.0);
+        } else {
+            re = (double)(int8_t)a * (1.0 / 128.0);
+            im = (double)(int8_t)b * (1.0 / 128.0);
+        }
+    }
+
+    // x[i] = padded-ext sample seg + i (zero outside the extended signal)
+    template <int L, int EDGE, class Comm>
+    TDM_HD void load(Comm &cm, int row, int blk, int lane, const ZpParams &P, double *xr, double *xi) const
+    {
+        typedef PzEdgeGeom<L, EDGE> G;
+        const int64_t seg = (int64_t)blk * (kWave * L) + (int64_t)lane * L;
+        const void *rowp = row_ptr(row);
+        const double f = row_shift(row);
+        const int64_t n = P.n;
+        const int64_t e0 = seg - G::P0;  // ext index of x[0]
+        if (e0 >= EDGE && e0 + L <= EDGE + n) {
+            const int64_t k = e0 - EDGE;
+            const char *p = (const char *)rowp + k * bytes();
+            // frequency_shift of the shared stream with a running phasor over the lane's consecutive samples; the
+            // anchor's (out-of-line) sincos runs before the samples occupy the register file
+            NcoRunT<1> nco;
+            if (SHIFT && f != 0.0) nco.init(k, f, fs);
+            switch (fmt) {
+            case FMT_CU8: fast8<L, FMT_CU8>(p, xr, xi); break;
+            case FMT_CS8: fast8<L, FMT_CS8>(p, xr, xi); break;
+            case FMT_CF32: {
+                const f32x2_a4 *v = (const f32x2_a4 *)p;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const f32x2_a4 t = v[i];
+                    xr[i] = (double)t.x;
+                    xi[i] = (double)t.y;
+                }
+            } break;
+            default: {
+                const f64x2_a8 *v = (const f64x2_a8 *)p;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const f64x2_a8 t = v[i];
+                    xr[i] = t.x;
+                    xi[i] = t.y;
+                }
+            } break;
+            }
+            if (SHIFT && f != 0.0) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    double c = nco.ar, sn = nco.ai;
+                    if (i > 0) nco.next(f, fs, c, sn);
+                    const double a = xr[i], b = xi[i];
+                    xr[i] = a * c - b * sn;
+                    xi[i] = a * sn + b * c;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            }
+        } else if (e0 >= n + 2 * (int64_t)EDGE) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) { xr[i] = 0; xi[i] = 0; }
+        } else {
+            int slot;
+            if (e0 < EDGE) {
+                slot = (int)(seg / L);
+            } else {
+                const int64_t seg_t0 = ((G::P0 + EDGE + n) / L) * L;
+                slot = G::kHead + (int)((seg - seg_t0) / L);
+            }
+            double *buf = cm.edge_slots() + (size_t)slot * L * 2;
+#pragma unroll 1
+            for (int i = 0; i < L; ++i) {
+                double re, im;
+                ext_sample(rowp, f, e0 + i, n, EDGE, re, im);
+                buf[2 * i] = re;
+                buf[2 * i + 1] = im;
+            }
+#pragma unroll
+            for (int i = 0; i < L; ++i) { xr[i] = buf[2 * i]; xi[i] = buf[2 * i + 1]; }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Block body: one wavefront = one block of 64 lanes x L samples, L = Q*S.
+//   Comm: edge_slots() -> PzEdgeGeom<L,EDGE>::kDoubles doubles of wavefront-private scratch;
+//   shfl_up2<2> / shfl_down2<2> as in zp_block_body.
+// ------------------------------------------------------------------------------------------
+template <int Q, int S, int EDGE, class Loader, class Comm>
+TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lane, int blk, int row)
+{
+    constexpr int NP = PzLayout::kMaxPairs, D = 2 * NP;
+    constexpr int L = Q * S;
+    constexpr int Bn = kWave * L;
+    typedef PzEdgeGeom<L, EDGE> G;
+    double xr[L], xi[L];
+    ld.template load<L, EDGE>(cm, row, blk, lane, P, xr, xi);
+
+    const auto pz = TDM_CPTR(P.pz);
+    const bool inject = (blk == 0 && lane == 0);
+    const double e0r = xr[G::P0], e0i = xi[G::P0];
+    const int64_t nbD = (int64_t)P.nb * D;
+    double *Ef = P.Ef + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
+    double *Eb = P.Eb + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
+    const bool last_blk = (blk == P.nb - 1);
+
+    double yr[S], yi[S];
+    {
+        const double dx = pz[PzLayout::off_dx];
+#pragma unroll
+        for (int t = 0; t < S; ++t) { yr[t] = dx * xr[t * Q]; yi[t] = dx * xi[t * Q]; }
+    }
+
+    // ---------------- one pole pair at a time: causal bank left to right, anticausal bank right to left ----------------
+    // (four independent recurrences in flight: two directions x re/im)
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        const double *cs = P.pz;
+        TDM_OPAQUE_SPTR(cs);   // (per-pair scalar loads: keeps all pairs' constants from being fetched at once)
+        const double na1 = -TDM_CPTR(cs)[PzLayout::off_a1 + s], na2 = -TDM_CPTR(cs)[PzLayout::off_a2 + s];
+        const double b0 = TDM_CPTR(cs)[PzLayout::off_b0 + s], b1 = TDM_CPTR(cs)[PzLayout::off_b1 + s];
+        double f1r = 0, f2r = 0, f1q = 0, f2q = 0;   // causal (w[n-1], w[n-2]), re / im
+        double a1r = 0, a2r = 0, a1q = 0, a2q = 0;   // anticausal (w'[n+1], w'[n+2])
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int ib = L - 1 - i;
+            if (i == G::P0) {
+                // scipy's zi*ext[0]: constant history ext[0] before the first extended sample
+                const double g = TDM_CPTR(cs)[PzLayout::off_g + s];
+                f1r = inject ? g * e0r : f1r; f2r = inject ? g * e0r : f2r;
+                f1q = inject ? g * e0i : f1q; f2q = inject ? g * e0i : f2q;
+            }
+            {
+                const double wr = fma(na1, f1r, fma(na2, f2r, xr[i]));
+                const double wq = fma(na1, f1q, fma(na2, f2q, xi[i]));
+                if (i % Q == 0) {
+                    yr[i / Q] = fma(b0, wr, fma(b1, f1r, yr[i / Q]));
+                    yi[i / Q] = fma(b0, wq, fma(b1, f1q, yi[i / Q]));
+                    TDM_PIN(yr[i / Q]);
+                    TDM_PIN(yi[i / Q]);
+                }
+                f2r = f1r; f1r = wr;
+                f2q = f1q; f1q = wq;
+            }
+            {
+                const double wr = fma(na1, a1r, fma(na2, a2r, xr[ib]));
+                const double wq = fma(na1, a1q, fma(na2, a2q, xi[ib]));
+                if (ib % Q == 0) {
+                    yr[ib / Q] = fma(b0, wr, fma(b1, a1r, yr[ib / Q]));
+                    yi[ib / Q] = fma(b0, wq, fma(b1, a1q, yi[ib / Q]));
+                    TDM_PIN(yr[ib / Q]);
+                    TDM_PIN(yi[ib / Q]);
+                }
+                a2r = a1r; a1r = wr;
+                a2q = a1q; a1q = wq;
+            }
+        }
+        // inclusive scans of the lanes' end states, both directions interleaved: I_l = e_l + C^L I_{l -/+ 1}
+        double zr[2] = {f1r, f2r}, zq[2] = {f1q, f2q};     // causal
+        double ur[2] = {a1r, a2r}, uq[2] = {a1q, a2q};     // anticausal
+        const double *Ms = P.Mpow + (size_t)s * kScanSteps * 4;
+        TDM_OPAQUE_SPTR(Ms);
+#pragma unroll
+        for (int j = 0; j < kScanSteps; ++j) {
+            const int d = 1 << j;
+            const auto M = TDM_CPTR(Ms + j * 4);
+            double jr[2], jq[2], kr[2], kq[2];
+            cm.template shfl_up2<2>(zr, zq, jr, jq, d);
+            cm.template shfl_down2<2>(ur, uq, kr, kq, d);
+            const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+            if (lane >= d) {
+                const double ar = zr[0], aq = zq[0], br = zr[1], bq = zq[1];
+                zr[0] = fma(m0, jr[0], fma(m1, jr[1], ar));
+                zr[1] = fma(m2, jr[0], fma(m3, jr[1], br));
+                zq[0] = fma(m0, jq[0], fma(m1, jq[1], aq));
+                zq[1] = fma(m2, jq[0], fma(m3, jq[1], bq));
+            }
+            if (lane + d < kWave) {
+                const double ar = ur[0], aq = uq[0], br = ur[1], bq = uq[1];
+                ur[0] = fma(m0, kr[0], fma(m1, kr[1], ar));
+                ur[1] = fma(m2, kr[0], fma(m3, kr[1], br));
+                uq[0] = fma(m0, kq[0], fma(m1, kq[1], aq));
+                uq[1] = fma(m2, kq[0], fma(m3, kq[1], bq));
+            }
+        }
+        if (lane == kWave - 1) {
+            Ef[(2 * s) * 2] = zr[0]; Ef[(2 * s) * 2 + 1] = zq[0];
+            Ef[(2 * s + 1) * 2] = zr[1]; Ef[(2 * s + 1) * 2 + 1] = zq[1];
+        }
+        if (lane == 0) {
+            Eb[(2 * s) * 2] = ur[0]; Eb[(2 * s) * 2 + 1] = uq[0];
+            Eb[(2 * s + 1) * 2] = ur[1]; Eb[(2 * s + 1) * 2 + 1] = uq[1];
+        }
+        if (last_blk && lane == (P.len_last - 1) / L) {
+            // the lane holding the last extended sample: its causal state after the lane's (zero-padded) tail
+            double *El = P.Elast + (int64_t)row * D * 2;
+            El[(2 * s) * 2] = zr[0]; El[(2 * s) * 2 + 1] = zq[0];
+            El[(2 * s + 1) * 2] = zr[1]; El[(2 * s + 1) * 2 + 1] = zq[1];
+        }
+        // start states of this lane = inclusive values of the neighbour lanes; their responses at the lane's outputs
+        double sr[2], sq[2], tr[2], tq[2];
+        cm.template shfl_up2<2>(zr, zq, sr, sq, 1);
+        cm.template shfl_down2<2>(ur, uq, tr, tq, 1);
+        if (lane == 0) { sr[0] = 0; sr[1] = 0; sq[0] = 0; sq[1] = 0; }
+        if (lane == kWave - 1) { tr[0] = 0; tr[1] = 0; tq[0] = 0; tq[1] = 0; }
+        const double *zfs = P.pz + PzLayout::off_zf + s * S * 2;
+        const double *zbs = P.pz + PzLayout::off_zf + (NP + s) * S * 2;   // == off_zb(S) + s*S*2
+        TDM_OPAQUE_SPTR(zfs);
+        TDM_OPAQUE_SPTR(zbs);
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const double z0 = TDM_CPTR(zfs)[t * 2], z1 = TDM_CPTR(zfs)[t * 2 + 1];
+            const double v0 = TDM_CPTR(zbs)[t * 2], v1 = TDM_CPTR(zbs)[t * 2 + 1];
+            yr[t] = fma(z0, sr[0], fma(z1, sr[1], fma(v0, tr[0], fma(v1, tr[1], yr[t]))));
+            yi[t] = fma(z0, sq[0], fma(z1, sq[1], fma(v0, tq[0], fma(v1, tq[1], yi[t]))));
+            TDM_PIN(yr[t]);
+            TDM_PIN(yi[t]);
+        }
+        TDM_SCHED_FENCE();
+    }
+    // the last extended sample (the anticausal start needs it, see pz_carry_last): 2 x[n-1] - x[n-1-edge]
+    if (last_blk && lane == 0) {
+        double re, im;
+        ld.ext_sample(ld.row_ptr(row), ld.row_shift(row), P.n + 2 * (int64_t)EDGE - 1, P.n, EDGE, re, im);
+        P.flast[(int64_t)row * 2] = re;
+        P.flast[(int64_t)row * 2 + 1] = im;
+    }
+    // ---------------- block-local outputs: S consecutive decimated samples per lane ----------------
+    {
+        static_assert((G::P0 + EDGE) % Q == 0 || S == 0, "outputs sit on lane-local multiples of Q");
+        const int64_t j0 = ((int64_t)blk * Bn + (int64_t)lane * L - P.k0L) / Q;   // exact: every term is a multiple of Q
+        f64x2 *y0 = (f64x2 *)(P.y0 + (int64_t)row * P.n_out * 2);
+        if ((int64_t)blk * Bn + (int64_t)lane * L >= P.k0L) {
+#pragma unroll
+            for (int t = 0; t < S; ++t)
+                if (j0 + t < P.n_out) y0[j0 + t] = f64x2{yr[t], yi[t]};
+        }
+    }
+}
+
+// Start of the anticausal carry chain (scipy: backward pass started at zi * forward output at the last
+// sample).  G = resolved causal carry into the last block, El = exported lane state, xl = ext[last].
+template <int D>
+TDM_HD void pz_carry_last(const ZpParams &P, int row, int ch, const double *G)
+{
+    const int nb = P.nb;
+    const int S = P.L / P.out_stride;
+    const auto AG = TDM_CPTR(P.pz + PzLayout::off_AG(S));
+    const auto AE = TDM_CPTR(P.pz + PzLayout::off_AE(S));
+    const auto wx = TDM_CPTR(P.pz + PzLayout::off_wx(S));
+    const double *El = P.Elast + (int64_t)row * D * 2 + ch;
+    const double xl = P.flast[(int64_t)row * 2 + ch];
+    double *Hb = P.Hb + (int64_t)row * nb * D * 2 + ch;
+    double e[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) e[k] = El[k * 2];
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        double acc = wx[r] * xl;
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc += AG[r * D + k] * G[k] + AE[r * D + k] * e[k];
+        Hb[((int64_t)(nb - 1) * D + r) * 2] = acc;
+    }
+}
+
+}  // namespace tdm

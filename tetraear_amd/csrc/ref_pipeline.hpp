@@ -16,6 +16,7 @@
 #pragma once
 #include "ref_plan.hpp"
 #include "zp_kernels.hpp"
+#include "pz_kernels.hpp"
 
 namespace tdm {
 
@@ -39,13 +40,33 @@ struct RefIO {
     double *min_margin;
 };
 
+// parallel-form decimator: one kernel per decimation factor, wire format as a run-time switch
+template <class BE, bool SHIFT>
+void run_pz_block(BE &be, const RefPlanHost &h, const ZpParams &P, const RawLoaderRT<SHIFT> &ld, int rows)
+{
+    const int nb = h.dec.p.nb;
+    switch (h.q) {
+#define TDM_PZ_CASE(Q, S) case Q: be.template pz_block<Q, S, kEdgeSos>(P, ld, nb, rows); break;
+        TDM_PZ_CASE(2, 16) TDM_PZ_CASE(3, 10) TDM_PZ_CASE(4, 8) TDM_PZ_CASE(5, 6) TDM_PZ_CASE(6, 5) TDM_PZ_CASE(7, 4)
+        TDM_PZ_CASE(8, 4) TDM_PZ_CASE(9, 3) TDM_PZ_CASE(10, 3) TDM_PZ_CASE(11, 2) TDM_PZ_CASE(12, 2) TDM_PZ_CASE(13, 2)
+        TDM_PZ_CASE(14, 2) TDM_PZ_CASE(15, 2) TDM_PZ_CASE(16, 2) TDM_PZ_CASE(41, 1)
+#undef TDM_PZ_CASE
+    default: break;   // (build_ref_plan only sets pz_S for the factors above)
+    }
+}
+
 template <class BE, int FMT, bool SHIFT>
 void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, const RefIO &io)
 {
     RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
     if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
-        be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
+        if (h.pz_S) {
+            RawLoaderRT<SHIFT> lr{io.iq, io.carrier_stride, SHIFT ? io.pre_shift : nullptr, h.sample_rate, FMT};
+            run_pz_block(be, h, B.dec_params, lr, rows);
+        } else {
+            be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
+        }
         be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
         if (!h.lpf)  // (n_dec <= 15) nothing downstream finishes the decimator output: do it here
             be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);

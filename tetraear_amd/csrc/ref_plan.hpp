@@ -6,6 +6,7 @@
 
 #include "design.hpp"
 #include "zp_tables.hpp"
+#include "pz_tables.hpp"
 
 namespace tdm {
 
@@ -21,6 +22,31 @@ constexpr int kEdgeSos = 27;  // sosfiltfilt pad for 4 sections: 3*(2*4+1)
 constexpr int kEdgeTf = 15;   // filtfilt pad for order 4: 3*5
 constexpr double kSymbolRate = 18000.0;
 
+// Parallel-form decimator kernels exist for these decimation factors; S = outputs per lane (lane length
+// S*q <= 32 samples, 41 for the 10 MS/s case).  Any other factor runs on the cascade engine.
+inline int pz_outputs_per_lane(int q)
+{
+    switch (q) {
+    case 2: return 16;
+    case 3: return 10;
+    case 4: return 8;
+    case 5: return 6;
+    case 6: return 5;
+    case 7: return 4;
+    case 8: return 4;
+    case 9: return 3;
+    case 10: return 3;
+    case 11: return 2;
+    case 12: return 2;
+    case 13: return 2;
+    case 14: return 2;
+    case 15: return 2;
+    case 16: return 2;
+    case 41: return 1;
+    default: return 0;
+    }
+}
+
 struct RefPlanHost {
     double sample_rate = 0;
     int64_t n = 0;
@@ -34,6 +60,7 @@ struct RefPlanHost {
     int64_t max_soft = 0;
     Sos4 sos{};
     Tf4 tf{};
+    int pz_S = 0;           // > 0: the decimator runs in parallel form with pz_S outputs per lane
     ZpHostTables dec;       // valid if decimated
     ZpHostTables lpf_t;     // valid if lpf
 };
@@ -72,7 +99,7 @@ inline ZpFilterDesc desc_from_sos(const Sos4 &s) { return desc_from_rows(s.sos, 
 // the order-4 channel filter runs as its two-biquad factorisation (see Tf4 in design.hpp)
 inline ZpFilterDesc desc_from_tf(const Tf4 &t) { return desc_from_rows(t.sos, 2); }
 
-inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidth = 25000.0)
+inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidth = 25000.0, bool allow_pz = true)
 {
     RefPlanHost h;
     h.sample_rate = sample_rate;
@@ -88,8 +115,13 @@ inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidt
     if (h.max_soft < 1) h.max_soft = 1;
     if (h.q > 1) h.sos = design_cheby1_8(0.05, 0.8 / h.q);
     h.tf = design_butter4(butter_cutoff(bandwidth, h.rate_dec));
-    if (h.decimated)
-        h.dec = build_zp_tables(desc_from_sos(h.sos), n, kEdgeSos, kLDec, h.n_dec, h.q);
+    if (h.decimated) {
+        h.pz_S = (allow_pz && rows_are_lp121(h.sos.sos, 4)) ? pz_outputs_per_lane(h.q) : 0;
+        if (h.pz_S)
+            h.dec = build_pz_tables(h.sos.sos, 4, n, kEdgeSos, h.q * h.pz_S, h.pz_S, h.n_dec, h.q);
+        else
+            h.dec = build_zp_tables(desc_from_sos(h.sos), n, kEdgeSos, kLDec, h.n_dec, h.q);
+    }
     if (h.lpf)
         h.lpf_t = build_zp_tables(desc_from_tf(h.tf), h.n_dec, kEdgeTf, kLLpf, h.n_dec, 1);
     return h;

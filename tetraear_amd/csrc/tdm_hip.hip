@@ -65,6 +65,7 @@ static int use_device(int device)
 struct WaveComm {
     double *stg;
     __device__ __forceinline__ double *stage() { return stg; }
+    __device__ __forceinline__ double *edge_slots() { return stg; }
     __device__ __forceinline__ void wave_sync() { __syncthreads(); }  // one wavefront per workgroup
     template <int K>
     __device__ __forceinline__ void shfl_up2(const double *a, const double *b, double *oa, double *ob, int d)
@@ -121,6 +122,15 @@ __global__ __launch_bounds__(64, (L <= 16 ? 4 : (L <= 24 ? 3 : TDM_BLOCK_WAVES))
     __shared__ __attribute__((aligned(16))) double stg[Loader::kStaged ? StageGeom<L>::kDoubles : 2];
     WaveComm cm{stg};
     zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// parallel-form decimator (pz_kernels.hpp): one wavefront per block of 64 lanes x Q*S samples
+template <int Q, int S, int EDGE, bool SHIFT>
+__global__ __launch_bounds__(64, (Q * S <= 32 ? 2 : 1)) void k_pz_block(const ZpParams P, const RawLoaderRT<SHIFT> ld)
+{
+    __shared__ __attribute__((aligned(16))) double stg[PzEdgeGeom<Q * S, EDGE>::kDoubles];
+    WaveComm cm{stg};
+    pz_block_body<Q, S, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 template <int K, int NSEC, bool FWD>
@@ -287,6 +297,12 @@ struct HipBackend {
         Scope s(*this, NSEC == 4 ? ST_DEC_BLOCK : ST_LPF_BLOCK);
         hipLaunchKernelGGL((k_zp_block<K, NSEC, L, EDGE, Loader>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
     }
+    template <int Q, int S, int EDGE, bool SHIFT>
+    void pz_block(const ZpParams &P, const RawLoaderRT<SHIFT> &ld, int nb, int rows)
+    {
+        Scope s(*this, ST_DEC_BLOCK);
+        hipLaunchKernelGGL((k_pz_block<Q, S, EDGE, SHIFT>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
+    }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
     {
@@ -367,7 +383,7 @@ struct DevZp {
         t.bind(p, d_blob);
         const size_t n_y0 = (size_t)rows * p.n_out * 2;
         const size_t n_e = (size_t)rows * p.nb * D * 2;
-        const size_t total = n_y0 + 4 * n_e + (size_t)rows * 2;
+        const size_t total = n_y0 + 4 * n_e + (size_t)rows * 2 + (size_t)rows * D * 2;
         HIP_TRY(hipMalloc(&d_work, total * sizeof(double)));
         p.y0 = d_work;
         p.Ef = p.y0 + n_y0;
@@ -375,6 +391,7 @@ struct DevZp {
         p.Gf = p.Eb + n_e;
         p.Hb = p.Gf + n_e;
         p.flast = p.Hb + n_e;
+        p.Elast = p.flast + (size_t)rows * 2;
         params = p;
         return TDM_OK;
     }
@@ -860,7 +877,15 @@ int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, do
     RawLoader<FMT_CF64, false> ld{dx.p, n, nullptr, fs};
     StagedLoader<PlainC128Src> ls{{dx.as<double>(), n}};
     if (sos) {
-        be.zp_block<2, 4, kLDec, kEdgeSos>(dz.params, ld, t.p.nb, 1);
+        if (t.p.pform) {
+            RefPlanHost h;
+            h.q = t.p.out_stride;
+            h.dec.p.nb = t.p.nb;
+            RawLoaderRT<false> lr{dx.p, n, nullptr, fs, FMT_CF64};
+            run_pz_block(be, h, dz.params, lr, 1);
+        } else {
+            be.zp_block<2, 4, kLDec, kEdgeSos>(dz.params, ld, t.p.nb, 1);
+        }
         be.zp_carry<2, 4>(dz.params, t.p.nb, 1);
         be.zp_fixup<8, kLDec>(dz.params, t.p.nb, 1, dy.as<double>(), n_out, nullptr, fs);
     } else {
@@ -903,7 +928,9 @@ int tdm_decimate(const double *x, int64_t n, int32_t q, double *y, int64_t *n_ou
     if (rc) return rc;
     Sos4 s = design_cheby1_8(0.05, 0.8 / q);
     const int64_t m = (n + q - 1) / q;
-    ZpHostTables t = build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, m, q);
+    const int S = pz_outputs_per_lane(q);
+    ZpHostTables t = S ? build_pz_tables(s.sos, 4, n, kEdgeSos, q * S, S, m, q)
+                       : build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, m, q);
     rc = run_zp_stage(t, true, x, n, y, m, 1.0);
     if (rc == TDM_OK && n_out) *n_out = m;
     return rc;

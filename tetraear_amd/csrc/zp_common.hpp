@@ -83,6 +83,10 @@ struct ZpParams {
     double *flast;  // [rows] c128, block-local forward output at the last extended sample
     double *Gf;     // [rows][nb][D] c128, resolved forward carry into each block
     double *Hb;     // [rows][nb][D] c128, resolved backward carry into each block
+    // ---- parallel-form stage (pz_kernels.hpp / pz_tables.hpp); pform == 0 for the cascade engine
+    int32_t pform;
+    const double *pz;   // constant block, layout PzLayout
+    double *Elast;      // [rows][D] c128, causal lane state exported by the last block (see pz_tables.hpp)
 };
 
 // One DF2T section step, the operation order of scipy's sosfilt (K == 2,

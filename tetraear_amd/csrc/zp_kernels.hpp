@@ -107,6 +107,39 @@ struct NcoRunT {
         const double q1 = fma(fma(-q0, b, a), r, q0);
         return fma(fma(-q1, b, a), r, q1);
     }
+    // step() split in two for callers that visit consecutive samples and want the (out-of-line) sincos calls
+    // made while few registers are live: init() anchors the phasor at j, next() advances to j_cur + STRIDE.
+    // Same arithmetic as step(), term for term.
+    TDM_HD void init(int64_t j, double f, double fs)
+    {
+        const double ci = -(2.0 * M_PI) * f;
+        rfs = 1.0 / fs;
+        union { double d; uint64_t u; } v;
+        v.d = ci / fs;
+        v.u &= ~uint64_t(0x1FFF);
+        dd = v.d;
+        sincos((double)STRIDE * dd, &si, &sr);
+        const double t = quot((double)(uint32_t)j, fs, rfs);
+        th_a = ci * t;
+        const phasor p = nco_phasor(j, f, fs);
+        ar = p.c; ai = p.s; wr = 1; wi = 0; j_a = j; j_cur = j;
+        on = true;
+    }
+    TDM_HD void next(double f, double fs, double &c, double &s)
+    {
+        const double ci = -(2.0 * M_PI) * f;
+        const int64_t j = j_cur + STRIDE;
+        const double t = quot((double)(uint32_t)j, fs, rfs);
+        const double th = ci * t;
+        j_cur = j;
+        const double nwr = wr * sr - wi * si, nwi = wr * si + wi * sr;
+        wr = nwr;
+        wi = nwi;
+        const double eps = (th - th_a) - (double)(int32_t)(j - j_a) * dd;
+        const double pr = ar * wr - ai * wi, pi_ = ar * wi + ai * wr;
+        c = pr - eps * pi_;
+        s = pi_ + eps * pr;
+    }
     TDM_HD void step(int64_t j, double f, double fs, double &c, double &s)
     {
         const double ci = -(2.0 * M_PI) * f;
@@ -367,7 +400,7 @@ struct DecFixSrc {
     };
     TDM_HD void get(State &st, int row, int64_t j, double &re, double &im) const
     {
-        constexpr int Bn = kWave * LDEC;
+        const int Bn = kWave * dec.L;   // (the decimator's lane length is a plan parameter: cascade 32, parallel form S*q)
         const int64_t pos = dec.k0L + j * dec.out_stride;
         const int b = (int)(pos / Bn);
         const int m = (int)(pos - (int64_t)b * Bn);
@@ -391,7 +424,7 @@ struct DecFixSrc {
     template <class Comm>
     TDM_HD void stage_range(Comm &cm, int row, int64_t j0, int64_t j1, int lane, f64x2 *lds, int slot0) const
     {
-        constexpr int Bn = kWave * LDEC;
+        const int Bn = kWave * dec.L;
         const int q = dec.out_stride;
         const double f = freq_offset ? freq_offset[row] : 0.0;
         {
@@ -747,6 +780,9 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 // P.carry_terms terms; the host picks carry_terms so that max|Mf^terms| < 1e-24 (or = nb, in
 // which case the series is complete).  One thread per (row, block, component).
 // ------------------------------------------------------------------------------------------
+template <int D>
+TDM_HD void pz_carry_last(const ZpParams &P, int row, int ch, const double *G);   // pz_kernels.hpp
+
 template <int D, class MP>
 TDM_HD void matvec_acc(MP M, const double *v, double *out)
 {
@@ -782,7 +818,9 @@ TDM_HD void zp_carry_fwd_body(const ZpParams &P, int row, int b, int ch)
     }
 #pragma unroll
     for (int k = 0; k < D; ++k) Gf[((int64_t)b * D + k) * 2] = G[k];
-    if (b == nb - 1) {
+    if (b == nb - 1 && P.pform) {
+        pz_carry_last<D>(P, row, ch, G);   // parallel form: anticausal bank's start state
+    } else if (b == nb - 1) {
         // true forward output at the last extended sample -> start state of the backward pass
         double fl = P.flast[(int64_t)row * 2 + ch];
         const auto c = TDM_CPTR(P.cf_last);
@@ -826,7 +864,7 @@ TDM_HD void zp_carry_bwd_body(const ZpParams &P, int row, int b, int ch)
             Gb[k] = Gf[((int64_t)bb * D + k) * 2];
         }
         matvec_acc<D>(TDM_CPTR(last ? P.Mb_last : P.Mf), H, Hn);
-        matvec_acc<D>(TDM_CPTR(last ? P.U_last : P.U_reg), Gb, Hn);
+        if (!P.pform) matvec_acc<D>(TDM_CPTR(last ? P.U_last : P.U_reg), Gb, Hn);   // (the parallel-form banks do not couple)
 #pragma unroll
         for (int k = 0; k < D; ++k) H[k] = Hn[k];
     }
@@ -917,7 +955,7 @@ template <int D, int L>
 TDM_HD void zp_fixup_body(const ZpParams &P, int row, int b, int tid, int nt, double *out /* row base */,
                           const double *freq_offset /* per row or null */, double fs_out)
 {
-    constexpr int Bn = kWave * L;
+    const int Bn = kWave * P.L;
     const int q = P.out_stride;
     const int64_t base = (int64_t)b * Bn - P.k0L;  // pos - k0L of offset m == 0
     // first offset m0 >= 0 of this block that is an output: (base + m0) % q == 0 and base + m0 >= 0

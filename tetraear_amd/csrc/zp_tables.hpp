@@ -26,7 +26,7 @@ struct ZpFilterDesc {
 struct ZpHostTables {
     ZpParams p;                // table/work pointers are null until patched by the owner
     std::vector<double> blob;  // all tables, concatenated
-    size_t off_Mpow, off_zirh, off_cflast, off_T1reg, off_T2reg, off_T1last, off_T2last, off_Mf, off_Mblast, off_Ureg, off_Ulast;
+    size_t off_Mpow, off_zirh, off_cflast, off_T1reg, off_T2reg, off_T1last, off_T2last, off_Mf, off_Mblast, off_Ureg, off_Ulast, off_pz = 0;
     // point p's table pointers into a copy of blob that lives at `base`
     void bind(ZpParams &q, const double *base) const
     {
@@ -34,6 +34,7 @@ struct ZpHostTables {
         q.T1_reg = base + off_T1reg; q.T2_reg = base + off_T2reg;
         q.T1_last = base + off_T1last; q.T2_last = base + off_T2last; q.Mf = base + off_Mf;
         q.Mb_last = base + off_Mblast; q.U_reg = base + off_Ureg; q.U_last = base + off_Ulast;
+        q.pz = q.pform ? base + off_pz : nullptr;
     }
 };
 
