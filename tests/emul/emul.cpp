@@ -48,6 +48,34 @@ struct EmuWaveComm {
         for (int k = 0; k < K; ++k) { oa[k] = from[k]; ob[k] = from[8 + k]; }
         g->bar.arrive_and_wait();
     }
+    // source lane or -1 -> zeros (the DPP / bpermute shuffles of the device build)
+    template <int K>
+    void gather0(const double *a, const double *b, double *oa, double *ob, int src)
+    {
+        xchg<K>(a, b, oa, ob, src < 0 ? lane : src);
+        if (src < 0)
+            for (int k = 0; k < K; ++k) { oa[k] = 0; ob[k] = 0; }
+    }
+    template <int K>
+    void row_shr2(const double *a, const double *b, double *oa, double *ob, int d) { gather0<K>(a, b, oa, ob, (lane & 15) >= d ? lane - d : -1); }
+    template <int K>
+    void row_shl2(const double *a, const double *b, double *oa, double *ob, int d) { gather0<K>(a, b, oa, ob, (lane & 15) + d <= 15 ? lane + d : -1); }
+    template <int K>
+    void row_total_prev2(const double *a, const double *b, double *oa, double *ob, int step)
+    {
+        const int row = lane >> 4;
+        gather0<K>(a, b, oa, ob, step == 0 ? ((row & 1) ? 16 * row - 1 : -1) : (row >= 2 ? 31 : -1));
+    }
+    template <int K>
+    void row_total_next2(const double *a, const double *b, double *oa, double *ob, int step)
+    {
+        const int row = lane >> 4;
+        gather0<K>(a, b, oa, ob, step == 0 ? ((row & 1) ? -1 : 16 * (row + 1)) : (row < 2 ? 32 : -1));
+    }
+    template <int K>
+    void wave_shr1(const double *a, const double *b, double *oa, double *ob) { gather0<K>(a, b, oa, ob, lane > 0 ? lane - 1 : -1); }
+    template <int K>
+    void wave_shl1(const double *a, const double *b, double *oa, double *ob) { gather0<K>(a, b, oa, ob, lane < 63 ? lane + 1 : -1); }
     template <int K>
     void shfl_up2(const double *a, const double *b, double *oa, double *ob, int d) { xchg<K>(a, b, oa, ob, lane - d); }
     template <int K>

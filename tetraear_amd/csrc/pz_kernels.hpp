@@ -266,8 +266,11 @@ TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
         for (int t = 0; t < S; ++t) { yr[t] = dx * xr[t * Q]; yi[t] = dx * xi[t * Q]; }
     }
 
-    // ---------------- one pole pair at a time: causal bank left to right, anticausal bank right to left ----------------
-    // (four independent recurrences in flight: two directions x re/im)
+    // ---------------- phase 1: the recurrences, one pole pair at a time ----------------
+    // causal bank left to right, anticausal bank right to left: four independent chains in flight
+    // (two directions x re/im).  End states of all pairs are kept for the scans of phase 2.
+    double zr[NP][2], zq[NP][2];   // causal end state (w[L-1], w[L-2]), re / im
+    double ur[NP][2], uq[NP][2];   // anticausal end state (w'[0], w'[1])
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
         const double *cs = P.pz;
@@ -310,68 +313,137 @@ TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
                 a2q = a1q; a1q = wq;
             }
         }
-        // inclusive scans of the lanes' end states, both directions interleaved: I_l = e_l + C^L I_{l -/+ 1}
-        double zr[2] = {f1r, f2r}, zq[2] = {f1q, f2q};     // causal
-        double ur[2] = {a1r, a2r}, uq[2] = {a1q, a2q};     // anticausal
-        const double *Ms = P.Mpow + (size_t)s * kScanSteps * 4;
-        TDM_OPAQUE_SPTR(Ms);
+        zr[s][0] = f1r; zr[s][1] = f2r; zq[s][0] = f1q; zq[s][1] = f2q;
+        ur[s][0] = a1r; ur[s][1] = a2r; uq[s][0] = a1q; uq[s][1] = a2q;
+        TDM_PIN(zr[s][0]); TDM_PIN(zr[s][1]); TDM_PIN(zq[s][0]); TDM_PIN(zq[s][1]);
+        TDM_PIN(ur[s][0]); TDM_PIN(ur[s][1]); TDM_PIN(uq[s][0]); TDM_PIN(uq[s][1]);
+        TDM_SCHED_FENCE();
+    }
+    // ---------------- phase 2: inclusive scans of the lanes' end states ----------------
+    // I_l = e_l + C^L I_{l -/+ 1}, all pairs and both directions per step (eight independent scans share each step's
+    // latency).  The shuffles follow the hardware's lane rows: four Kogge-Stone steps inside each row of 16 lanes
+    // (DPP row shifts, no LDS traffic), then the row totals are passed on twice (rows 1,3 <- 0,2; rows 2,3 <- lane
+    // 31), where the distance to the source lane -- hence the transition matrix -- depends on the lane.
+    double lmf[NP][4], lmb[NP][4];   // C^(L (r+1)) for this lane's distance to the previous / next row
+    {
+        const int r = lane & 15;
+        const f64x2 *tf = (const f64x2 *)(P.pz + PzLayout::off_rowm(S)) + (size_t)r * NP * 2;
+        const f64x2 *tb = (const f64x2 *)(P.pz + PzLayout::off_rowm(S)) + (size_t)(15 - r) * NP * 2;
 #pragma unroll
-        for (int j = 0; j < kScanSteps; ++j) {
-            const int d = 1 << j;
-            const auto M = TDM_CPTR(Ms + j * 4);
-            double jr[2], jq[2], kr[2], kq[2];
-            cm.template shfl_up2<2>(zr, zq, jr, jq, d);
-            cm.template shfl_down2<2>(ur, uq, kr, kq, d);
+        for (int s = 0; s < NP; ++s) {
+            const f64x2 a0 = tf[s * 2], a1 = tf[s * 2 + 1], c0 = tb[s * 2], c1 = tb[s * 2 + 1];
+            lmf[s][0] = a0.x; lmf[s][1] = a0.y; lmf[s][2] = a1.x; lmf[s][3] = a1.y;
+            lmb[s][0] = c0.x; lmb[s][1] = c0.y; lmb[s][2] = c1.x; lmb[s][3] = c1.y;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = 1 << j;
+        double jr[NP][2], jq[NP][2], kr[NP][2], kq[NP][2];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            cm.template row_shr2<2>(zr[s], zq[s], jr[s], jq[s], d);   // lane - d of the same row, 0 where there is none
+            cm.template row_shl2<2>(ur[s], uq[s], kr[s], kq[s], d);   // lane + d
+        }
+        const double *Mj = P.Mpow + j * 4;
+        TDM_OPAQUE_SPTR(Mj);
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const auto M = TDM_CPTR(Mj + (size_t)s * kScanSteps * 4);
             const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
-            if (lane >= d) {
-                const double ar = zr[0], aq = zq[0], br = zr[1], bq = zq[1];
-                zr[0] = fma(m0, jr[0], fma(m1, jr[1], ar));
-                zr[1] = fma(m2, jr[0], fma(m3, jr[1], br));
-                zq[0] = fma(m0, jq[0], fma(m1, jq[1], aq));
-                zq[1] = fma(m2, jq[0], fma(m3, jq[1], bq));
-            }
-            if (lane + d < kWave) {
-                const double ar = ur[0], aq = uq[0], br = ur[1], bq = uq[1];
-                ur[0] = fma(m0, kr[0], fma(m1, kr[1], ar));
-                ur[1] = fma(m2, kr[0], fma(m3, kr[1], br));
-                uq[0] = fma(m0, kq[0], fma(m1, kq[1], aq));
-                uq[1] = fma(m2, kq[0], fma(m3, kq[1], bq));
+            zr[s][0] = fma(m0, jr[s][0], fma(m1, jr[s][1], zr[s][0]));
+            zr[s][1] = fma(m2, jr[s][0], fma(m3, jr[s][1], zr[s][1]));
+            zq[s][0] = fma(m0, jq[s][0], fma(m1, jq[s][1], zq[s][0]));
+            zq[s][1] = fma(m2, jq[s][0], fma(m3, jq[s][1], zq[s][1]));
+            ur[s][0] = fma(m0, kr[s][0], fma(m1, kr[s][1], ur[s][0]));
+            ur[s][1] = fma(m2, kr[s][0], fma(m3, kr[s][1], ur[s][1]));
+            uq[s][0] = fma(m0, kq[s][0], fma(m1, kq[s][1], uq[s][0]));
+            uq[s][1] = fma(m2, kq[s][0], fma(m3, kq[s][1], uq[s][1]));
+        }
+        TDM_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        double jr[NP][2], jq[NP][2], kr[NP][2], kq[NP][2];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            cm.template row_total_prev2<2>(zr[s], zq[s], jr[s], jq[s], step);   // step 0: rows 1,3 <- lane 15 of rows 0,2; step 1: rows 2,3 <- lane 31
+            cm.template row_total_next2<2>(ur[s], uq[s], kr[s], kq[s], step);   // mirror image: rows 0,2 <- lane 0 of rows 1,3; rows 0,1 <- lane 32
+        }
+        if (step == 1) {
+            // rows 3 (causal) and 0 (anticausal) are a whole row further from the source lane: C^(16 L) first
+            const double *M16 = P.Mpow + 4 * 4;
+            TDM_OPAQUE_SPTR(M16);
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const auto M = TDM_CPTR(M16 + (size_t)s * kScanSteps * 4);
+                const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+                const bool far_f = lane >= 48, far_b = lane < 16;
+                const double a0 = fma(m0, jr[s][0], m1 * jr[s][1]), a1 = fma(m2, jr[s][0], m3 * jr[s][1]);
+                const double b0_ = fma(m0, jq[s][0], m1 * jq[s][1]), b1_ = fma(m2, jq[s][0], m3 * jq[s][1]);
+                jr[s][0] = far_f ? a0 : jr[s][0]; jr[s][1] = far_f ? a1 : jr[s][1];
+                jq[s][0] = far_f ? b0_ : jq[s][0]; jq[s][1] = far_f ? b1_ : jq[s][1];
+                const double c0 = fma(m0, kr[s][0], m1 * kr[s][1]), c1 = fma(m2, kr[s][0], m3 * kr[s][1]);
+                const double d0_ = fma(m0, kq[s][0], m1 * kq[s][1]), d1_ = fma(m2, kq[s][0], m3 * kq[s][1]);
+                kr[s][0] = far_b ? c0 : kr[s][0]; kr[s][1] = far_b ? c1 : kr[s][1];
+                kq[s][0] = far_b ? d0_ : kq[s][0]; kq[s][1] = far_b ? d1_ : kq[s][1];
             }
         }
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            zr[s][0] = fma(lmf[s][0], jr[s][0], fma(lmf[s][1], jr[s][1], zr[s][0]));
+            zr[s][1] = fma(lmf[s][2], jr[s][0], fma(lmf[s][3], jr[s][1], zr[s][1]));
+            zq[s][0] = fma(lmf[s][0], jq[s][0], fma(lmf[s][1], jq[s][1], zq[s][0]));
+            zq[s][1] = fma(lmf[s][2], jq[s][0], fma(lmf[s][3], jq[s][1], zq[s][1]));
+            ur[s][0] = fma(lmb[s][0], kr[s][0], fma(lmb[s][1], kr[s][1], ur[s][0]));
+            ur[s][1] = fma(lmb[s][2], kr[s][0], fma(lmb[s][3], kr[s][1], ur[s][1]));
+            uq[s][0] = fma(lmb[s][0], kq[s][0], fma(lmb[s][1], kq[s][1], uq[s][0]));
+            uq[s][1] = fma(lmb[s][2], kq[s][0], fma(lmb[s][3], kq[s][1], uq[s][1]));
+        }
+        TDM_SCHED_FENCE();
+    }
+    // ---------------- phase 3: exports; start-state responses at the lane's outputs ----------------
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
         if (lane == kWave - 1) {
-            Ef[(2 * s) * 2] = zr[0]; Ef[(2 * s) * 2 + 1] = zq[0];
-            Ef[(2 * s + 1) * 2] = zr[1]; Ef[(2 * s + 1) * 2 + 1] = zq[1];
+            Ef[(2 * s) * 2] = zr[s][0]; Ef[(2 * s) * 2 + 1] = zq[s][0];
+            Ef[(2 * s + 1) * 2] = zr[s][1]; Ef[(2 * s + 1) * 2 + 1] = zq[s][1];
         }
         if (lane == 0) {
-            Eb[(2 * s) * 2] = ur[0]; Eb[(2 * s) * 2 + 1] = uq[0];
-            Eb[(2 * s + 1) * 2] = ur[1]; Eb[(2 * s + 1) * 2 + 1] = uq[1];
+            Eb[(2 * s) * 2] = ur[s][0]; Eb[(2 * s) * 2 + 1] = uq[s][0];
+            Eb[(2 * s + 1) * 2] = ur[s][1]; Eb[(2 * s + 1) * 2 + 1] = uq[s][1];
         }
         if (last_blk && lane == (P.len_last - 1) / L) {
             // the lane holding the last extended sample: its causal state after the lane's (zero-padded) tail
             double *El = P.Elast + (int64_t)row * D * 2;
-            El[(2 * s) * 2] = zr[0]; El[(2 * s) * 2 + 1] = zq[0];
-            El[(2 * s + 1) * 2] = zr[1]; El[(2 * s + 1) * 2 + 1] = zq[1];
+            El[(2 * s) * 2] = zr[s][0]; El[(2 * s) * 2 + 1] = zq[s][0];
+            El[(2 * s + 1) * 2] = zr[s][1]; El[(2 * s + 1) * 2 + 1] = zq[s][1];
         }
-        // start states of this lane = inclusive values of the neighbour lanes; their responses at the lane's outputs
-        double sr[2], sq[2], tr[2], tq[2];
-        cm.template shfl_up2<2>(zr, zq, sr, sq, 1);
-        cm.template shfl_down2<2>(ur, uq, tr, tq, 1);
-        if (lane == 0) { sr[0] = 0; sr[1] = 0; sq[0] = 0; sq[1] = 0; }
-        if (lane == kWave - 1) { tr[0] = 0; tr[1] = 0; tq[0] = 0; tq[1] = 0; }
-        const double *zfs = P.pz + PzLayout::off_zf + s * S * 2;
-        const double *zbs = P.pz + PzLayout::off_zf + (NP + s) * S * 2;   // == off_zb(S) + s*S*2
-        TDM_OPAQUE_SPTR(zfs);
-        TDM_OPAQUE_SPTR(zbs);
+    }
+    {
+        // start states of this lane = inclusive values of the neighbour lanes (0 at the ends of the block)
+        double sr[NP][2], sq[NP][2], tr[NP][2], tq[NP][2];
 #pragma unroll
-        for (int t = 0; t < S; ++t) {
-            const double z0 = TDM_CPTR(zfs)[t * 2], z1 = TDM_CPTR(zfs)[t * 2 + 1];
-            const double v0 = TDM_CPTR(zbs)[t * 2], v1 = TDM_CPTR(zbs)[t * 2 + 1];
-            yr[t] = fma(z0, sr[0], fma(z1, sr[1], fma(v0, tr[0], fma(v1, tr[1], yr[t]))));
-            yi[t] = fma(z0, sq[0], fma(z1, sq[1], fma(v0, tq[0], fma(v1, tq[1], yi[t]))));
-            TDM_PIN(yr[t]);
-            TDM_PIN(yi[t]);
+        for (int s = 0; s < NP; ++s) {
+            cm.template wave_shr1<2>(zr[s], zq[s], sr[s], sq[s]);
+            cm.template wave_shl1<2>(ur[s], uq[s], tr[s], tq[s]);
         }
-        TDM_SCHED_FENCE();
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const double *zfs = P.pz + PzLayout::off_zf + s * S * 2;
+            const double *zbs = P.pz + PzLayout::off_zf + (NP + s) * S * 2;   // == off_zb(S) + s*S*2
+            TDM_OPAQUE_SPTR(zfs);
+            TDM_OPAQUE_SPTR(zbs);
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                const double z0 = TDM_CPTR(zfs)[t * 2], z1 = TDM_CPTR(zfs)[t * 2 + 1];
+                const double v0 = TDM_CPTR(zbs)[t * 2], v1 = TDM_CPTR(zbs)[t * 2 + 1];
+                yr[t] = fma(z0, sr[s][0], fma(z1, sr[s][1], fma(v0, tr[s][0], fma(v1, tr[s][1], yr[t]))));
+                yi[t] = fma(z0, sq[s][0], fma(z1, sq[s][1], fma(v0, tq[s][0], fma(v1, tq[s][1], yi[t]))));
+                TDM_PIN(yr[t]);
+                TDM_PIN(yi[t]);
+            }
+        }
     }
     // the last extended sample (the anticausal start needs it, see pz_carry_last): 2 x[n-1] - x[n-1-edge]
     if (last_blk && lane == 0) {

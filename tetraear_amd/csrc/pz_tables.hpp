@@ -40,7 +40,8 @@ struct PzLayout {
     TDM_HD static int off_AG(int S) { return off_zb(S) + S * kMaxPairs * 2; }    // [D][D] V <- causal carry into the last block
     TDM_HD static int off_AE(int S) { return off_AG(S) + kMaxD * kMaxD; }        // [D][D] V <- exported lane state of the last block
     TDM_HD static int off_wx(int S) { return off_AE(S) + kMaxD * kMaxD; }        // [D]    V <- ext[last]
-    TDM_HD static int size(int S) { return off_wx(S) + kMaxD; }
+    TDM_HD static int off_rowm(int S) { return off_wx(S) + kMaxD; }              // [16][NP][4] C^(L (r+1)), r = position in a 16-lane row
+    TDM_HD static int size(int S) { return off_rowm(S) + 16 * kMaxPairs * 4; }
 };
 
 namespace detail {
@@ -157,11 +158,17 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
     t.off_Mblast = reserve((size_t)D * D);
     t.off_Ureg = reserve((size_t)D * D);   // stays zero: the two banks do not couple
     t.off_Ulast = reserve((size_t)D * D);
+    if (blob.size() & 1) reserve(1);   // 16-byte alignment of the block (its lane tables are read as pairs)
     t.off_pz = reserve((size_t)PzLayout::size(S));
     auto prow = [&](int m, int R) { return (size_t)(m % qs) * R + (size_t)(m / qs); };
 
-    // ---- scan matrices C^(L 2^j); block transitions
+    // ---- scan matrices C^(L 2^j); lane-distance matrices of the cross-row scan steps; block transitions
     for (int s = 0; s < NP; ++s) {
+        for (int r = 0; r < 16; ++r) {
+            const M2 m = m2pow(C[s], (long)L * (r + 1));
+            double *o = &blob[t.off_pz + PzLayout::off_rowm(S) + ((size_t)r * PzLayout::kMaxPairs + s) * 4];
+            o[0] = (double)m.a; o[1] = (double)m.b; o[2] = (double)m.c; o[3] = (double)m.d;
+        }
         for (int j = 0; j < kScanSteps; ++j) {
             const M2 m = m2pow(C[s], (long)L << j);
             double *o = &blob[t.off_Mpow + ((size_t)s * kScanSteps + j) * 4];

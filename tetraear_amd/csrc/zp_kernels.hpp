@@ -37,16 +37,23 @@ namespace tdm {
 // exact-rounding helpers (no FMA contraction) for the few places where the reference's own
 // rounding sequence defines the data (cu8 -> float conversion, slicer products)
 // ------------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-TDM_HD double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-TDM_HD double add_rn(double a, double b) { return __dadd_rn(a, b); }
-TDM_HD double sub_rn(double a, double b) { return __dsub_rn(a, b); }
-#else
-// host builds of this header use -ffp-contract=off
-TDM_HD double mul_rn(double a, double b) { return a * b; }
-TDM_HD double add_rn(double a, double b) { return a + b; }
-TDM_HD double sub_rn(double a, double b) { return a - b; }
-#endif
+// (HIP's __dmul_rn / __dsub_rn are plain operators and get contracted into one v_fma_f64 with a neighbouring
+// operation under the default -ffp-contract=fast-honor-pragmas; the pragma is what keeps the two roundings)
+TDM_HD double mul_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+TDM_HD double add_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+TDM_HD double sub_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
 
 #if defined(__HIPCC__)
 #define TDM_NOINLINE __host__ __device__ __attribute__((noinline))
