@@ -37,7 +37,7 @@ def make_batch(carriers, chunk, fmt, rank):
     base = [synth.dqpsk_cu8(chunk, SAMPLE_RATE, seed=1000 * (rank + 1) + i, carrier_offset=0.0)[0]
             for i in range(distinct)]
     u8 = np.concatenate([base[i % distinct] for i in range(carriers)])
-    foffs = np.array([((i * 7) % 21 - 10) * 117.1875 for i in range(carriers)], dtype=np.float64)
+    foffs = np.array([((i * 5) % 21 - 10) * 117.1875 for i in range(carriers)], dtype=np.float64)
     if fmt == "cu8":
         return u8, foffs
     x = synth.cu8_to_c128(u8)
@@ -46,6 +46,33 @@ def make_batch(carriers, chunk, fmt, rank):
     if fmt == "cf64":
         return x, foffs
     raise ValueError(fmt)
+
+
+def output_digest(hard, n_soft, best_phase):
+    """SHA-256 over everything the hot path decided for the batch: per carrier the symbol count, the timing
+    phase picked and the hard symbols.  Bit-exact work, so the digest is the same on every MI355X."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(n_soft, dtype=np.int32).tobytes())
+    h.update(np.ascontiguousarray(best_phase, dtype=np.int32).tobytes())
+    for r in range(len(n_soft)):
+        h.update(np.ascontiguousarray(hard[r, :max(int(n_soft[r]) - 1, 0)]).tobytes())
+    return h.hexdigest()
+
+
+def digest_key(carriers, chunk, fmt, rate, rank, shared):
+    return f"{fmt}:{carriers}x{chunk}@{rate:g}:rank{rank}" + (":shared" if shared else "")
+
+
+def expected_digest(key):
+    """Digests of the default workloads, pinned to the CPU oracle by tools/make_bench_digest.py (which compares every
+    carrier of the batch with the oracle before it writes the file) and re-checked by tests/test_gpu_parity.py."""
+    path = os.path.join(HERE, "tests", "golden", "bench_digest.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(key)
+    except OSError:
+        return None
 
 
 def measured_traffic(samples_per_launch, fmt, key="k1"):
@@ -179,6 +206,14 @@ def main():
 
     hard, soft, n_soft, bp, mm = bd.download()
     sym_per_step = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
+    # the output of the last timed step is checked, not just counted: its digest must equal the one pinned to the oracle
+    dkey = digest_key(args.carriers, args.chunk, args.fmt, args.rate, rank, args.shared)
+    digest, want = output_digest(hard, n_soft, bp), expected_digest(dkey)
+    if want is not None and digest != want and not args.zero_foff:
+        raise SystemExit(f"bench: output digest {digest} differs from the oracle-pinned {want} for {dkey}")
+    output_check = {"key": dkey, "sha256": digest,
+                    "status": "matches oracle-pinned digest" if want == digest else
+                              ("no pinned digest for this workload" if want is None else "not compared")}
 
     from tetraear_amd.shard import reduce_job
     dt, total_sym_per_step = reduce_job(dist, dt, sym_per_step, device="cuda" if dist is not None else None)
@@ -213,6 +248,7 @@ def main():
                        "carriers_per_gpu": args.carriers, "chunk_samples": args.chunk, "in_fmt": args.fmt,
                        "mode": "reference", "parallelism": f"carriers sharded over {world} GPU(s), no data-path collective"},
             "realtime_carriers": value * 1e6 / sym_rate_per_carrier,
+            "output_check": output_check,
             "event_ms_per_step_rank0": ev_ms / args.steps,
             "stage_ms_per_launch": stage_ms,
             "roofline": {

@@ -109,10 +109,18 @@ def test_stage_methods(gold_stages, SP):
     close(p.resample(x[:301], 3.0e6), g["resample_up"], 1e-12)
     # 1-ulp threshold probes: decisions depend on the last bit of libm's atan2; require agreement
     # on every probe that is not within 4 ulp of a threshold
-    probe = p.demodulate_dqpsk(g["demod_probe_in"])
+    seq = g["demod_probe_in"]
+    probe = p.demodulate_dqpsk(seq)
     ref = g["demod_probe"]
     assert len(probe) == len(ref)
-    assert np.mean(probe == ref) > 0.6
+    ph = np.angle(seq[1:] * np.conj(seq[:-1]))
+    thr = np.array([-5 * np.pi / 8, -3 * np.pi / 8, 3 * np.pi / 8, 5 * np.pi / 8])
+    dist_ulp = np.min(np.abs(ph[:, None] - thr[None, :]) / np.spacing(np.abs(thr))[None, :], axis=1)
+    differ = np.nonzero(probe != ref)[0]
+    print("threshold probes that differ from the reference (index, phase, ulps from the threshold):",
+          [(int(i), float(ph[i]), float(dist_ulp[i])) for i in differ])
+    assert np.all(dist_ulp[differ] <= 4), "a decision more than 4 ulp from every threshold differs"
+    assert np.array_equal(probe[dist_ulp > 4], ref[dist_ulp > 4])
 
 
 def test_reference_style_contracts(SP):
@@ -296,9 +304,12 @@ def test_random_lengths_and_rates_vs_oracle():
     from tetraear_amd.signal.processor import SignalProcessor
     rng = np.random.default_rng(77)
     rates = [2.4e6, 2.4e6, 1.8e6, 2.048e6, 960000.0, 480000.0, 240000.0, 72000.0, 3.2e6, 10e6]
+    # the GUI's sample-rate control is continuous (ui/modern.py:3915-3917): seeded arbitrary rates, 0.5 .. 10.5 MS/s
+    # (every decimation factor 2 .. 43, i.e. both decimator engines), beside the RTL-SDR ones
+    rates += [float(np.round(r, 1)) for r in np.random.default_rng(78).uniform(0.5e6, 10.5e6, 14)]
     specials = [27, 28, 29, 150, 161, 5119, 5120, 5121, 20480, 20481, 6144, 131071, 131072, 262145]
     procs = {}
-    for it in range(120):
+    for it in range(160):
         fs = rates[rng.integers(len(rates))]
         n = int(specials[it % len(specials)]) if it % 3 == 0 else int(rng.integers(1, 300000 if it % 10 == 1 else 40000))
         f = 0.0 if it % 4 == 0 else float(rng.uniform(-8000, 8000))
@@ -311,3 +322,39 @@ def test_random_lengths_and_rates_vs_oracle():
         assert len(p.symbols) == len(ref.symbols), (fs, n, f)
         if len(ref.symbols):
             assert np.max(np.abs(p.symbols - ref.symbols)) <= 1e-10 * (np.max(np.abs(ref.symbols)) or 1.0), (fs, n, f)
+
+
+def test_c4_full_batch_every_carrier_vs_oracle():
+    """BASELINE config 4 at its full size, the very batch bench.py times: 1024 carriers x 262144 cu8 samples through
+    BatchDemodulator.enqueue; every carrier's hard symbols and timing phase equal the C oracle's (8 signals x 21
+    offsets = 168 oracle runs), soft <= 1e-10, and the digest bench.py asserts after its timed region is this one."""
+    import bench
+    from tools.make_bench_digest import check_batch
+    digest, n_oracle, worst = check_batch(1024, 262144, 0)
+    assert n_oracle == 168 and worst <= SOFT_TOL
+    want = bench.expected_digest(bench.digest_key(1024, 262144, "cu8", bench.SAMPLE_RATE, 0, False))
+    assert want is not None and digest == want
+
+
+def test_decimate_entry_vs_goldens(gold_stages):
+    """tdm_decimate (the stand-alone scipy.signal.decimate entry) against the goldens of the imported scipy, both
+    engines: q = 7, 10, 41 run in parallel form, q = 23 on the cascade engine (checked against the oracle)."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from tetraear_amd import _lib, synth
+    L = _lib.load()
+    g = gold_stages
+    x = synth.cu8_to_c128(synth.noise_cu8(4000, int(g["x4000_seed"][0])))
+
+    def dec(q):
+        y = np.zeros((len(x) + q - 1) // q, dtype=np.complex128)
+        m = C.c_int64()
+        _lib.check(L.tdm_decimate(_lib.ptr(x), len(x), q, _lib.ptr(y), C.byref(m), 0))
+        assert m.value == len(y)
+        return y
+    for q in (7, 10, 41):
+        ref = g[f"decimate_q{q}"]
+        assert np.max(np.abs(dec(q) - ref)) <= 1e-12 * np.max(np.abs(ref)), q
+    import scipy.signal as sg                     # (present on the GPU box as in this container; the goldens above do not need it)
+    ref = sg.decimate(x, 23)
+    assert np.max(np.abs(dec(23) - ref)) <= 1e-12 * np.max(np.abs(ref))

@@ -270,3 +270,48 @@ def test_gpu_channeliser_random_configurations():
         sc = max(np.max(np.abs(ref)), 1e-30)
         for i, k in enumerate(probe):
             assert np.max(np.abs(y[k] - ref[i])) < 2e-5 * sc, (M, D, n, fmt, pitch, k)
+
+
+@pytest.mark.gpu
+def test_gpu_c5_full_size_wideband_chain():
+    """BASELINE config 5 at its full size: one 10 MS/s cu8 stream of 1 048 576 samples -> 400-channel filter bank
+    (D = 125, 80 kS/s per channel, 8389 samples each) -> TETRA-mode demodulation of every channel on the device.
+    Nine occupied channels (band edges, both sides of DC, neighbours) give back their transmitted dibits without
+    error, the device-chained result equals the host-chained one, the channeliser equals its fp64 definition on
+    the probe channels over the whole length, and the channels away from every carrier stay at the noise floor."""
+    from oracle import pfb_np
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    from tetraear_amd.channeliser import channelise
+    from tetraear_amd.wideband import WidebandReceiver
+    M, D, fs, n = 400, 125, 10e6, 1048576
+    ks = [0, 1, 57, 133, 199, 201, 310, 398, 399]
+    x, dibs = _wideband(n, fs, ks, M)
+    u8 = synth.quantise_cu8(x, scale=1.0 / (4.0 * np.sqrt(len(ks) + 1.0)))
+    rx = WidebandReceiver(fs, n, M, D, streams=1, fmt="cu8")
+    hard, n_sym, timing, margin = rx.process(u8)
+    assert hard.shape[:2] == (1, M) and rx.n_out == 8389
+    y = channelise(u8, "cu8", M, D)                                   # [400][8389] cf32
+    bd = BatchDemodulator(fs / D, y.shape[1], len(ks), "cf32", mode=MODE_TETRA)
+    hards, _, _, _ = bd.process(np.ascontiguousarray(y[ks]))
+    bd.close()
+    for i, k in enumerate(ks):
+        got = hard[0, k, :n_sym[0, k]]
+        np.testing.assert_array_equal(got, hards[i])
+        ber, lag = best_ber(got, dibs[k], edge=8)
+        assert n_sym[0, k] > 1850 and ber == 0.0, (k, ber, lag)
+    # channeliser against its definition at the full length (three probe channels: occupied, DC, empty)
+    xd = synth.cu8_to_c128(u8)
+    probe = [57, 0, 250]
+    ref = pfb_np.channelise(xd, M, D, channels=probe)
+    scale = np.max(np.abs(ref))
+    for i, k in enumerate(probe):
+        assert np.max(np.abs(y[k] - ref[i])) < 2e-5 * scale, k
+    # channels at least three slots from every carrier hold only the noise floor (the bank is oversampled: 80 kS/s per
+    # 25 kHz slot, so a carrier's energy also shows in its neighbours' transition bands)
+    near = np.zeros(M, dtype=bool)
+    for k in ks:
+        near[[(k + d) % M for d in range(-2, 3)]] = True
+    p_ch = np.mean(np.abs(y) ** 2, axis=1)
+    assert np.max(p_ch[~near]) < 5e-2 * np.min(p_ch[ks])
+    rx.close()
