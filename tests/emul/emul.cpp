@@ -28,7 +28,7 @@ struct Group {
     int nt;
     std::barrier<> bar;
     std::vector<double> slots;
-    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024 + 2 * 2200 + 4 * 2048) {}
+    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024 + 2 * 2200 + 4 * 2048 + (n > 256 ? Lp2Lds::kStage + Lp2Lds::kSmall + 64 : 0)) {}
 };
 
 struct EmuWaveComm {
@@ -80,6 +80,51 @@ struct EmuWaveComm {
     void shfl_up2(const double *a, const double *b, double *oa, double *ob, int d) { xchg<K>(a, b, oa, ob, lane - d); }
     template <int K>
     void shfl_down2(const double *a, const double *b, double *oa, double *ob, int d) { xchg<K>(a, b, oa, ob, lane + d); }
+};
+
+// workgroup of several wavefronts (lp2_kernels.hpp): shuffles stay inside a thread's own 64-lane wavefront, the barrier
+// is the whole group's (every thread runs the same sequence of exchanges)
+struct EmuWgComm {
+    Group *g;
+    int t;
+    int tid() const { return t; }
+    void sync() { g->bar.arrive_and_wait(); }
+    double *stage() { return &g->slots[(size_t)g->nt * 16 + 1024 + 2 * 2200 + 4 * 2048]; }
+    double *small() { return stage() + Lp2Lds::kStage; }
+    template <int K>
+    void gather0(const double *a, const double *b, double *oa, double *ob, int src_lane)
+    {
+        double *mine = &g->slots[(size_t)t * 16];
+        for (int k = 0; k < K; ++k) { mine[k] = a[k]; mine[8 + k] = b[k]; }
+        g->bar.arrive_and_wait();
+        if (src_lane >= 0) {
+            const double *from = &g->slots[(size_t)((t & ~63) + src_lane) * 16];
+            for (int k = 0; k < K; ++k) { oa[k] = from[k]; ob[k] = from[8 + k]; }
+        } else {
+            for (int k = 0; k < K; ++k) { oa[k] = 0; ob[k] = 0; }
+        }
+        g->bar.arrive_and_wait();
+    }
+    template <int K>
+    void row_shr2(const double *a, const double *b, double *oa, double *ob, int d) { const int l = t & 63; gather0<K>(a, b, oa, ob, (l & 15) >= d ? l - d : -1); }
+    template <int K>
+    void row_shl2(const double *a, const double *b, double *oa, double *ob, int d) { const int l = t & 63; gather0<K>(a, b, oa, ob, (l & 15) + d <= 15 ? l + d : -1); }
+    template <int K>
+    void row_total_prev2(const double *a, const double *b, double *oa, double *ob, int step)
+    {
+        const int row = (t & 63) >> 4;
+        gather0<K>(a, b, oa, ob, step == 0 ? ((row & 1) ? 16 * row - 1 : -1) : (row >= 2 ? 31 : -1));
+    }
+    template <int K>
+    void row_total_next2(const double *a, const double *b, double *oa, double *ob, int step)
+    {
+        const int row = (t & 63) >> 4;
+        gather0<K>(a, b, oa, ob, step == 0 ? ((row & 1) ? -1 : 16 * (row + 1)) : (row < 2 ? 32 : -1));
+    }
+    template <int K>
+    void wave_shr1(const double *a, const double *b, double *oa, double *ob) { const int l = t & 63; gather0<K>(a, b, oa, ob, l > 0 ? l - 1 : -1); }
+    template <int K>
+    void wave_shl1(const double *a, const double *b, double *oa, double *ob) { const int l = t & 63; gather0<K>(a, b, oa, ob, l < 63 ? l + 1 : -1); }
 };
 
 struct EmuBlockComm {
@@ -134,6 +179,16 @@ struct EmuBackend {
                 run_group(kWave, [&](int lane, Group *g) {
                     EmuWaveComm cm{g, lane};
                     pz_block_body<Q, S, EDGE>(P, ld, cm, lane, b, row);
+                });
+    }
+    template <class Src>
+    void lp2(const Lp2Params &P, const Src &src, int rows)
+    {
+        for (int row = 0; row < rows; ++row)
+            for (int c = 0; c < P.n_chunks; ++c)
+                run_group(kLp2Lanes, [&](int t, Group *g) {
+                    EmuWgComm cm{g, t};
+                    lp2_body(P, src, cm, c, row);
                 });
     }
     template <int K, int NSEC>
@@ -239,6 +294,17 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
     RefBuffers B;
     if (h.decimated) { dec.t = h.dec; dec.bind(rows); B.dec_params = dec.t.p; }
     if (h.lpf) { lpf.t = h.lpf_t; lpf.bind(rows); B.lpf_params = lpf.t.p; }
+    std::vector<double> zt, lp2p;
+    if (h.lp2.ok) {
+        B.lp2 = h.lp2.p;
+        zt.assign((size_t)rows * h.sps * B.lp2.zt_k * 2 + 2, std::numeric_limits<double>::quiet_NaN());
+        lp2p.assign((size_t)rows * B.lp2.n_chunks * kMaxSps + 2, std::numeric_limits<double>::quiet_NaN());
+        B.lp2.zt = zt.data();
+        B.lp2.partials = lp2p.data();
+        B.lp2.lane_m = h.lp2.lane_m.data();
+        B.lp2.cst = h.lp2.cst.data();
+        B.lp2.seeds = h.lp2.seeds.data();
+    }
     const double nan = std::numeric_limits<double>::quiet_NaN();
     std::vector<double> y((size_t)rows * h.n_dec * 2 + 2, nan), z((size_t)rows * h.n_dec * 2 + 2, nan);
     B.y = y.data();

@@ -31,6 +31,8 @@
 
 namespace tdm {
 
+constexpr int kPzExtraRows = 16;
+
 // layout of the parallel-form constant block ZpParams::pz (doubles); NP = pole pairs, S = outputs per lane
 struct PzLayout {
     static constexpr int kMaxPairs = 4;
@@ -72,49 +74,34 @@ inline M2 m2inv(const M2 &x)
 }
 }  // namespace detail
 
-// sos rows must be g*[1,2,1]/[1,a1,a2] (rows_are_lp121).  L = samples per lane (a multiple of out_stride
-// whenever S > 0 outputs per lane are tabulated), S = outputs per lane of the in-lane tables.
-inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n, int edge, int L, int S,
-                                    int64_t n_out, int out_stride)
+// Partial-fraction data of H(z)H(1/z) for a cascade of sections g*[1,2,1]/[1,a1,a2] (rows_are_lp121), in long double.
+struct PzDesign {
+    int NP = 0;                                  // pole pairs (= sections)
+    std::vector<detail::ldbl> a1, a2, b0, b1;    // all-pole recursion and two-tap output per pair
+    std::vector<detail::M2> C;                   // one-step transition of (w[n-1], w[n-2])
+    detail::ldbl dx = 0;                         // direct term
+    std::vector<detail::ldbl> AE;                // [D][D+1]: anticausal start (w'[Ne], w'[Ne+1]) per pair from the causal state
+                                                 // (w[Ne-1], w[Ne-2]) per pair (columns 0..D-1) and ext[Ne-1] (column D)
+};
+
+inline PzDesign design_pz(const double (*sos)[6], int nsec)
 {
     using namespace detail;
-    ZpHostTables t;
-    std::memset(&t.p, 0, sizeof(t.p));
-    ZpParams &p = t.p;
+    PzDesign d;
     const int NP = nsec, D = 2 * nsec, N = 2 * nsec;
-    p.nsec = nsec;
-    p.K = 2;
-    p.pform = 1;
-    for (int s = 0; s < nsec; ++s) {
-        p.b[s][0] = 1; p.b[s][1] = 2; p.b[s][2] = 1;
-        for (int k = 0; k < 3; ++k) p.a[s][k] = sos[s][3 + k];
-    }
-    p.in_gain = 1.0;
-    p.n = n;
-    p.edge = edge;
-    p.L = L;
-    p.P0 = (L - edge % L) % L;
-    p.k0L = p.P0 + edge;
-    p.Ne = p.P0 + n + 2 * (int64_t)edge;
-    const int64_t Bn = (int64_t)kWave * L;
-    p.nb = (int32_t)((p.Ne + Bn - 1) / Bn);
-    p.len_last = (int32_t)(p.Ne - (int64_t)(p.nb - 1) * Bn);
-    p.n_out = n_out;
-    p.out_stride = out_stride;
-    const int qs = out_stride, len_last = p.len_last;
-
-    // ---- poles, residues (long double, from the double-precision coefficients)
+    d.NP = NP;
     ldbl kgain = 1;
     std::vector<lcx> pl(N);   // pl[2s] = pole with Im > 0 of section s, pl[2s+1] its conjugate
-    std::vector<ldbl> a1(NP), a2(NP);
+    d.a1.resize(NP); d.a2.resize(NP); d.b0.resize(NP); d.b1.resize(NP); d.C.resize(NP);
     for (int s = 0; s < nsec; ++s) {
         kgain *= (ldbl)sos[s][0];
-        a1[s] = sos[s][4];
-        a2[s] = sos[s][5];
-        const ldbl disc = 4 * a2[s] - a1[s] * a1[s];   // > 0: complex pair
-        const lcx r(-a1[s] / 2, std::sqrt(disc) / 2);
+        d.a1[s] = sos[s][4];
+        d.a2[s] = sos[s][5];
+        const ldbl disc = 4 * d.a2[s] - d.a1[s] * d.a1[s];   // > 0: complex pair
+        const lcx r(-d.a1[s] / 2, std::sqrt(disc) / 2);
         pl[2 * s] = r;
         pl[2 * s + 1] = std::conj(r);
+        d.C[s] = M2{-d.a1[s], -d.a2[s], 1, 0};
     }
     const lcx one(1, 0);
     std::vector<lcx> res(N), cc(N), hinv(N);
@@ -135,20 +122,84 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
     const lcx D0 = kgain * kgain / prodp;     // G at z -> infinity
     lcx csum(0, 0);
     for (int i = 0; i < N; ++i) csum += cc[i];
-    std::vector<ldbl> b0(NP), b1(NP);
+    d.dx = (D0 - csum).real();
     for (int s = 0; s < NP; ++s) {
-        b0[s] = 2 * cc[2 * s].real();
-        b1[s] = -2 * (cc[2 * s] * std::conj(pl[2 * s])).real();
+        d.b0[s] = 2 * cc[2 * s].real();
+        d.b1[s] = -2 * (cc[2 * s] * std::conj(pl[2 * s])).real();
     }
-    std::vector<M2> C(NP);
-    for (int s = 0; s < NP; ++s) C[s] = M2{-a1[s], -a2[s], 1, 0};
+    // ---- edge map.  alpha_i = inclusive causal modal state at the last position: for the pole with Im > 0
+    // of pair s, alpha = w[last] - conj(p) w[last-1].  F = d0 x_last + sum_j r_j alpha_j is the forward
+    // output there; scipy continues it as a constant, which is the anticausal modal start
+    //   V_i = (1/H(1/p_i)) [ F/(1-p_i) - sum_j r_j p_j alpha_j / (1 - p_i p_j) ]      (at the first position past the end)
+    // and in biquad coordinates (w'[Ne], w'[Ne+1]) = (Im(p V)/Im p, Im V / Im p).
+    d.AE.assign((size_t)D * (D + 1), 0);
+    for (int col = 0; col <= D; ++col) {
+        std::vector<lcx> alpha(N, lcx(0, 0));
+        ldbl xl = 0;
+        if (col < D) {
+            const int s = col / 2;
+            const lcx al = (col % 2 == 0) ? one : -std::conj(pl[2 * s]);
+            alpha[2 * s] = al;
+            alpha[2 * s + 1] = std::conj(al);
+        } else {
+            xl = 1;
+        }
+        lcx F = d0 * xl;
+        for (int j = 0; j < N; ++j) F += res[j] * alpha[j];
+        for (int s = 0; s < NP; ++s) {
+            const lcx pi_ = pl[2 * s];
+            lcx acc = F / (one - pi_);
+            for (int j = 0; j < N; ++j) acc -= res[j] * pl[j] * alpha[j] / (one - pi_ * pl[j]);
+            const lcx V = acc / hinv[2 * s];
+            d.AE[(size_t)(2 * s) * (D + 1) + col] = (pi_ * V).imag() / pi_.imag();
+            d.AE[(size_t)(2 * s + 1) * (D + 1) + col] = V.imag() / pi_.imag();
+        }
+    }
+    return d;
+}
+
+// L = samples per lane (a multiple of out_stride whenever S > 0 outputs per lane are tabulated), S = outputs per
+// lane of the in-lane tables.
+inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n, int edge, int L, int S,
+                                    int64_t n_out, int out_stride)
+{
+    using namespace detail;
+    ZpHostTables t;
+    std::memset(&t.p, 0, sizeof(t.p));
+    ZpParams &p = t.p;
+    const int NP = nsec, D = 2 * nsec;
+    p.nsec = nsec;
+    p.K = 2;
+    p.pform = 1;
+    for (int s = 0; s < nsec; ++s) {
+        p.b[s][0] = 1; p.b[s][1] = 2; p.b[s][2] = 1;
+        for (int k = 0; k < 3; ++k) p.a[s][k] = sos[s][3 + k];
+    }
+    p.in_gain = 1.0;
+    p.n = n;
+    p.edge = edge;
+    p.L = L;
+    p.P0 = (L - edge % L) % L;
+    p.k0L = p.P0 + edge;
+    p.Ne = p.P0 + n + 2 * (int64_t)edge;
+    const int64_t Bn = (int64_t)kWave * L;
+    p.nb = (int32_t)((p.Ne + Bn - 1) / Bn);
+    p.len_last = (int32_t)(p.Ne - (int64_t)(p.nb - 1) * Bn);
+    p.n_out = n_out;
+    p.out_stride = out_stride;
+    const int qs = out_stride, len_last = p.len_last;
+    const PzDesign dz = design_pz(sos, nsec);
+    const std::vector<ldbl> &a1 = dz.a1, &a2 = dz.a2, &b0 = dz.b0, &b1 = dz.b1;
+    const std::vector<M2> &C = dz.C;
 
     std::vector<double> &blob = t.blob;
     auto reserve = [&](size_t cnt) { size_t o = blob.size(); blob.resize(o + cnt, 0.0); return o; };
     t.off_Mpow = reserve((size_t)nsec * kScanSteps * 4);
     t.off_zirh = reserve(1);
+    // the last block's tables run kPzExtraRows outputs past its end (both responses continued by their own recurrence):
+    // a consumer that walks whole groups of outputs (lp2_kernels.hpp) may then read rows of outputs the row does not have
     p.R_reg = (int32_t)((Bn + qs - 1) / qs);
-    p.R_last = (len_last + qs - 1) / qs;
+    p.R_last = (len_last + qs - 1) / qs + kPzExtraRows;
     t.off_cflast = reserve((size_t)D);
     t.off_T1reg = reserve((size_t)qs * p.R_reg * D);
     t.off_T2reg = reserve((size_t)qs * p.R_reg * D);
@@ -187,24 +238,29 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
     // ---- carry-response tables.  u_m = C^m e_kappa (first component):
     //   causal carry (w[-1], w[-2]) = e_kappa     -> output at offset m: b0 u_{m+1} + b1 u_m
     //   anticausal carry (w'[len], w'[len+1])     -> output at offset m: b0 u_{len-m} + b1 u_{len-m-1}
-    std::vector<ldbl> u((size_t)Bn + 2);
+    const int64_t ext = (int64_t)kPzExtraRows * qs;
+    std::vector<ldbl> ubuf((size_t)(Bn + 2 * ext + 4));
+    ldbl *u = ubuf.data() + ext + 1;   // u[-ext-1 .. Bn+ext+1]
     for (int s = 0; s < NP; ++s)
         for (int kap = 0; kap < 2; ++kap) {
             ldbl v0 = kap == 0 ? 1 : 0, v1 = kap == 0 ? 0 : 1;   // (w[n], w[n-1]) pair; u_0 = first comp of e_kappa
-            for (int64_t m = 0; m <= Bn + 1; ++m) {
-                u[(size_t)m] = v0;
+            for (int64_t m = 0; m <= Bn + ext + 1; ++m) {
+                u[m] = v0;
                 const ldbl nv = -a1[s] * v0 - a2[s] * v1;
                 v1 = v0;
                 v0 = nv;
             }
+            // the same sequence continued to negative indices: u[k-1] = -(u[k+1] + a1 u[k]) / a2
+            for (int64_t m = 0; m >= -ext; --m) u[m - 1] = -(u[m + 1] + a1[s] * u[m]) / a2[s];
             const int k = 2 * s + kap;
             for (int v = 0; v < 2; ++v) {
                 const int len = v ? len_last : (int)Bn;
                 const int R = v ? p.R_last : p.R_reg;
                 const size_t o1 = v ? t.off_T1last : t.off_T1reg, o2 = v ? t.off_T2last : t.off_T2reg;
-                for (int m = 0; m < len; ++m) {
-                    blob[o1 + prow(m, R) * D + k] = (double)(b0[s] * u[(size_t)m + 1] + b1[s] * u[(size_t)m]);
-                    blob[o2 + prow(m, R) * D + k] = (double)(b0[s] * u[(size_t)(len - m)] + b1[s] * u[(size_t)(len - m - 1)]);
+                const int64_t mend = v ? len + ext : len;
+                for (int64_t m = 0; m < mend; ++m) {
+                    blob[o1 + prow((int)m, R) * D + k] = (double)(b0[s] * u[m + 1] + b1[s] * u[m]);
+                    blob[o2 + prow((int)m, R) * D + k] = (double)(b0[s] * u[len - m] + b1[s] * u[len - m - 1]);
                 }
             }
             // in-lane tables: outputs of a lane at local positions t*qs
@@ -212,9 +268,9 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
             for (int tt = 0; tt < S; ++tt) {
                 const int m = tt * qs;
                 pz[PzLayout::off_zf + (s * S + tt) * 2 + kap] =
-                    (double)(b0[s] * u[(size_t)m + 1] + b1[s] * u[(size_t)m]);
+                    (double)(b0[s] * u[m + 1] + b1[s] * u[m]);
                 pz[PzLayout::off_zb(S) + (s * S + tt) * 2 + kap] =
-                    (double)(b0[s] * u[(size_t)(L - m)] + b1[s] * u[(size_t)(L - m - 1)]);
+                    (double)(b0[s] * u[L - m] + b1[s] * u[L - m - 1]);
             }
         }
     {
@@ -226,37 +282,10 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
             pz[PzLayout::off_b1 + s] = (double)b1[s];
             pz[PzLayout::off_g + s] = (double)(1 / (1 + a1[s] + a2[s]));
         }
-        pz[PzLayout::off_dx] = (double)(D0 - csum).real();
+        pz[PzLayout::off_dx] = (double)dz.dx;
     }
-    // ---- edge map.  alpha_i = inclusive causal modal state at the last position: for the pole with Im > 0
-    // of pair s, alpha = w[last] - conj(p) w[last-1].  F = d0 x_last + sum_j r_j alpha_j is the forward
-    // output there; scipy continues it as a constant, which is the anticausal modal start
-    //   V_i = (1/H(1/p_i)) [ F/(1-p_i) - sum_j r_j p_j alpha_j / (1 - p_i p_j) ]      (at the first position past the end)
-    // and in biquad coordinates (w'[Ne], w'[Ne+1]) = (Im(p V)/Im p, Im V / Im p).
     {
-        std::vector<ldbl> AE((size_t)D * (D + 1));   // column D = x_last
-        for (int col = 0; col <= D; ++col) {
-            std::vector<lcx> alpha(N, lcx(0, 0));
-            ldbl xl = 0;
-            if (col < D) {
-                const int s = col / 2;
-                const lcx al = (col % 2 == 0) ? one : -std::conj(pl[2 * s]);
-                alpha[2 * s] = al;
-                alpha[2 * s + 1] = std::conj(al);
-            } else {
-                xl = 1;
-            }
-            lcx F = d0 * xl;
-            for (int j = 0; j < N; ++j) F += res[j] * alpha[j];
-            for (int s = 0; s < NP; ++s) {
-                const lcx pi_ = pl[2 * s];
-                lcx acc = F / (one - pi_);
-                for (int j = 0; j < N; ++j) acc -= res[j] * pl[j] * alpha[j] / (one - pi_ * pl[j]);
-                const lcx V = acc / hinv[2 * s];
-                AE[(size_t)(2 * s) * (D + 1) + col] = (pi_ * V).imag() / pi_.imag();
-                AE[(size_t)(2 * s + 1) * (D + 1) + col] = V.imag() / pi_.imag();
-            }
-        }
+        const std::vector<ldbl> &AE = dz.AE;
         // the kernel exports the inclusive scan state of the lane that holds the last position, i.e. the state
         // after that lane's zero-padded tail: undo the kinv padded steps (a few dozen at most, mildly expanding)
         const int kinv = L - 1 - (len_last - 1) % L;

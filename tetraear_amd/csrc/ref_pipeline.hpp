@@ -17,6 +17,7 @@
 #include "ref_plan.hpp"
 #include "zp_kernels.hpp"
 #include "pz_kernels.hpp"
+#include "lp2_kernels.hpp"
 
 namespace tdm {
 
@@ -26,6 +27,7 @@ struct RefBuffers {
     double *y = nullptr;  // [rows][n_dec] c128: decimated (+freq_offset) signal
     double *z = nullptr;  // [rows][n_dec] c128: channel-filtered signal
     double *partials = nullptr;  // [rows][ceil(n_dec/kPowThreads)][kMaxSps] partial phase powers
+    Lp2Params lp2{};             // (h.lp2.ok) pointers bound for the backend
 };
 
 struct RefIO {
@@ -77,7 +79,18 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     const double *partials = nullptr;
     int n_pblk = 0;
     bool fix_in_finish = false;
-    if (h.lpf) {
+    if (h.lp2.ok) {
+        // fix-up + frequency_shift + filter_signal + phase powers in one kernel, output final and phase-major
+        if (h.decimated) {
+            Lp2SrcDec src{B.dec_params, io.freq_offset, h.rate_dec};
+            be.lp2(B.lp2, src, rows);
+        } else {
+            Lp2SrcPlain src{B.y, h.n_dec};
+            be.lp2(B.lp2, src, rows);
+        }
+        partials = B.lp2.partials;
+        n_pblk = B.lp2.n_chunks;
+    } else if (h.lpf) {
         // filter_signal(samples, 25000, current_rate)  (processor.py:264).  When decimated, the
         // loader finishes the decimator output (carry responses) and applies
         // frequency_shift(samples, freq_offset, current_rate) (processor.py:260-261) on the fly.
@@ -118,6 +131,10 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     fa.n_pblk = n_pblk;
     fa.use_fix = fix_in_finish;
     if (fix_in_finish) fa.fix = B.lpf_params;
+    if (h.lp2.ok) {
+        fa.zt = B.lp2.zt;
+        fa.zt_k = B.lp2.zt_k;
+    }
     static_assert(kFixBn == kWave * kLLpf, "finish evaluates the channel filter's fix-up with its block length");
     be.finish(fa, rows);
 }

@@ -7,6 +7,7 @@
 #include "design.hpp"
 #include "zp_tables.hpp"
 #include "pz_tables.hpp"
+#include "lp2_tables.hpp"
 
 namespace tdm {
 
@@ -63,6 +64,7 @@ struct RefPlanHost {
     int pz_S = 0;           // > 0: the decimator runs in parallel form with pz_S outputs per lane
     ZpHostTables dec;       // valid if decimated
     ZpHostTables lpf_t;     // valid if lpf
+    Lp2Host lp2;            // lp2.ok: the low-rate stage runs as one parallel-form kernel (lp2_kernels.hpp)
 };
 
 // sos rows b = g*[1,2,1], a -> device form (unit numerators, one input gain, matching zi)
@@ -124,6 +126,8 @@ inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidt
     }
     if (h.lpf)
         h.lpf_t = build_zp_tables(desc_from_tf(h.tf), h.n_dec, kEdgeTf, kLLpf, h.n_dec, 1);
+    if (allow_pz && h.lpf && h.sps > 1 && h.sps <= 32 && (!h.decimated || h.pz_S) && rows_are_lp121(h.tf.sos, 2))
+        h.lp2 = build_lp2(h.tf.sos, h.n_dec, kEdgeTf, h.sps, h.decimated ? &h.dec : nullptr, h.sos.sos);
     return h;
 }
 

@@ -22,6 +22,9 @@
 #ifdef TDM_ZP_TIMING
 __device__ unsigned long long g_zp_dbg[16];
 #endif
+#ifdef TDM_LP2_TIMING
+__device__ unsigned long long g_lp2_dbg[16];
+#endif
 #include "pfb_kernels.hpp"
 #include "gate_kernels.hpp"
 #include "detect_kernels.hpp"
@@ -142,6 +145,14 @@ struct WaveComm {
     }
 };
 
+// workgroup of kLp2Waves wavefronts (lp2_kernels.hpp): the wavefront shuffles of WaveComm + barrier and two LDS areas
+struct WgComm : WaveComm {
+    double *sml;
+    __device__ __forceinline__ double *small() { return sml; }
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+};
+
 constexpr int kFinishThreads = 256;
 
 struct BlockComm {
@@ -192,6 +203,18 @@ __global__ __launch_bounds__(64, (Q * S <= 32 ? 2 : 1)) void k_pz_block(const Zp
     __shared__ __attribute__((aligned(16))) double stg[PzEdgeGeom<Q * S, EDGE>::kDoubles];
     WaveComm cm{stg};
     pz_block_body<Q, S, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// low-rate stage in one kernel (lp2_kernels.hpp): grid = (chunks, rows), one workgroup of 8 wavefronts per chunk
+template <class Src>
+__global__ __launch_bounds__(kLp2Lanes, 2) void k_lp2(const Lp2Params P, const Src src)
+{
+    __shared__ __attribute__((aligned(16))) double stg[Lp2Lds::kStage];
+    __shared__ __attribute__((aligned(16))) double sml[Lp2Lds::kSmall];
+    WgComm cm;
+    cm.stg = stg;
+    cm.sml = sml;
+    lp2_body(P, src, cm, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 template <int K, int NSEC, bool FWD>
@@ -364,6 +387,12 @@ struct HipBackend {
         Scope s(*this, ST_DEC_BLOCK);
         hipLaunchKernelGGL((k_pz_block<Q, S, EDGE, SHIFT>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
     }
+    template <class Src>
+    void lp2(const Lp2Params &P, const Src &src, int rows)
+    {
+        Scope s(*this, ST_LPF_BLOCK);
+        hipLaunchKernelGGL((k_lp2<Src>), dim3(P.n_chunks, rows), dim3(kLp2Lanes), 0, stream, P, src);
+    }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
     {
@@ -472,6 +501,8 @@ struct tdm_plan {
     int rows = 0, fmt = 0, mode = 0, device = 0;
     DevZp dec, lpf;
     double *d_y = nullptr, *d_z = nullptr, *d_partials = nullptr;
+    double *d_zt = nullptr, *d_lp2p = nullptr, *d_lp2m = nullptr, *d_lp2s = nullptr, *d_lp2c = nullptr;   // lp2: phase-major filter output, chunk partials, lane matrices, seed rows
+    Lp2Params lp2{};
     // TETRA mode
     TetraParams tp{};
     float2 *d_ty = nullptr, *d_tsym = nullptr, *d_tstat = nullptr;
@@ -494,7 +525,7 @@ static void plan_free(tdm_plan *p)
     (void)hipSetDevice(p->device);
     p->dec.destroy();
     p->lpf.destroy();
-    void *ptrs[] = {p->d_y, p->d_z, p->d_partials, p->d_ty, p->d_tsym, p->d_tstat, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    void *ptrs[] = {p->d_zt, p->d_lp2p, p->d_lp2m, p->d_lp2s, p->d_lp2c, p->d_y, p->d_z, p->d_partials, p->d_ty, p->d_tsym, p->d_tstat, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -580,7 +611,25 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     HIP_TRY(hipEventCreate(&p->ev0));
     HIP_TRY(hipEventCreate(&p->ev1));
     if (h.decimated && (rc = p->dec.init(h.dec, n_carriers))) return rc;
-    if (h.lpf && (rc = p->lpf.init(h.lpf_t, n_carriers))) return rc;
+    if (h.lpf && !h.lp2.ok && (rc = p->lpf.init(h.lpf_t, n_carriers))) return rc;
+    if (h.lp2.ok) {
+        p->lp2 = h.lp2.p;
+        HIP_TRY(hipMalloc(&p->d_zt, (size_t)n_carriers * h.sps * p->lp2.zt_k * 2 * sizeof(double)));
+        HIP_TRY(hipMalloc(&p->d_lp2p, (size_t)n_carriers * p->lp2.n_chunks * kMaxSps * sizeof(double)));
+        HIP_TRY(hipMalloc(&p->d_lp2m, h.lp2.lane_m.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(p->d_lp2m, h.lp2.lane_m.data(), h.lp2.lane_m.size() * sizeof(double), hipMemcpyHostToDevice));
+        p->lp2.zt = p->d_zt;
+        p->lp2.partials = p->d_lp2p;
+        p->lp2.lane_m = p->d_lp2m;
+        HIP_TRY(hipMalloc(&p->d_lp2c, h.lp2.cst.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(p->d_lp2c, h.lp2.cst.data(), h.lp2.cst.size() * sizeof(double), hipMemcpyHostToDevice));
+        p->lp2.cst = p->d_lp2c;
+        if (!h.lp2.seeds.empty()) {
+            HIP_TRY(hipMalloc(&p->d_lp2s, h.lp2.seeds.size() * sizeof(double)));
+            HIP_TRY(hipMemcpy(p->d_lp2s, h.lp2.seeds.data(), h.lp2.seeds.size() * sizeof(double), hipMemcpyHostToDevice));
+            p->lp2.seeds = p->d_lp2s;
+        }
+    }
     const size_t nd = (size_t)n_carriers * h.n_dec * 2 * sizeof(double);
     HIP_TRY(hipMalloc(&p->d_y, nd));
     HIP_TRY(hipMalloc(&p->d_z, nd));
@@ -594,6 +643,14 @@ static void zp_timing_dump();
 #endif
 int tdm_plan_destroy(tdm_plan *plan)
 {
+#ifdef TDM_LP2_TIMING
+    {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lp2_dbg), sizeof(h)) == hipSuccess)
+            fprintf(stderr, "lp2 phases (memtime ticks): stage-in %llu fixup+nco %llu ext+pass1 %llu scans %llu pass2 %llu stage-out %llu store+power %llu\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+    }
+#endif
 #ifdef TDM_ZP_TIMING
     zp_timing_dump();
 #endif
@@ -663,6 +720,7 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     B.y = plan->d_y;
     B.z = plan->d_z;
     B.partials = plan->d_partials;
+    B.lp2 = plan->lp2;
     RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin};
     run_ref(be, plan->h, plan->rows, plan->fmt, B, io);
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));

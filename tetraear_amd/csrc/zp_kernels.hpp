@@ -126,7 +126,7 @@ struct NcoRunT {
         v.u &= ~uint64_t(0x1FFF);
         dd = v.d;
         sincos((double)STRIDE * dd, &si, &sr);
-        const double t = quot((double)(uint32_t)j, fs, rfs);
+        const double t = quot((double)(int32_t)j, fs, rfs);
         th_a = ci * t;
         const phasor p = nco_phasor(j, f, fs);
         ar = p.c; ai = p.s; wr = 1; wi = 0; j_a = j; j_cur = j;
@@ -136,7 +136,7 @@ struct NcoRunT {
     {
         const double ci = -(2.0 * M_PI) * f;
         const int64_t j = j_cur + STRIDE;
-        const double t = quot((double)(uint32_t)j, fs, rfs);
+        const double t = quot((double)(int32_t)j, fs, rfs);
         const double th = ci * t;
         j_cur = j;
         const double nwr = wr * sr - wi * si, nwi = wr * si + wi * sr;
@@ -1006,6 +1006,10 @@ struct FinishArgs {
     // carry responses, evaluated where it is gathered (zp_fixup_at<4> on `fix`, block length kFixBn)
     int32_t use_fix;
     ZpParams fix;
+    // zt != null: the filter output is final and stored phase-major by the low-rate kernel (lp2_kernels.hpp):
+    // sample p + sps*k of a row at zt[(row*sps + p)*zt_k + k]
+    const double *zt;
+    int64_t zt_k;
 };
 
 constexpr int kMaxSps = 32;       // phases a partial-power record holds
@@ -1103,7 +1107,11 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
     for (int64_t k = tid; k < ns; k += nt) {
         const int64_t j = best + k * stride;
         double re, im;
-        if (A.use_fix) {
+        if (A.zt) {
+            const double *sp = A.zt + (((int64_t)row * sps + best) * A.zt_k + k) * 2;
+            re = sp[0];
+            im = sp[1];
+        } else if (A.use_fix) {
             const int64_t pos = j + A.fix.k0L;
             const int b = (int)(pos / kFixBn);
             zp_fixup_at<4>(A.fix, row, b, (int)(pos - (int64_t)b * kFixBn), j, re, im);
