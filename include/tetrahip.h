@@ -119,6 +119,14 @@ TDM_API int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_s
                        double *soft, int32_t *n_soft, int32_t *best_phase, double *min_margin,
                        void *stream);
 TDM_API int tdm_plan_sync(tdm_plan *plan);
+/* Stream ordering of the stand-alone entry points.  Plans run on their own (non-blocking) stream, which has no implicit
+ * ordering with the null stream.  The device-pointer forms of tdm_spectrum_gate, tdm_channelise(_batch) and
+ * tdm_find_sync enqueue on the calling thread's CURRENT stream: the null stream until tdm_set_stream names another.
+ * To chain them with tdm_process_device on the device without any host synchronisation, make the plan's stream
+ * current:    tdm_plan_stream(plan, &s); tdm_set_stream(s);   (tdm_set_stream(NULL) restores the null stream)
+ * Without that, a tdm_dev_sync / tdm_plan_sync is required between stages that run on different streams.       */
+TDM_API int tdm_set_stream(void *stream);
+TDM_API int tdm_plan_stream(tdm_plan *plan, void **stream);
 /* Host-fed streaming: n_batches consecutive batches, each laid out like one
  * tdm_process call (n_carriers x n_samples back to back; outputs [n_batches][n_carriers][max_soft]...).
  * The host->device copy of batch i+1 and the device->host copy of batch i-1 overlap the kernels of
@@ -157,8 +165,8 @@ TDM_API int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int
  * +-12.5 kHz band mean / peak / peak bin, out-of-band noise floor, SNR rule.
  *  out [rows][8] = peak_freq_offset_hz, signal_power_db, peak_power_db, noise_floor_db, snr_db,
  *                  strong (0/1), afc_offset_hz, 0        afc [rows] (may be NULL) = afc_offset_hz
- * With device pointers the launch is asynchronous on the default stream and `afc` can be passed
- * straight to tdm_process_device as freq_offset_hz.                                                 */
+ * With device pointers the launch is asynchronous on the current stream (tdm_set_stream) and `afc` can be
+ * passed straight to a tdm_process_device that runs on the same stream as freq_offset_hz.             */
 TDM_API int tdm_spectrum_gate(const void *iq, int32_t in_fmt, int64_t row_stride, int64_t n_samples, int32_t rows,
                               double sample_rate, double *out, double *afc, int32_t device_pointers,
                               int32_t device);
@@ -175,8 +183,9 @@ TDM_API int tdm_detect(const double *x, int64_t n, int32_t rows, double sample_r
  * the bit stream itself, one byte per bit (from_bits = 1).  Row r holds n_units[r] entries at
  * units + r*row_stride.  positions [rows][max_pos] receives the accepted bit positions in order
  * (n_pos[r] may exceed max_pos: only max_pos are stored), max_corr[r] the reference's max correlation.
- * device_pointers != 0: units/n_units/positions/n_pos/max_corr are device memory (e.g. the `hard`
- * and `n_soft` buffers of tdm_process_device, with n_units = n_soft-1 prepared by the caller).      */
+ * device_pointers != 0: units/n_units/positions/n_pos/max_corr are device memory and the call is asynchronous on the
+ * current stream (tdm_set_stream); rows are then bounded by row_stride.  from_bits | 2: n_units holds symbols + 1,
+ * i.e. the `n_soft` buffer of tdm_process_device can be passed as it is (with its `hard` buffer as units).      */
 TDM_API int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_units, int32_t rows,
                           int32_t from_bits, double threshold, int32_t max_pos, int32_t *positions,
                           int32_t *n_pos, double *max_corr, int32_t device_pointers, int32_t device);

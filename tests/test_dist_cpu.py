@@ -76,3 +76,21 @@ def test_two_rank_job_matches_single_process():
         assert s == total                  # sum over ranks
         got.update(dict(digest))
     assert got == expect
+
+
+def test_strong_scaling_partition_covers_the_batch_once():
+    """bench.py --total-carriers: the ranks' slices of the one global batch are disjoint, in order and complete."""
+    import bench
+    from tetraear_amd.shard import carrier_range
+    total, chunk = 21, 512
+    iq, foffs = bench.make_batch(total, chunk, "cu8", 0)
+    per = len(iq) // total
+    for world in (1, 2, 4, 8):
+        parts, offs = [], []
+        for r in range(world):
+            lo, hi = carrier_range(total, r, world)
+            parts.append(iq[lo * per: hi * per])
+            offs.append(foffs[lo:hi])
+        assert np.array_equal(np.concatenate(parts), iq) and np.array_equal(np.concatenate(offs), foffs)
+        sizes = [len(o) for o in offs]
+        assert max(sizes) - min(sizes) <= 1

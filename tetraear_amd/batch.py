@@ -146,6 +146,16 @@ class BatchDemodulator:
     def sync(self):
         check(self.lib.tdm_plan_sync(self.handle))
 
+    def make_stream_current(self):
+        """The stand-alone device-pointer entry points (gate, channeliser, find_sync) called from this thread now enqueue on
+        this plan's stream, i.e. in order with `enqueue` and without a host synchronisation in between."""
+        s = C.c_void_p()
+        check(self.lib.tdm_plan_stream(self.handle, C.byref(s)))
+        check(self.lib.tdm_set_stream(s))
+
+    def release_stream(self):
+        check(self.lib.tdm_set_stream(None))
+
     def download(self):
         d = self._dev
         rows, ms = self.n_carriers, self.info.max_soft

@@ -35,6 +35,10 @@ using namespace tdm;
 // error plumbing
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+// stream used by the device-pointer forms of the stand-alone entry points (gate, channeliser, find_sync):
+// the null stream unless the caller chose one with tdm_set_stream -- typically a plan's own stream, which puts
+// those launches in order with tdm_process_device without any host synchronisation
+static thread_local hipStream_t g_cur_stream = nullptr;
 
 static int fail(int code, const std::string &msg)
 {
@@ -296,13 +300,21 @@ __global__ __launch_bounds__(kFinishThreads) void k_detect(const DetectArgs A)
     detect_body(A, cm, (int)blockIdx.x);
 }
 
+// from_bits bit 0: units are bits (else dibit symbols); bit 1: n_units holds n_soft of tdm_process_device (symbols + 1)
+__device__ __forceinline__ int64_t sync_row_bits(int32_t n_units, int from_bits)
+{
+    int64_t n = n_units;
+    if (from_bits & 2) n = n > 0 ? n - 1 : 0;
+    return (from_bits & 1) ? n : 2 * n;
+}
+
 __global__ __launch_bounds__(256) void k_sync_count(const uint8_t *sym, int64_t row_stride, const int32_t *n_units,
                                                     int from_bits, int64_t max_bits, uint16_t *counts)
 {
     const int row = blockIdx.y;
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n_bits = from_bits ? (int64_t)n_units[row] : 2 * (int64_t)n_units[row];
-    sync_count_body(sym + (int64_t)row * row_stride, n_bits, pos, from_bits, counts + (int64_t)row * max_bits);
+    const int64_t n_bits = sync_row_bits(n_units[row], from_bits);
+    sync_count_body(sym + (int64_t)row * row_stride, n_bits, pos, from_bits & 1, counts + (int64_t)row * max_bits);
 }
 
 __global__ __launch_bounds__(64) void k_sync_walk(const uint16_t *counts, const int32_t *n_units, int from_bits,
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(64) void k_sync_walk(const uint16_t *counts, const 
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
-    const int64_t n_bits = from_bits ? (int64_t)n_units[row] : 2 * (int64_t)n_units[row];
+    const int64_t n_bits = sync_row_bits(n_units[row], from_bits);
     double mc;
     n_pos[row] = sync_walk_body(counts + (int64_t)row * max_bits, n_bits, threshold,
                                 positions + (int64_t)row * max_pos, max_pos, &mc);
@@ -736,6 +748,19 @@ static void zp_timing_dump()
             h[0], h[1], h[2], h[3], h[8], h[9], h[10], h[11]);
 }
 #endif
+
+int tdm_set_stream(void *stream)
+{
+    g_cur_stream = (hipStream_t)stream;
+    return TDM_OK;
+}
+
+int tdm_plan_stream(tdm_plan *plan, void **stream)
+{
+    if (!plan || !stream) return fail(TDM_ERR_INVALID, "null argument");
+    *stream = (void *)plan->stream;
+    return TDM_OK;
+}
 
 int tdm_plan_sync(tdm_plan *plan)
 {
@@ -1199,7 +1224,7 @@ int tdm_spectrum_gate(const void *iq, int32_t in_fmt, int64_t row_stride, int64_
         A.out = dout.as<double>();
         A.afc = dafc.as<double>();
     }
-    hipLaunchKernelGGL(k_gate, dim3(rows), dim3(kFinishThreads), 0, 0, A);
+    hipLaunchKernelGGL(k_gate, dim3(rows), dim3(kFinishThreads), 0, device_pointers ? g_cur_stream : nullptr, A);
     HIP_TRY(hipGetLastError());
     if (!device_pointers) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1243,18 +1268,18 @@ int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_uni
     const int32_t *nu = n_units;
     int32_t *pp = positions, *np_ = n_pos;
     double *mc = max_corr;
-    std::vector<int32_t> hn(rows);
-    if (device_pointers) {
-        HIP_TRY(hipMemcpy(hn.data(), n_units, rows * sizeof(int32_t), hipMemcpyDeviceToHost));
-    } else {
-        std::memcpy(hn.data(), n_units, rows * sizeof(int32_t));
+    const int unit_bits = (from_bits & 1) ? 1 : 2;
+    int64_t max_units = row_stride;   // device pointers: the counts stay on the device, rows are bounded by their stride
+    if (!device_pointers) {
+        max_units = 0;
+        for (int r = 0; r < rows; ++r) {
+            const int64_t nr = (from_bits & 2) ? (n_units[r] > 0 ? n_units[r] - 1 : 0) : n_units[r];
+            if (nr < 0 || nr > row_stride) return fail(TDM_ERR_INVALID, "n_units out of range");
+            if (nr > max_units) max_units = nr;
+        }
     }
-    int64_t max_units = 0;
-    for (int r = 0; r < rows; ++r) {
-        if (hn[r] < 0 || hn[r] > row_stride) return fail(TDM_ERR_INVALID, "n_units out of range");
-        if (hn[r] > max_units) max_units = hn[r];
-    }
-    const int64_t max_bits = (from_bits ? max_units : 2 * max_units) + 1;
+    const int64_t max_bits = unit_bits * max_units + 1;
+    hipStream_t st = device_pointers ? g_cur_stream : nullptr;
     if (!device_pointers) {
         if ((rc = du.alloc((size_t)rows * row_stride + 1)) || (rc = dn.alloc(rows * 4)) ||
             (rc = dp.alloc((size_t)rows * max_pos * 4)) || (rc = dnp.alloc(rows * 4)) || (rc = dmc.alloc(rows * 8)))
@@ -1263,15 +1288,31 @@ int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_uni
         HIP_TRY(hipMemcpy(dn.p, n_units, rows * 4, hipMemcpyHostToDevice));
         u = du.as<uint8_t>(); nu = dn.as<int32_t>(); pp = dp.as<int32_t>(); np_ = dnp.as<int32_t>(); mc = dmc.as<double>();
     }
-    if ((rc = dcnt.alloc((size_t)rows * max_bits * 2))) return rc;
-    hipLaunchKernelGGL(k_sync_count, dim3((unsigned)((max_bits + 255) / 256), rows), dim3(256), 0, 0, u, row_stride, nu,
-                       from_bits, max_bits, dcnt.as<uint16_t>());
+    // scratch for the per-position counts: pooled per thread for the device-pointer form (asynchronous: it must outlive
+    // the call), released with the call otherwise
+    uint16_t *cnt = nullptr;
+    const size_t cnt_bytes = (size_t)rows * max_bits * 2;
+    if (device_pointers) {
+        static thread_local void *pool = nullptr;
+        static thread_local size_t pool_bytes = 0;
+        if (pool_bytes < cnt_bytes) {
+            if (pool) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pool); pool = nullptr; pool_bytes = 0; }
+            HIP_TRY(hipMalloc(&pool, cnt_bytes));
+            pool_bytes = cnt_bytes;
+        }
+        cnt = (uint16_t *)pool;
+    } else {
+        if ((rc = dcnt.alloc(cnt_bytes))) return rc;
+        cnt = dcnt.as<uint16_t>();
+    }
+    hipLaunchKernelGGL(k_sync_count, dim3((unsigned)((max_bits + 255) / 256), rows), dim3(256), 0, st, u, row_stride, nu,
+                       from_bits, max_bits, cnt);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_sync_walk, dim3((rows + 63) / 64), dim3(64), 0, 0, dcnt.as<uint16_t>(), nu, from_bits, max_bits,
+    hipLaunchKernelGGL(k_sync_walk, dim3((rows + 63) / 64), dim3(64), 0, st, cnt, nu, from_bits, max_bits,
                        rows, threshold, pp, max_pos, np_, mc);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
     if (!device_pointers) {
+        HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(positions, dp.p, (size_t)rows * max_pos * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(n_pos, dnp.p, rows * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(max_corr, dmc.p, rows * 8, hipMemcpyDeviceToHost));
@@ -1462,11 +1503,11 @@ int tdm_channelise_batch(const void *iq, int32_t in_fmt, int64_t n_in, int32_t n
 #ifndef TDM_PFB80
 #define TDM_PFB80 32, 3
 #endif
-    case 96: rc = launch_pfb<8, 12, 3, TDM_PFB96>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 72: rc = launch_pfb<8, 9, 3, TDM_PFB72>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 80: rc = launch_pfb<8, 10, 3, TDM_PFB80>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 128: rc = launch_pfb<8, 16, 3, TDM_PFB128>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
-    case 400: rc = launch_pfb<20, 20, 3, 32, 1>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, 0, sync); break;
+    case 96: rc = launch_pfb<8, 12, 3, TDM_PFB96>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, device_pointers ? g_cur_stream : nullptr, sync); break;
+    case 72: rc = launch_pfb<8, 9, 3, TDM_PFB72>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, device_pointers ? g_cur_stream : nullptr, sync); break;
+    case 80: rc = launch_pfb<8, 10, 3, TDM_PFB80>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, device_pointers ? g_cur_stream : nullptr, sync); break;
+    case 128: rc = launch_pfb<8, 16, 3, TDM_PFB128>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, device_pointers ? g_cur_stream : nullptr, sync); break;
+    case 400: rc = launch_pfb<20, 20, 3, 32, 1>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, device_pointers ? g_cur_stream : nullptr, sync); break;
     default: return fail(TDM_ERR_UNSUPPORTED, "channeliser built for M in {72, 80, 96, 128, 400}");
     }
     if (rc) return rc;

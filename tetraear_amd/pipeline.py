@@ -31,7 +31,6 @@ class CaptureChain:
         self.dev["use_foff"] = True              # process() reads the gate's AFC offsets from device memory
         rows = self.rows
         self.d_gate = DeviceBuffer(device, rows * 8 * 8)
-        self.d_nun = DeviceBuffer(device, rows * 4)
         self.d_pos = [DeviceBuffer(device, rows * self.max_pos * 4) for _ in LADDER]
         self.d_npos = [DeviceBuffer(device, rows * 4) for _ in LADDER]
         self.d_mc = [DeviceBuffer(device, rows * 8) for _ in LADDER]
@@ -41,19 +40,22 @@ class CaptureChain:
         the gate's figures, `symbols` (uint8, None when the gate did not pass), `sync_positions`, `max_corr`."""
         L, d, rows = self.lib, self.dev, self.rows
         d["iq"].upload(iq)
-        check(L.tdm_spectrum_gate(d["iq"].ptr, self.bd.fmt, self.n, self.n, rows, self.fs, self.d_gate.ptr,
-                                  d["foff"].ptr, 1, self.device))
-        check(L.tdm_dev_sync(self.device))     # gate: default stream; plan: its own stream
-        self.bd.enqueue()
+        # one stream, no host round trip: gate -> process (AFC offsets read on the device) -> sync ladder on the hard
+        # symbols in place (symbol counts read on the device: n_soft as it is, from_bits = 2)
+        self.bd.make_stream_current()
+        try:
+            check(L.tdm_spectrum_gate(d["iq"].ptr, self.bd.fmt, self.n, self.n, rows, self.fs, self.d_gate.ptr,
+                                      d["foff"].ptr, 1, self.device))
+            self.bd.enqueue()
+            ms = self.bd.info.max_soft
+            for i, thr in enumerate(LADDER):
+                check(L.tdm_find_sync(d["hard"].ptr, ms, d["n_soft"].ptr, rows, 2, float(thr), self.max_pos,
+                                      self.d_pos[i].ptr, self.d_npos[i].ptr, self.d_mc[i].ptr, 1, self.device))
+        finally:
+            self.bd.release_stream()
         self.bd.sync()
         n_soft = d["n_soft"].download(np.int32, rows)
         n_units = np.maximum(n_soft - 1, 0).astype(np.int32)
-        self.d_nun.upload(n_units)
-        ms = self.bd.info.max_soft
-        for i, thr in enumerate(LADDER):
-            check(L.tdm_find_sync(d["hard"].ptr, ms, self.d_nun.ptr, rows, 0, float(thr), self.max_pos,
-                                  self.d_pos[i].ptr, self.d_npos[i].ptr, self.d_mc[i].ptr, 1, self.device))
-        check(L.tdm_dev_sync(self.device))
         gate = self.d_gate.download(np.float64, rows * 8).reshape(rows, 8)
         hard = d["hard"].download(np.uint8, rows * ms).reshape(rows, ms)
         pos = [b.download(np.int32, rows * self.max_pos).reshape(rows, self.max_pos) for b in self.d_pos]
@@ -81,5 +83,5 @@ class CaptureChain:
 
     def close(self):
         self.bd.close()
-        for b in [self.d_gate, self.d_nun] + self.d_pos + self.d_npos + self.d_mc:
+        for b in [self.d_gate] + self.d_pos + self.d_npos + self.d_mc:
             b.free()

@@ -41,16 +41,23 @@ class WidebandReceiver:
         if iq.nbytes != self.d_in.nbytes:
             raise ValueError(f"iq holds {iq.nbytes} bytes, receiver needs {self.d_in.nbytes}")
         self.d_in.upload(iq)
-        no = C.c_int64()
-        check(self.lib.tdm_channelise_batch(self.d_in.ptr, self.fmt, self.n_in, self.streams, self.M, self.D,
-                                            self.d_ch.ptr, self.pitch, C.byref(no), 1, self.device))
-        check(self.lib.tdm_dev_sync(self.device))      # channeliser: default stream; demodulator: the plan's stream
-        self.demod.enqueue(iq_ptr=self.d_ch.ptr, stride=self.pitch)
+        self.enqueue()
         self.demod.sync()
         hard, soft, n_soft, timing, margin = self.demod.download()
         shape = (self.streams, self.M)
         n_sym = np.maximum(n_soft - 1, 0).reshape(shape)
         return hard.reshape(shape + (-1,)), n_sym, timing.reshape(shape), margin.reshape(shape)
+
+    def enqueue(self):
+        """channeliser and demodulator back to back on the demodulator plan's stream (no host synchronisation)"""
+        no = C.c_int64()
+        self.demod.make_stream_current()
+        try:
+            check(self.lib.tdm_channelise_batch(self.d_in.ptr, self.fmt, self.n_in, self.streams, self.M, self.D,
+                                                self.d_ch.ptr, self.pitch, C.byref(no), 1, self.device))
+            self.demod.enqueue(iq_ptr=self.d_ch.ptr, stride=self.pitch)
+        finally:
+            self.demod.release_stream()
 
     def channel_frequency(self, k):
         """centre frequency of channel k relative to the stream's centre [Hz]"""
