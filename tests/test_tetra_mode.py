@@ -85,6 +85,36 @@ def test_gpu_tetra_noise_and_silence_do_not_crash():
     bd.close()
 
 
+@pytest.mark.gpu
+def test_gpu_tetra_every_rate_in_the_contract_and_nonfinite_input():
+    """Channel rates whose RRC length is not one the kernel is instantiated for (45 / 50 / 60 kHz: 21, 23, 27 taps) run
+    with the taps centred in the next length up and still equal the fp64 definition; a NaN / Inf sample in one
+    carrier spoils that carrier only and never makes the symbol stage index outside its row."""
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    for fs in (45000.0, 50000.0, 60000.0, 36000.0, 144000.0):
+        n = 6000
+        x, dib = make_signal(n, fs, 77, 0.2, 30.0, 20.0)
+        bd = BatchDemodulator(fs, n, 1, "cf32", mode=MODE_TETRA)
+        hards, softs, timing, margin = bd.process(x)
+        ref_hard, _, info = tetra_np.demod(x.astype(np.complex128), fs)
+        np.testing.assert_array_equal(hards[0], ref_hard)
+        # (at exactly 2 samples per symbol the square-law timing statistic has no margin: agreement with the
+        # definition is required there, error-free reception from 2.5 samples per symbol up)
+        assert best_ber(hards[0], dib, edge=8)[0] <= (0.0 if fs >= 45000.0 else 5e-3), fs
+        bd.close()
+    n, fs = 8192, 72000.0
+    good, dib = make_signal(n, fs, 5, 0.1, 0.0, 20.0)
+    bad = good.copy()
+    bad[1000] = np.nan
+    bad[5000] = np.inf
+    bd = BatchDemodulator(fs, n, 3, "cf32", mode=MODE_TETRA)
+    hards, softs, timing, margin = bd.process(np.concatenate([bad, good, bad]))
+    assert best_ber(hards[1], dib, edge=8)[0] == 0.0
+    assert all(np.all(h <= 3) for h in hards)
+    bd.close()
+
+
 def _wideband(n, fs, ks, M, seed0=300, snr_db=25.0):
     """Sum of pi/4-DQPSK carriers on the channeliser grid (channel index k -> k*fs/M, k >= M/2 negative)."""
     acc = np.zeros(n, dtype=np.complex128)

@@ -521,6 +521,7 @@ struct tdm_plan {
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
+    bool staging_ready = false;
     double *d_pre = nullptr, *d_foff = nullptr, *d_soft = nullptr, *d_margin = nullptr;
     uint8_t *d_hard = nullptr;
     int32_t *d_nsoft = nullptr, *d_bp = nullptr;
@@ -591,6 +592,19 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             return fail(TDM_ERR_UNSUPPORTED, "TETRA mode chunk length must be 64..131072 samples");
         std::vector<double> h = tetra_rrc_taps(sps);
         if ((int)h.size() > kRrcMaxTaps) return fail(TDM_ERR_UNSUPPORTED, "too many RRC taps");
+        {
+            // the matched-filter kernel is instantiated for these (odd) lengths: centre the taps in the next one up,
+            // zeros either side (same filter, same alignment), so that every rate in the 2..8 samples/symbol contract runs
+            static const int kInst[] = {17, 25, 33, 35, 41, 49, 57, 65};
+            int nt = 0;
+            for (int c : kInst)
+                if (c >= (int)h.size()) { nt = c; break; }
+            if (!nt) return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel for this tap count");
+            const int pad = (nt - (int)h.size()) / 2;
+            std::vector<double> hp((size_t)nt, 0.0);
+            for (size_t i = 0; i < h.size(); ++i) hp[i + pad] = h[i];
+            h.swap(hp);
+        }
         TetraParams &tp = p->tp;
         tp.n = (int32_t)n_samples;
         tp.ntaps = (int32_t)h.size();
@@ -642,10 +656,14 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             p->lp2.seeds = p->d_lp2s;
         }
     }
+    // y: the low-rate signal when nothing downstream forms it on the fly (no decimation, or no channel filter);
+    // z / partials: only the cascade-engine fallback of the low-rate stage materialises them
     const size_t nd = (size_t)n_carriers * h.n_dec * 2 * sizeof(double);
-    HIP_TRY(hipMalloc(&p->d_y, nd));
-    HIP_TRY(hipMalloc(&p->d_z, nd));
-    HIP_TRY(hipMalloc(&p->d_partials, (size_t)n_carriers * (h.n_dec / kPowThreads + 16) * kMaxSps * sizeof(double)));
+    if (!h.decimated || !h.lpf) HIP_TRY(hipMalloc(&p->d_y, nd));
+    if (!h.lp2.ok) {
+        if (h.lpf && !(h.sps > 1 && h.sps <= kMaxSps)) HIP_TRY(hipMalloc(&p->d_z, nd));
+        HIP_TRY(hipMalloc(&p->d_partials, (size_t)n_carriers * (h.n_dec / kPowThreads + 16) * kMaxSps * sizeof(double)));
+    }
     *out = p.release();
     return TDM_OK;
 }
@@ -775,6 +793,7 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
                 double *min_margin)
 {
     if (!plan || !iq || !hard || !soft || !n_soft) return fail(TDM_ERR_INVALID, "null argument");
+    if (carrier_stride_samples < 0) return fail(TDM_ERR_INVALID, "negative carrier stride");
     HIP_TRY(hipSetDevice(plan->device));
     const RefPlanHost &h = plan->h;
     const int rows = plan->rows;
@@ -788,14 +807,19 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
         HIP_TRY(hipMalloc(&plan->d_iq, bytes));
         plan->d_iq_bytes = bytes;
     }
-    if (!plan->d_soft) {
-        HIP_TRY(hipMalloc(&plan->d_pre, rows * sizeof(double)));
-        HIP_TRY(hipMalloc(&plan->d_foff, rows * sizeof(double)));
-        HIP_TRY(hipMalloc(&plan->d_soft, (size_t)rows * h.max_soft * 2 * sizeof(double)));  // cf32 in TETRA mode uses half
-        HIP_TRY(hipMalloc(&plan->d_hard, (size_t)rows * h.max_soft));
-        HIP_TRY(hipMalloc(&plan->d_nsoft, rows * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&plan->d_bp, rows * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&plan->d_margin, rows * sizeof(double)));
+    if (!plan->staging_ready) {
+        // all or nothing: a failed allocation leaves the flag clear, the next call starts over (plan_free releases
+        // whatever a failed attempt left behind)
+        void **slots[] = {(void **)&plan->d_pre, (void **)&plan->d_foff, (void **)&plan->d_soft, (void **)&plan->d_hard,
+                          (void **)&plan->d_nsoft, (void **)&plan->d_bp, (void **)&plan->d_margin};
+        const size_t sizes[] = {rows * sizeof(double), rows * sizeof(double),
+                                (size_t)rows * h.max_soft * 2 * sizeof(double),   // cf32 in TETRA mode uses half
+                                (size_t)rows * h.max_soft, rows * sizeof(int32_t), rows * sizeof(int32_t), rows * sizeof(double)};
+        for (int i = 0; i < 7; ++i) {
+            if (*slots[i]) { (void)hipFree(*slots[i]); *slots[i] = nullptr; }
+            HIP_TRY(hipMalloc(slots[i], sizes[i]));
+        }
+        plan->staging_ready = true;
     }
     hipStream_t st = plan->stream;
     HIP_TRY(hipMemcpyAsync(plan->d_iq, iq, bytes, hipMemcpyHostToDevice, st));
@@ -840,6 +864,10 @@ int tdm_process_pipelined(tdm_plan *plan, const void *iq, int64_t n_batches, con
     double *d_fo = nullptr;
     int rc = TDM_OK;
     auto cleanup = [&]() {
+        // copies and kernels may still be in flight on the error path: drain before buffers and pins go away
+        if (s_in) (void)hipStreamSynchronize(s_in);
+        if (s_out) (void)hipStreamSynchronize(s_out);
+        (void)hipStreamSynchronize(plan->stream);
         for (auto &x : sl) {
             void *ps[] = {x.iq, x.hard, x.soft, x.ns, x.bp, x.mm};
             for (void *q : ps) if (q) (void)hipFree(q);

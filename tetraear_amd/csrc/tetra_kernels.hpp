@@ -192,7 +192,7 @@ struct FarrowTaps {
 };
 __device__ __forceinline__ void farrow_load(const float2 *y, double t, FarrowTaps &f)
 {
-    const int m = (int)floor(t);
+    const int m = (int)floor(t);   // (callers keep 1 <= t <= n-3; tau is sanitised in k_tetra_sym)
     f.mu = (float)(t - (double)m);
     f.ym1 = y[m - 1];
     f.y0 = y[m];
@@ -281,7 +281,12 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
     for (int b = tid; b < nb; b += kSymThreads) {
         const int hi = min(nb, b + kTimingHalfWin + 1), lo = max(0, b - kTimingHalfWin);
         const float cr = Cr[hi] - Cr[lo], ci = Ci[hi] - Ci[lo];
-        tau[b] = -atan2f(ci, cr) * 0.15915494309189535f;  // / (2 pi)
+        float tb = -atan2f(ci, cr) * 0.15915494309189535f;  // / (2 pi)
+        // a non-finite input sample makes the statistic NaN and the prefix sums carry it to every later sub-block:
+        // such a carrier demodulates garbage, but it must not index outside its row (the range checks below are
+        // false for NaN)
+        if (!(fabsf(tb) <= 1.0f)) tb = 0.f;
+        tau[b] = tb;
     }
     __syncthreads();
     if (tid == 0) {
