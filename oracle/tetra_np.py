@@ -120,3 +120,66 @@ def demod(x, sample_rate):
     margin = np.min(np.minimum(np.arctan2(np.abs(dd.imag), np.abs(dd.real)),
                                np.pi / 2 - np.arctan2(np.abs(dd.imag), np.abs(dd.real))))
     return hard, dd, dict(tau=tau_b, delta=delta, n_sym=len(s), t=t, sym=s, margin=margin)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Comparison receiver: the textbook feedback loop BASELINE.json's north_star names (Gardner timing-error detector +
+# proportional-integral loop filter + Farrow interpolator), fp64, strictly sequential.  It is NOT what the device
+# runs -- the device runs the feed-forward estimator above, which has no recurrence over symbols and is therefore
+# fully parallel -- it exists so that tests/test_tetra_gardner.py can show, point by point over Es/N0, timing offset
+# and carrier offset, that the substitution costs nothing in symbol error rate or timing jitter.
+# ------------------------------------------------------------------------------------------------------------------
+def _farrow1(y, t):
+    m = int(np.floor(t))
+    mu = t - m
+    ym1, y0, y1, y2 = y[m - 1], y[m], y[m + 1], y[m + 2]
+    c1 = y1 - ym1 / 3 - y0 / 2 - y2 / 6
+    c2 = (ym1 + y1) / 2 - y0
+    c3 = (y2 - ym1) / 6 + (y0 - y1) / 2
+    return ((c3 * mu + c2) * mu + c1) * mu + y0
+
+
+def demod_gardner(x, sample_rate, bn_t=0.01, zeta=0.7071):
+    """Gardner TED (e_k = Re{(s_k - s_{k-1}) conj(s_{k-1/2})}, normalised by the running symbol power) -> PI loop
+    (noise bandwidth bn_t symbol rates, damping zeta) -> period-controlled Farrow interpolation of the matched-filter
+    output; then the same differential detection, 4th-power carrier-offset estimate and quadrant slicer as demod().
+    Returns (hard, derotated d_k, info with the symbol instants `t`)."""
+    x = np.asarray(x, dtype=np.complex128)
+    sps = sample_rate / SYMBOL_RATE
+    y = matched_filter(x, rrc_taps(sps))
+    n = len(y)
+    # loop constants (Rice, Digital Communications, eq. C.61) for detector gain kp (S-curve slope of the
+    # normalised Gardner detector for RRC alpha 0.35, about 2.7 per symbol) and unit NCO gain
+    kp = 2.7
+    th = bn_t / (zeta + 0.25 / zeta)
+    k1 = 4 * zeta * th / (1 + 2 * zeta * th + th * th) / kp
+    k2 = 4 * th * th / (1 + 2 * zeta * th + th * th) / kp
+    t = 1.0 + sps          # first symbol instant (the loop pulls it onto the eye)
+    integ = 0.0
+    pw = 1.0               # running symbol power
+    ts, s = [], []
+    prev = None
+    while t <= n - 3.0:
+        sk = _farrow1(y, t)
+        if prev is not None:
+            mid = _farrow1(y, t - 0.5 * sps * (1.0 - integ))
+            pw = 0.99 * pw + 0.01 * (abs(sk) ** 2)
+            e = ((sk - prev) * np.conj(mid)).real / max(pw, 1e-12)
+            integ += k2 * e
+            v = k1 * e + integ
+        else:
+            v = 0.0
+        ts.append(t)
+        s.append(sk)
+        prev = sk
+        t += sps * (1.0 - v)     # (a late strobe makes e positive: shorten the period)
+    s = np.array(s)
+    ts = np.array(ts)
+    d = s[1:] * np.conj(s[:-1])
+    if len(d) == 0:
+        return np.zeros(0, np.uint8), d, dict(t=ts)
+    acc = np.sum(d ** 4)
+    delta = np.angle(-acc) / 4 if acc != 0 else 0.0
+    dd = d * np.exp(-1j * delta)
+    hard = np.where(dd.imag >= 0, np.where(dd.real >= 0, 0, 1), np.where(dd.real >= 0, 2, 3)).astype(np.uint8)
+    return hard, dd, dict(t=ts, delta=delta)
