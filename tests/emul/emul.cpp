@@ -28,7 +28,7 @@ struct Group {
     int nt;
     std::barrier<> bar;
     std::vector<double> slots;
-    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024 + 2 * 2200 + 4 * 2048 + (n > 256 ? Lp2Lds::kStage + Lp2Lds::kSmall + 64 : 0)) {}
+    explicit Group(int n) : nt(n), bar(n), slots((size_t)n * 16 + 1024 + 2 * 2200 + 4 * 2048 + (n > 64 ? Lp2Lds::kStage + Lp2Lds::kSmall + 64 : 0)) {}
 };
 
 struct EmuWaveComm {
@@ -194,6 +194,12 @@ struct EmuBackend {
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
     {
+        if (P.pform) {
+            for (int row = 0; row < rows; ++row)
+                for (int b = nb - 1; b >= 0; --b)   // (any order: every thread is self-contained)
+                    for (int ch = 0; ch < 2; ++ch) pz_carry_body<NSEC>(P, row, b, ch);
+            return;
+        }
         for (int row = 0; row < rows; ++row)
             for (int b = 0; b < nb; ++b)
                 for (int ch = 0; ch < 2; ++ch) zp_carry_fwd_body<K, NSEC>(P, row, b, ch);

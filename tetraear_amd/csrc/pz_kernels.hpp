@@ -490,4 +490,71 @@ TDM_HD void pz_carry_last(const ZpParams &P, int row, int ch, const double *G)
     }
 }
 
+// Both carries of a parallel-form stage in ONE pass (the two banks do not couple, so the anticausal carry of a block
+// needs no other block's causal carry -- except through the start state at the end of the row, which the few
+// threads near the end recompute for themselves).  Transitions are block-diagonal: 2x2 per pole pair.
+//     Gf[b] = Mf Gf[b-1] + Ef[b-1],   Hb[b-1] = Mb(b) Hb[b] + Eb[b],   Hb[nb-1] from pz_carry_last's formula
+// each evaluated as the Horner form of its series over P.carry_terms blocks (see zp_carry_fwd_body).
+template <int NSEC>
+TDM_HD void pz_carry_body(const ZpParams &P, int row, int b, int ch)
+{
+    constexpr int D = 2 * NSEC;
+    const int nb = P.nb, terms = P.carry_terms;
+    const int64_t base = (int64_t)row * nb * D * 2 + ch;
+    const double *Ef = P.Ef + base, *Eb = P.Eb + base;
+    const auto Mf = TDM_CPTR(P.Mf), Ml = TDM_CPTR(P.Mb_last);
+    auto step = [&](const auto &M, double *v, const double *e) {   // v <- M v + e, M block-diagonal
+#pragma unroll
+        for (int s = 0; s < NSEC; ++s) {
+            const double a = v[2 * s], c = v[2 * s + 1];
+            v[2 * s] = fma(M[(2 * s) * D + 2 * s], a, fma(M[(2 * s) * D + 2 * s + 1], c, e[(2 * s) * 2]));
+            v[2 * s + 1] = fma(M[(2 * s + 1) * D + 2 * s], a, fma(M[(2 * s + 1) * D + 2 * s + 1], c, e[(2 * s + 1) * 2]));
+        }
+    };
+    auto causal_carry = [&](int blk, double *G) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) G[k] = 0;
+        for (int bb = blk - terms > 0 ? blk - terms : 0; bb < blk; ++bb) step(Mf, G, Ef + (int64_t)bb * D * 2);
+    };
+    auto row_end_start = [&](const double *G, double *H) {   // pz_carry_last's formula
+        const int S = P.L / P.out_stride;
+        const auto AG = TDM_CPTR(P.pz + PzLayout::off_AG(S));
+        const auto AE = TDM_CPTR(P.pz + PzLayout::off_AE(S));
+        const auto wx = TDM_CPTR(P.pz + PzLayout::off_wx(S));
+        const double *El = P.Elast + (int64_t)row * D * 2 + ch;
+        const double xl = P.flast[(int64_t)row * 2 + ch];
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            double acc = wx[r] * xl;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += AG[r * D + k] * G[k] + AE[r * D + k] * El[k * 2];
+            H[r] = acc;
+        }
+    };
+    double G[D], H[D];
+    causal_carry(b, G);
+#pragma unroll
+    for (int k = 0; k < D; ++k) P.Gf[base + ((int64_t)b * D + k) * 2] = G[k];
+    if (b == nb - 1) {
+        row_end_start(G, H);
+    } else {
+        int far = b + terms;
+        if (far >= nb - 1) {
+            far = nb - 1;
+            double Gl[D];
+            causal_carry(nb - 1, Gl);
+            row_end_start(Gl, H);
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) H[k] = 0;
+        }
+        for (int bb = far; bb > b; --bb) {
+            if (bb == nb - 1) step(Ml, H, Eb + (int64_t)bb * D * 2);
+            else step(Mf, H, Eb + (int64_t)bb * D * 2);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) P.Hb[base + ((int64_t)b * D + k) * 2] = H[k];
+}
+
 }  // namespace tdm

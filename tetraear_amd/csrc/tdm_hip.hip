@@ -236,6 +236,18 @@ __global__ __launch_bounds__(256) void k_zp_carry(const ZpParams P, int nb, int 
         zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
 }
 
+template <int NSEC>
+__global__ __launch_bounds__(256) void k_pz_carry(const ZpParams P, int nb, int rows)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = (int)(idx & 1);
+    const int64_t rb = idx >> 1;
+    const int b = (int)(rb % nb);
+    const int row = (int)(rb / nb);
+    if (row >= rows) return;
+    pz_carry_body<NSEC>(P, row, b, ch);
+}
+
 template <int D, int L>
 __global__ __launch_bounds__(256) void k_zp_fixup(const ZpParams P, double *out, int64_t out_row_stride,
                                                   const double *freq_offset, double fs_out)
@@ -411,6 +423,10 @@ struct HipBackend {
         Scope s(*this, NSEC == 4 ? ST_DEC_CARRY : ST_LPF_CARRY);
         const int64_t threads = (int64_t)rows * nb * 2;
         const unsigned blocks = (unsigned)((threads + 255) / 256);
+        if (P.pform) {   // both carries in one launch
+            hipLaunchKernelGGL((k_pz_carry<NSEC>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
+            return;
+        }
         hipLaunchKernelGGL((k_zp_carry<K, NSEC, true>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
         hipLaunchKernelGGL((k_zp_carry<K, NSEC, false>), dim3(blocks), dim3(256), 0, stream, P, nb, rows);
     }
