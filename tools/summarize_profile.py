@@ -39,7 +39,7 @@ def main():
     src = os.path.join(HERE, "gpurun_out", tag)
     dst = os.path.join(HERE, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for name in ("bench", "bench_tetra", "bench_pfb", "bench_single", "bench_cf64_256", "bench_shared64", "bench_wideband"):
+    for name in ("bench", "bench_forcedist_rccl", "bench_strong1024", "bench_tetra", "bench_pfb", "bench_single", "bench_cf64_256", "bench_shared64", "bench_wideband"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(dst, f"{tag}_{name}.json"))
@@ -50,9 +50,12 @@ def main():
                        "[--mode tetra --carriers 4096 | --mode pfb --carriers 12800] --steps 2 --warmup 1",
             "note": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM "
                     "section) -> doubled; WRITE_SIZE taken as is; counter unit KB"}
-    t = traffic(os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write"), "k_zp_block<2, 4, 32, 27", 1024 * 262144)
+    t = traffic(os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write"), "k_pz_block<10, 3, 27", 1024 * 262144)
     if t:
         prof["k1"] = t
+    t = traffic(os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write"), "k_lp2<", 1024 * 26215)
+    if t:
+        prof["lp2"] = t
     t = traffic(os.path.join(src, "pmc_tetra_fetch"), os.path.join(src, "pmc_tetra_write"), "k_tetra_rrc", 4096 * 32768)
     if t:
         prof["tetra_rrc"] = t
