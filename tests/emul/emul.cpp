@@ -181,6 +181,16 @@ struct EmuBackend {
                     pz_block_body<Q, S, EDGE>(P, ld, cm, lane, b, row);
                 });
     }
+    template <int Q, int S, int EDGE, int FMT8, bool WIDE>
+    void pz_raw(const ZpParams &P, const void *iq, int64_t stride, int blk_first, int b_tail, int nblk, int rows)
+    {
+        for (int row = 0; row < rows; ++row)
+            for (int idx = 0; idx < nblk; ++idx)
+                run_group(kWave, [&](int lane, Group *g) {
+                    EmuWaveComm cm{g, lane};
+                    pz_raw_body<Q, S, EDGE, FMT8, WIDE>(P, iq, stride, cm, lane, pz_raw_block(idx, blk_first, b_tail, WIDE), row);
+                });
+    }
     template <class Src>
     void lp2(const Lp2Params &P, const Src &src, int rows)
     {
@@ -281,22 +291,24 @@ static void small_dft_host(const float *in, float *out)
     }
 }
 
-static bool g_allow_pz = true;
+static bool g_allow_pz = true, g_allow_raw = true;
 
 extern "C" {
 
 // tests: 0 forces the cascade engine for every decimation factor (the generic fallback of the library)
 void emu_allow_parallel_form(int on) { g_allow_pz = on != 0; }
+// tests: 0 keeps cu8 plans on the kernel that holds its samples as doubles
+void emu_allow_raw_integer(int on) { g_allow_raw = on != 0; }
 
 // whole pipeline == tdm_process with host pointers
 int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq, int64_t stride,
                 const double *pre_shift, const double *freq_offset, uint8_t *hard, double *soft,
                 int32_t *n_soft, int32_t *best_phase, double *min_margin, int32_t *max_soft_out)
 {
-    RefPlanHost h = build_ref_plan(sample_rate, n, 25000.0, g_allow_pz);
+    RefPlanHost h = build_ref_plan(sample_rate, n, 25000.0, g_allow_pz, g_allow_raw ? fmt : -1);
     if (max_soft_out) *max_soft_out = (int32_t)h.max_soft;
     if (!iq) return 0;  // query only
-    HostZp dec, lpf;
+    HostZp dec, lpf, dec_raw;
     RefBuffers B;
     if (h.decimated) { dec.t = h.dec; dec.bind(rows); B.dec_params = dec.t.p; }
     if (h.lpf) { lpf.t = h.lpf_t; lpf.bind(rows); B.lpf_params = lpf.t.p; }
@@ -310,6 +322,20 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
         B.lp2.lane_m = h.lp2.lane_m.data();
         B.lp2.cst = h.lp2.cst.data();
         B.lp2.seeds = h.lp2.seeds.data();
+        if (h.raw_S) {
+            dec_raw.t = h.dec_raw;
+            dec_raw.bind(rows);
+            B.dec_raw_params = dec_raw.t.p;
+            B.lp2_raw = h.lp2_raw.p;
+            if (B.lp2_raw.n_chunks > B.lp2.n_chunks)
+                lp2p.assign((size_t)rows * B.lp2_raw.n_chunks * kMaxSps + 2, std::numeric_limits<double>::quiet_NaN());
+            B.lp2.partials = lp2p.data();
+            B.lp2_raw.zt = zt.data();
+            B.lp2_raw.partials = lp2p.data();
+            B.lp2_raw.lane_m = h.lp2.lane_m.data();
+            B.lp2_raw.cst = h.lp2_raw.cst.data();
+            B.lp2_raw.seeds = h.lp2_raw.seeds.data();
+        }
     }
     const double nan = std::numeric_limits<double>::quiet_NaN();
     std::vector<double> y((size_t)rows * h.n_dec * 2 + 2, nan), z((size_t)rows * h.n_dec * 2 + 2, nan);

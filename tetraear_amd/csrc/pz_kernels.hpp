@@ -241,84 +241,21 @@ struct RawLoaderRT {
 //   Comm: edge_slots() -> PzEdgeGeom<L,EDGE>::kDoubles doubles of wavefront-private scratch;
 //   shfl_up2<2> / shfl_down2<2> as in zp_block_body.
 // ------------------------------------------------------------------------------------------
-template <int Q, int S, int EDGE, class Loader, class Comm>
-TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lane, int blk, int row)
+// Phases 2 and 3 of a block, shared by the kernels that differ in how a lane holds its samples: scans of the lane
+// end states, exports of the block's end states, start-state responses at the lane's outputs, block-local outputs
+// (minus `y_const`: the response to a constant input offset that a kernel working on raw integers leaves out).
+template <int Q, int S, int EDGE, class Comm>
+TDM_HD void pz_block_finish(const ZpParams &P, Comm &cm, int lane, int blk, int row, double (*zr)[2], double (*zq)[2],
+                            double (*ur)[2], double (*uq)[2], double *yr, double *yi, double y_const)
 {
     constexpr int NP = PzLayout::kMaxPairs, D = 2 * NP;
     constexpr int L = Q * S;
     constexpr int Bn = kWave * L;
     typedef PzEdgeGeom<L, EDGE> G;
-    double xr[L], xi[L];
-    ld.template load<L, EDGE>(cm, row, blk, lane, P, xr, xi);
-
-    const auto pz = TDM_CPTR(P.pz);
-    const bool inject = (blk == 0 && lane == 0);
-    const double e0r = xr[G::P0], e0i = xi[G::P0];
     const int64_t nbD = (int64_t)P.nb * D;
     double *Ef = P.Ef + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
     double *Eb = P.Eb + ((int64_t)row * nbD + (int64_t)blk * D) * 2;
     const bool last_blk = (blk == P.nb - 1);
-
-    double yr[S], yi[S];
-    {
-        const double dx = pz[PzLayout::off_dx];
-#pragma unroll
-        for (int t = 0; t < S; ++t) { yr[t] = dx * xr[t * Q]; yi[t] = dx * xi[t * Q]; }
-    }
-
-    // ---------------- phase 1: the recurrences, one pole pair at a time ----------------
-    // causal bank left to right, anticausal bank right to left: four independent chains in flight
-    // (two directions x re/im).  End states of all pairs are kept for the scans of phase 2.
-    double zr[NP][2], zq[NP][2];   // causal end state (w[L-1], w[L-2]), re / im
-    double ur[NP][2], uq[NP][2];   // anticausal end state (w'[0], w'[1])
-#pragma unroll
-    for (int s = 0; s < NP; ++s) {
-        const double *cs = P.pz;
-        TDM_OPAQUE_SPTR(cs);   // (per-pair scalar loads: keeps all pairs' constants from being fetched at once)
-        const double na1 = -TDM_CPTR(cs)[PzLayout::off_a1 + s], na2 = -TDM_CPTR(cs)[PzLayout::off_a2 + s];
-        const double b0 = TDM_CPTR(cs)[PzLayout::off_b0 + s], b1 = TDM_CPTR(cs)[PzLayout::off_b1 + s];
-        double f1r = 0, f2r = 0, f1q = 0, f2q = 0;   // causal (w[n-1], w[n-2]), re / im
-        double a1r = 0, a2r = 0, a1q = 0, a2q = 0;   // anticausal (w'[n+1], w'[n+2])
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const int ib = L - 1 - i;
-            if (i == G::P0) {
-                // scipy's zi*ext[0]: constant history ext[0] before the first extended sample
-                const double g = TDM_CPTR(cs)[PzLayout::off_g + s];
-                f1r = inject ? g * e0r : f1r; f2r = inject ? g * e0r : f2r;
-                f1q = inject ? g * e0i : f1q; f2q = inject ? g * e0i : f2q;
-            }
-            {
-                const double wr = fma(na1, f1r, fma(na2, f2r, xr[i]));
-                const double wq = fma(na1, f1q, fma(na2, f2q, xi[i]));
-                if (i % Q == 0) {
-                    yr[i / Q] = fma(b0, wr, fma(b1, f1r, yr[i / Q]));
-                    yi[i / Q] = fma(b0, wq, fma(b1, f1q, yi[i / Q]));
-                    TDM_PIN(yr[i / Q]);
-                    TDM_PIN(yi[i / Q]);
-                }
-                f2r = f1r; f1r = wr;
-                f2q = f1q; f1q = wq;
-            }
-            {
-                const double wr = fma(na1, a1r, fma(na2, a2r, xr[ib]));
-                const double wq = fma(na1, a1q, fma(na2, a2q, xi[ib]));
-                if (ib % Q == 0) {
-                    yr[ib / Q] = fma(b0, wr, fma(b1, a1r, yr[ib / Q]));
-                    yi[ib / Q] = fma(b0, wq, fma(b1, a1q, yi[ib / Q]));
-                    TDM_PIN(yr[ib / Q]);
-                    TDM_PIN(yi[ib / Q]);
-                }
-                a2r = a1r; a1r = wr;
-                a2q = a1q; a1q = wq;
-            }
-        }
-        zr[s][0] = f1r; zr[s][1] = f2r; zq[s][0] = f1q; zq[s][1] = f2q;
-        ur[s][0] = a1r; ur[s][1] = a2r; uq[s][0] = a1q; uq[s][1] = a2q;
-        TDM_PIN(zr[s][0]); TDM_PIN(zr[s][1]); TDM_PIN(zq[s][0]); TDM_PIN(zq[s][1]);
-        TDM_PIN(ur[s][0]); TDM_PIN(ur[s][1]); TDM_PIN(uq[s][0]); TDM_PIN(uq[s][1]);
-        TDM_SCHED_FENCE();
-    }
     // ---------------- phase 2: inclusive scans of the lanes' end states ----------------
     // I_l = e_l + C^L I_{l -/+ 1}, all pairs and both directions per step (eight independent scans share each step's
     // latency).  The shuffles follow the hardware's lane rows: four Kogge-Stone steps inside each row of 16 lanes
@@ -445,13 +382,6 @@ TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             }
         }
     }
-    // the last extended sample (the anticausal start needs it, see pz_carry_last): 2 x[n-1] - x[n-1-edge]
-    if (last_blk && lane == 0) {
-        double re, im;
-        ld.ext_sample(ld.row_ptr(row), ld.row_shift(row), P.n + 2 * (int64_t)EDGE - 1, P.n, EDGE, re, im);
-        P.flast[(int64_t)row * 2] = re;
-        P.flast[(int64_t)row * 2 + 1] = im;
-    }
     // ---------------- block-local outputs: S consecutive decimated samples per lane ----------------
     {
         static_assert((G::P0 + EDGE) % Q == 0 || S == 0, "outputs sit on lane-local multiples of Q");
@@ -460,8 +390,307 @@ TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
         if ((int64_t)blk * Bn + (int64_t)lane * L >= P.k0L) {
 #pragma unroll
             for (int t = 0; t < S; ++t)
-                if (j0 + t < P.n_out) y0[j0 + t] = f64x2{yr[t], yi[t]};
+                if (j0 + t < P.n_out) y0[j0 + t] = f64x2{yr[t] - y_const, yi[t] - y_const};
         }
+    }
+}
+
+template <int Q, int S, int EDGE, class Loader, class Comm>
+TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lane, int blk, int row)
+{
+    constexpr int NP = PzLayout::kMaxPairs, D = 2 * NP;
+    constexpr int L = Q * S;
+    constexpr int Bn = kWave * L;
+    typedef PzEdgeGeom<L, EDGE> G;
+    double xr[L], xi[L];
+    ld.template load<L, EDGE>(cm, row, blk, lane, P, xr, xi);
+
+    const auto pz = TDM_CPTR(P.pz);
+    const bool inject = (blk == 0 && lane == 0);
+    const double e0r = xr[G::P0], e0i = xi[G::P0];
+    const bool last_blk = (blk == P.nb - 1);
+
+    double yr[S], yi[S];
+    {
+        const double dx = pz[PzLayout::off_dx];
+#pragma unroll
+        for (int t = 0; t < S; ++t) { yr[t] = dx * xr[t * Q]; yi[t] = dx * xi[t * Q]; }
+    }
+
+    // ---------------- phase 1: the recurrences, one pole pair at a time ----------------
+    // causal bank left to right, anticausal bank right to left: four independent chains in flight
+    // (two directions x re/im).  End states of all pairs are kept for the scans of phase 2.
+    double zr[NP][2], zq[NP][2];   // causal end state (w[L-1], w[L-2]), re / im
+    double ur[NP][2], uq[NP][2];   // anticausal end state (w'[0], w'[1])
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        const double *cs = P.pz;
+        TDM_OPAQUE_SPTR(cs);   // (per-pair scalar loads: keeps all pairs' constants from being fetched at once)
+        const double na1 = -TDM_CPTR(cs)[PzLayout::off_a1 + s], na2 = -TDM_CPTR(cs)[PzLayout::off_a2 + s];
+        const double b0 = TDM_CPTR(cs)[PzLayout::off_b0 + s], b1 = TDM_CPTR(cs)[PzLayout::off_b1 + s];
+        double f1r = 0, f2r = 0, f1q = 0, f2q = 0;   // causal (w[n-1], w[n-2]), re / im
+        double a1r = 0, a2r = 0, a1q = 0, a2q = 0;   // anticausal (w'[n+1], w'[n+2])
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int ib = L - 1 - i;
+            if (i == G::P0) {
+                // scipy's zi*ext[0]: constant history ext[0] before the first extended sample
+                const double g = TDM_CPTR(cs)[PzLayout::off_g + s];
+                f1r = inject ? g * e0r : f1r; f2r = inject ? g * e0r : f2r;
+                f1q = inject ? g * e0i : f1q; f2q = inject ? g * e0i : f2q;
+            }
+            {
+                const double wr = fma(na1, f1r, fma(na2, f2r, xr[i]));
+                const double wq = fma(na1, f1q, fma(na2, f2q, xi[i]));
+                if (i % Q == 0) {
+                    yr[i / Q] = fma(b0, wr, fma(b1, f1r, yr[i / Q]));
+                    yi[i / Q] = fma(b0, wq, fma(b1, f1q, yi[i / Q]));
+                    TDM_PIN(yr[i / Q]);
+                    TDM_PIN(yi[i / Q]);
+                }
+                f2r = f1r; f1r = wr;
+                f2q = f1q; f1q = wq;
+            }
+            {
+                const double wr = fma(na1, a1r, fma(na2, a2r, xr[ib]));
+                const double wq = fma(na1, a1q, fma(na2, a2q, xi[ib]));
+                if (ib % Q == 0) {
+                    yr[ib / Q] = fma(b0, wr, fma(b1, a1r, yr[ib / Q]));
+                    yi[ib / Q] = fma(b0, wq, fma(b1, a1q, yi[ib / Q]));
+                    TDM_PIN(yr[ib / Q]);
+                    TDM_PIN(yi[ib / Q]);
+                }
+                a2r = a1r; a1r = wr;
+                a2q = a1q; a1q = wq;
+            }
+        }
+        zr[s][0] = f1r; zr[s][1] = f2r; zq[s][0] = f1q; zq[s][1] = f2q;
+        ur[s][0] = a1r; ur[s][1] = a2r; uq[s][0] = a1q; uq[s][1] = a2q;
+        TDM_PIN(zr[s][0]); TDM_PIN(zr[s][1]); TDM_PIN(zq[s][0]); TDM_PIN(zq[s][1]);
+        TDM_PIN(ur[s][0]); TDM_PIN(ur[s][1]); TDM_PIN(uq[s][0]); TDM_PIN(uq[s][1]);
+        TDM_SCHED_FENCE();
+    }
+    pz_block_finish<Q, S, EDGE>(P, cm, lane, blk, row, zr, zq, ur, uq, yr, yi, 0.0);
+    // the last extended sample (the anticausal start needs it, see pz_carry_last): 2 x[n-1] - x[n-1-edge]
+    if (last_blk && lane == 0) {
+        double re, im;
+        ld.ext_sample(ld.row_ptr(row), ld.row_shift(row), P.n + 2 * (int64_t)EDGE - 1, P.n, EDGE, re, im);
+        P.flast[(int64_t)row * 2] = re;
+        P.flast[(int64_t)row * 2 + 1] = im;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same block for 8-bit wire formats with the samples kept as the raw integers (round-2 main kernel): a lane then
+// holds four times as many samples in the same registers (L = Q*S = 120 at q = 10), so the per-block work -- scans,
+// start-state responses -- is spread over four times as many samples.  The recurrences run on the integers
+// themselves (exactly representable); the wire format's affine map x = c*u - o (cu8: c = fl(1/127.5), o = 1; cs8:
+// c = 2^-7, o = 0) is applied through linearity: c is folded into the output taps and tables by the host
+// (build_pz_tables in_scale) and the response to the constant -o over the extended row, which scipy's edge recipe makes
+// exactly -o*H(1)^2 at every output, is subtracted from the block-local outputs.  Against the reference's own
+// two-rounding conversion this moves an input sample by at most one ulp of 1.0, far below the arithmetic's own noise.
+// Each sample is converted once per direction (cheap: byte -> f32 -> f64).
+//   WIDE = false : interior blocks, two samples per dword as they come off the wire
+//   WIDE = true  : the first block and the block(s) holding the tail extension: samples as int16 pairs, because the odd
+//                  extension 2 u[0] - u[k] does not fit a byte; extension lanes are filled through a small LDS buffer
+// ------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_OPAQUE)
+#define TDM_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#else
+#define TDM_OPAQUE_V(x)
+#endif
+// OPAQUE: the second conversion of a sample (other direction, many steps later) must not be recognised as the same
+// computation -- the compiler would keep the first result alive across the loop instead of converting again
+template <int FMT8, bool WIDE, bool OPAQUE>
+TDM_HD void pz_raw_cvt(const uint32_t *raw, int i, double &re, double &im)
+{
+    if (WIDE) {
+        uint32_t w = raw[i];
+        if (OPAQUE) TDM_OPAQUE_V(w);
+        re = (double)(int32_t)(int16_t)(w & 0xffffu);
+        im = (double)((int32_t)w >> 16);
+    } else {
+        uint32_t w = raw[i / 2];
+        if (OPAQUE) TDM_OPAQUE_V(w);
+        const int sh = 16 * (i % 2);
+        if (FMT8 == FMT_CU8) {
+            re = (double)(float)((w >> sh) & 0xffu);          // v_cvt_f32_ubyteN + v_cvt_f64_f32
+            im = (double)(float)((w >> (sh + 8)) & 0xffu);
+        } else {
+            re = (double)(int32_t)(int8_t)((w >> sh) & 0xffu);
+            im = (double)(int32_t)(int8_t)((w >> (sh + 8)) & 0xffu);
+        }
+    }
+}
+
+// integer sample k of the row (re, im)
+template <int FMT8>
+TDM_HD void pz_raw_sample(const void *rowp, int64_t k, int &re, int &im)
+{
+    if (FMT8 == FMT_CU8) {
+        const uint8_t *p = (const uint8_t *)rowp + 2 * k;
+        re = p[0];
+        im = p[1];
+    } else {
+        const int8_t *p = (const int8_t *)rowp + 2 * k;
+        re = p[0];
+        im = p[1];
+    }
+}
+
+template <int Q, int S, int EDGE, int FMT8, bool WIDE, class Comm>
+TDM_HD void pz_raw_body(const ZpParams &P, const void *iq, int64_t row_stride, Comm &cm, int lane, int blk, int row)
+{
+    constexpr int NP = PzLayout::kMaxPairs;
+    constexpr int L = Q * S;
+    constexpr int NR = WIDE ? L : L / 2;
+    static_assert(L % 2 == 0, "two samples per dword");
+    typedef PzEdgeGeom<L, EDGE> G;
+    const int64_t n = P.n;
+    const int64_t seg = (int64_t)blk * (kWave * L) + (int64_t)lane * L;
+    const int64_t e0 = seg - G::P0;   // ext index of the lane's first sample
+    const char *rowp = (const char *)iq + (int64_t)row * row_stride * 2;
+    uint32_t raw[NR];
+    if (e0 >= EDGE && e0 + L <= EDGE + n) {
+        const char *p = rowp + (e0 - EDGE) * 2;
+        uint32_t w[L / 2];
+        if ((((uintptr_t)p) & 3) == 0) {
+            const uint32_t *dw = (const uint32_t *)p;   // (4-byte aligned: merged into 16-byte loads)
+#pragma unroll
+            for (int c = 0; c < L / 2; ++c) w[c] = dw[c];
+        } else {
+            const uint16_t *h = (const uint16_t *)p;
+#pragma unroll
+            for (int c = 0; c < L / 2; ++c) w[c] = (uint32_t)h[2 * c] | ((uint32_t)h[2 * c + 1] << 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (WIDE) {
+                const uint32_t b = w[i / 2] >> (16 * (i % 2));
+                const int re = FMT8 == FMT_CU8 ? (int)(b & 0xffu) : (int)(int8_t)(b & 0xffu);
+                const int im = FMT8 == FMT_CU8 ? (int)((b >> 8) & 0xffu) : (int)(int8_t)((b >> 8) & 0xffu);
+                raw[i] = ((uint32_t)re & 0xffffu) | ((uint32_t)im << 16);
+            } else {
+                raw[i] = w[i];
+            }
+        }
+    } else if (!WIDE || e0 >= n + 2 * (int64_t)EDGE) {
+        // (nothing of the extended row in this lane; a narrow block never holds an extension sample: see the launch)
+#pragma unroll
+        for (int c = 0; c < NR; ++c) raw[c] = 0;
+    } else {
+        int slot;
+        if (e0 < EDGE) {
+            slot = (int)(seg / L);
+        } else {
+            const int64_t seg_t0 = ((G::P0 + EDGE + n) / L) * L;
+            slot = G::kHead + (int)((seg - seg_t0) / L);
+        }
+        uint32_t *buf = (uint32_t *)cm.edge_slots() + (size_t)slot * L;
+#pragma unroll 1
+        for (int i = 0; i < L; ++i) {
+            const int64_t e = e0 + i;
+            int re = 0, im = 0;
+            if (e >= 0 && e < n + 2 * (int64_t)EDGE) {
+                if (e < EDGE) {  // 2*x[0] - x[edge - e]
+                    int ar, ai;
+                    pz_raw_sample<FMT8>(rowp, 0, ar, ai);
+                    pz_raw_sample<FMT8>(rowp, EDGE - e, re, im);
+                    re = 2 * ar - re;
+                    im = 2 * ai - im;
+                } else if (e < EDGE + n) {
+                    pz_raw_sample<FMT8>(rowp, e - EDGE, re, im);
+                } else {  // 2*x[n-1] - x[n-2-(e-edge-n)]
+                    int ar, ai;
+                    pz_raw_sample<FMT8>(rowp, n - 1, ar, ai);
+                    pz_raw_sample<FMT8>(rowp, n - 2 - (e - EDGE - n), re, im);
+                    re = 2 * ar - re;
+                    im = 2 * ai - im;
+                }
+            }
+            buf[i] = ((uint32_t)re & 0xffffu) | ((uint32_t)im << 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) raw[i] = buf[i];
+    }
+
+    const auto pz = TDM_CPTR(P.pz);
+    const bool inject = (blk == 0 && lane == 0);
+    double e0r, e0i;
+    pz_raw_cvt<FMT8, WIDE, true>(raw, G::P0, e0r, e0i);
+    double yr[S], yi[S];
+    {
+        const double dx = pz[PzLayout::off_dx];
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            double xr, xi;
+            pz_raw_cvt<FMT8, WIDE, true>(raw, t * Q, xr, xi);
+            yr[t] = dx * xr;
+            yi[t] = dx * xi;
+        }
+    }
+    // ---------------- phase 1: all pole pairs per sample (a sample is converted once per direction) ----------------
+    double na1[NP], na2[NP], b0[NP], b1[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        na1[s] = -pz[PzLayout::off_a1 + s];
+        na2[s] = -pz[PzLayout::off_a2 + s];
+        b0[s] = pz[PzLayout::off_b0 + s];
+        b1[s] = pz[PzLayout::off_b1 + s];
+    }
+    double f1r[NP], f2r[NP], f1q[NP], f2q[NP], a1r[NP], a2r[NP], a1q[NP], a2q[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) { f1r[s] = 0; f2r[s] = 0; f1q[s] = 0; f2q[s] = 0; a1r[s] = 0; a2r[s] = 0; a1q[s] = 0; a2q[s] = 0; }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int ib = L - 1 - i;
+        if (i == G::P0) {
+            // scipy's zi*ext[0]: constant history ext[0] before the first extended sample
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const double g = pz[PzLayout::off_g + s];
+                f1r[s] = inject ? g * e0r : f1r[s]; f2r[s] = inject ? g * e0r : f2r[s];
+                f1q[s] = inject ? g * e0i : f1q[s]; f2q[s] = inject ? g * e0i : f2q[s];
+            }
+        }
+        double xfr, xfq, xbr, xbq;
+        pz_raw_cvt<FMT8, WIDE, true>(raw, i, xfr, xfq);
+        pz_raw_cvt<FMT8, WIDE, true>(raw, ib, xbr, xbq);
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const double wr = fma(na1[s], f1r[s], fma(na2[s], f2r[s], xfr)), wq = fma(na1[s], f1q[s], fma(na2[s], f2q[s], xfq));
+            if (i % Q == 0) {
+                yr[i / Q] = fma(b0[s], wr, fma(b1[s], f1r[s], yr[i / Q]));
+                yi[i / Q] = fma(b0[s], wq, fma(b1[s], f1q[s], yi[i / Q]));
+            }
+            f2r[s] = f1r[s]; f1r[s] = wr; f2q[s] = f1q[s]; f1q[s] = wq;
+            const double vr = fma(na1[s], a1r[s], fma(na2[s], a2r[s], xbr)), vq = fma(na1[s], a1q[s], fma(na2[s], a2q[s], xbq));
+            if (ib % Q == 0) {
+                yr[ib / Q] = fma(b0[s], vr, fma(b1[s], a1r[s], yr[ib / Q]));
+                yi[ib / Q] = fma(b0[s], vq, fma(b1[s], a1q[s], yi[ib / Q]));
+            }
+            a2r[s] = a1r[s]; a1r[s] = vr; a2q[s] = a1q[s]; a1q[s] = vq;
+        }
+        // one sample step at a time (see TDM_PIN): keeps conversions and chains of later steps from being hoisted
+#pragma unroll
+        for (int s = 0; s < NP; ++s) { TDM_PIN(f1r[s]); TDM_PIN(f1q[s]); TDM_PIN(a1r[s]); TDM_PIN(a1q[s]); }
+        if (i % Q == 0) { TDM_PIN(yr[i / Q]); TDM_PIN(yi[i / Q]); }
+        if (ib % Q == 0) { TDM_PIN(yr[ib / Q]); TDM_PIN(yi[ib / Q]); }
+    }
+    double zr[NP][2], zq[NP][2], ur[NP][2], uq[NP][2];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        zr[s][0] = f1r[s]; zr[s][1] = f2r[s]; zq[s][0] = f1q[s]; zq[s][1] = f2q[s];
+        ur[s][0] = a1r[s]; ur[s][1] = a2r[s]; uq[s][0] = a1q[s]; uq[s][1] = a2q[s];
+    }
+    pz_block_finish<Q, S, EDGE>(P, cm, lane, blk, row, zr, zq, ur, uq, yr, yi, pz[PzLayout::off_yc]);
+    // the last extended sample, as an integer: 2 u[n-1] - u[n-1-edge]
+    if (blk == P.nb - 1 && lane == 0) {
+        int ar, ai, br, bi;
+        pz_raw_sample<FMT8>(rowp, n - 1, ar, ai);
+        pz_raw_sample<FMT8>(rowp, n - 1 - EDGE, br, bi);
+        P.flast[(int64_t)row * 2] = (double)(2 * ar - br);
+        P.flast[(int64_t)row * 2 + 1] = (double)(2 * ai - bi);
     }
 }
 

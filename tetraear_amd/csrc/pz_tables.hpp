@@ -37,6 +37,7 @@ constexpr int kPzExtraRows = 16;
 struct PzLayout {
     static constexpr int kMaxPairs = 4;
     static constexpr int off_a1 = 0, off_a2 = 4, off_b0 = 8, off_b1 = 12, off_g = 16, off_dx = 20;
+    static constexpr int off_yc = 21;                 // response to the constant input offset left out by the raw-integer kernel (0 otherwise)
     static constexpr int off_zf = 24;                 // [NP][S][2] in-lane response to the causal start state
     TDM_HD static int off_zb(int S) { return off_zf + S * kMaxPairs * 2; }       // [NP][S][2] anticausal
     TDM_HD static int off_AG(int S) { return off_zb(S) + S * kMaxPairs * 2; }    // [D][D] V <- causal carry into the last block
@@ -160,8 +161,10 @@ inline PzDesign design_pz(const double (*sos)[6], int nsec)
 
 // L = samples per lane (a multiple of out_stride whenever S > 0 outputs per lane are tabulated), S = outputs per
 // lane of the in-lane tables.
+// in_scale / in_offset: the kernel runs on u with x = in_scale*u - in_offset (raw-integer kernel; 1 and 0 otherwise):
+// every output-side coefficient carries in_scale, and off_yc holds in_offset * H(1)^2.
 inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n, int edge, int L, int S,
-                                    int64_t n_out, int out_stride)
+                                    int64_t n_out, int out_stride, double in_scale = 1.0, double in_offset = 0.0)
 {
     using namespace detail;
     ZpHostTables t;
@@ -188,7 +191,11 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
     p.n_out = n_out;
     p.out_stride = out_stride;
     const int qs = out_stride, len_last = p.len_last;
-    const PzDesign dz = design_pz(sos, nsec);
+    PzDesign dz = design_pz(sos, nsec);
+    ldbl h1 = 1;   // H(1) = prod g_s * 4 / (1 + a1 + a2)
+    for (int s = 0; s < nsec; ++s) h1 *= (ldbl)sos[s][0] * 4 / (1 + dz.a1[s] + dz.a2[s]);
+    for (int s = 0; s < nsec; ++s) { dz.b0[s] *= (ldbl)in_scale; dz.b1[s] *= (ldbl)in_scale; }
+    dz.dx *= (ldbl)in_scale;
     const std::vector<ldbl> &a1 = dz.a1, &a2 = dz.a2, &b0 = dz.b0, &b1 = dz.b1;
     const std::vector<M2> &C = dz.C;
 
@@ -283,6 +290,7 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
             pz[PzLayout::off_g + s] = (double)(1 / (1 + a1[s] + a2[s]));
         }
         pz[PzLayout::off_dx] = (double)dz.dx;
+        pz[PzLayout::off_yc] = (double)((ldbl)in_offset * h1 * h1);
     }
     {
         const std::vector<ldbl> &AE = dz.AE;

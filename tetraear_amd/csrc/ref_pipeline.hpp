@@ -28,6 +28,8 @@ struct RefBuffers {
     double *z = nullptr;  // [rows][n_dec] c128: channel-filtered signal
     double *partials = nullptr;  // [rows][ceil(n_dec/kPowThreads)][kMaxSps] partial phase powers
     Lp2Params lp2{};             // (h.lp2.ok) pointers bound for the backend
+    ZpParams dec_raw_params{};   // (h.raw_S) the raw-integer decimator's geometry and its low-rate stage
+    Lp2Params lp2_raw{};
 };
 
 struct RefIO {
@@ -57,11 +59,47 @@ void run_pz_block(BE &be, const RefPlanHost &h, const ZpParams &P, const RawLoad
     }
 }
 
+// raw-integer decimator (cu8): blocks that hold no extension sample run on the bytes as they are, the first block and
+// the block(s) with the tail extension on int16 pairs
+template <class BE>
+void run_pz_raw(BE &be, const RefPlanHost &h, const ZpParams &P, const void *iq, int64_t stride, int rows)
+{
+    const int nb = P.nb, Bn = kWave * P.L;
+    int b_tail = (int)((P.k0L + P.n) / Bn);   // block of the first position past the signal
+    if (b_tail > nb - 1) b_tail = nb - 1;
+    const int n_narrow = b_tail - 1;           // blocks 1 .. b_tail-1
+    const int n_wide = b_tail >= 1 ? 1 + (nb - b_tail) : nb;
+    switch (h.q) {
+#define TDM_PZR_CASE(Q, S)                                                                                  \
+    case Q:                                                                                                 \
+        if (n_narrow > 0) be.template pz_raw<Q, S, kEdgeSos, FMT_CU8, false>(P, iq, stride, 1, 0, n_narrow, rows); \
+        be.template pz_raw<Q, S, kEdgeSos, FMT_CU8, true>(P, iq, stride, 0, b_tail, n_wide, rows);           \
+        break;
+        TDM_PZR_CASE(3, 16) TDM_PZR_CASE(4, 16) TDM_PZR_CASE(6, 16) TDM_PZR_CASE(7, 16) TDM_PZR_CASE(8, 15)
+        TDM_PZR_CASE(10, 12) TDM_PZR_CASE(12, 10) TDM_PZR_CASE(13, 8) TDM_PZR_CASE(41, 2)
+#undef TDM_PZR_CASE
+    default: break;
+    }
+}
+
+// block index of workgroup `idx` of a pz_raw launch: narrow launches cover blk_first + idx; wide launches cover block 0
+// and then the blocks from b_tail on (all blocks in order when b_tail == 0)
+TDM_HD int pz_raw_block(int idx, int blk_first, int b_tail, bool wide)
+{
+    if (!wide) return blk_first + idx;
+    if (b_tail < 1) return idx;
+    return idx == 0 ? 0 : b_tail + idx - 1;
+}
+
 template <class BE, int FMT, bool SHIFT>
 void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, const RefIO &io)
 {
     RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
-    if (h.decimated) {
+    const bool use_raw = h.raw_S > 0 && FMT == FMT_CU8 && !SHIFT;
+    if (use_raw) {
+        run_pz_raw(be, h, B.dec_raw_params, io.iq, io.carrier_stride, rows);
+        be.template zp_carry<2, 4>(B.dec_raw_params, h.dec_raw.p.nb, rows);
+    } else if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
         if (h.pz_S) {
             RawLoaderRT<SHIFT> lr{io.iq, io.carrier_stride, SHIFT ? io.pre_shift : nullptr, h.sample_rate, FMT};
@@ -81,15 +119,18 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     bool fix_in_finish = false;
     if (h.lp2.ok) {
         // fix-up + frequency_shift + filter_signal + phase powers in one kernel, output final and phase-major
-        if (h.decimated) {
+        if (use_raw) {
+            Lp2SrcDec src{B.dec_raw_params, io.freq_offset, h.rate_dec};
+            be.lp2(B.lp2_raw, src, rows);
+        } else if (h.decimated) {
             Lp2SrcDec src{B.dec_params, io.freq_offset, h.rate_dec};
             be.lp2(B.lp2, src, rows);
         } else {
             Lp2SrcPlain src{B.y, h.n_dec};
             be.lp2(B.lp2, src, rows);
         }
-        partials = B.lp2.partials;
-        n_pblk = B.lp2.n_chunks;
+        partials = use_raw ? B.lp2_raw.partials : B.lp2.partials;
+        n_pblk = use_raw ? B.lp2_raw.n_chunks : B.lp2.n_chunks;
     } else if (h.lpf) {
         // filter_signal(samples, 25000, current_rate)  (processor.py:264).  When decimated, the
         // loader finishes the decimator output (carry responses) and applies

@@ -48,6 +48,24 @@ inline int pz_outputs_per_lane(int q)
     }
 }
 
+// Raw-integer decimator kernels (pz_raw_body: cu8 samples kept as bytes, about 120 per lane) exist for the decimation
+// factors of the RTL-SDR rates and of 10 MS/s.  S = outputs per lane (lane length S*q, even).
+inline int pz_raw_outputs_per_lane(int q)
+{
+    switch (q) {
+    case 3: return 16;
+    case 4: return 16;
+    case 6: return 16;
+    case 7: return 16;
+    case 8: return 15;
+    case 10: return 12;
+    case 12: return 10;
+    case 13: return 8;
+    case 41: return 2;
+    default: return 0;
+    }
+}
+
 struct RefPlanHost {
     double sample_rate = 0;
     int64_t n = 0;
@@ -65,6 +83,11 @@ struct RefPlanHost {
     ZpHostTables dec;       // valid if decimated
     ZpHostTables lpf_t;     // valid if lpf
     Lp2Host lp2;            // lp2.ok: the low-rate stage runs as one parallel-form kernel (lp2_kernels.hpp)
+    // cu8 plans: the same two stages with the decimator on the raw bytes (longer lanes, other block geometry); used
+    // whenever no input-rate pre-shift is requested
+    int raw_S = 0;
+    ZpHostTables dec_raw;
+    Lp2Host lp2_raw;
 };
 
 // sos rows b = g*[1,2,1], a -> device form (unit numerators, one input gain, matching zi)
@@ -101,7 +124,7 @@ inline ZpFilterDesc desc_from_sos(const Sos4 &s) { return desc_from_rows(s.sos, 
 // the order-4 channel filter runs as its two-biquad factorisation (see Tf4 in design.hpp)
 inline ZpFilterDesc desc_from_tf(const Tf4 &t) { return desc_from_rows(t.sos, 2); }
 
-inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidth = 25000.0, bool allow_pz = true)
+inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidth = 25000.0, bool allow_pz = true, int in_fmt = -1)
 {
     RefPlanHost h;
     h.sample_rate = sample_rate;
@@ -128,6 +151,13 @@ inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidt
         h.lpf_t = build_zp_tables(desc_from_tf(h.tf), h.n_dec, kEdgeTf, kLLpf, h.n_dec, 1);
     if (allow_pz && h.lpf && h.sps > 1 && h.sps <= 32 && (!h.decimated || h.pz_S) && rows_are_lp121(h.tf.sos, 2))
         h.lp2 = build_lp2(h.tf.sos, h.n_dec, kEdgeTf, h.sps, h.decimated ? &h.dec : nullptr, h.sos.sos);
+    if (h.lp2.ok && h.decimated && in_fmt == 0 /* FMT_CU8 */ && pz_raw_outputs_per_lane(h.q)) {
+        const int S = pz_raw_outputs_per_lane(h.q);
+        // x = fl(1/127.5) * u - 1 (pyrtlsdr's conversion without its two roundings, see pz_raw_body)
+        h.dec_raw = build_pz_tables(h.sos.sos, 4, n, kEdgeSos, h.q * S, S, h.n_dec, h.q, 1.0 / 127.5, 1.0);
+        h.lp2_raw = build_lp2(h.tf.sos, h.n_dec, kEdgeTf, h.sps, &h.dec_raw, h.sos.sos);
+        if (h.lp2_raw.ok) h.raw_S = S;
+    }
     return h;
 }
 

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -236,6 +237,17 @@ __global__ __launch_bounds__(256) void k_zp_carry(const ZpParams P, int nb, int 
         zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
 }
 
+// raw-integer decimator (pz_raw_body): narrow = blocks without extension samples, wide = the others
+template <int Q, int S, int EDGE, int FMT8, bool WIDE>
+__global__ __launch_bounds__(64, (WIDE ? 1 : 2)) void k_pz_raw(const ZpParams P, const void *iq, int64_t stride, int blk_first,
+                                                                 int b_tail)
+{
+    __shared__ __attribute__((aligned(16))) double stg[WIDE ? PzEdgeGeom<Q * S, EDGE>::kDoubles : 2];
+    WaveComm cm{stg};
+    pz_raw_body<Q, S, EDGE, FMT8, WIDE>(P, iq, stride, cm, (int)threadIdx.x, pz_raw_block((int)blockIdx.x, blk_first, b_tail, WIDE),
+                                        (int)blockIdx.y);
+}
+
 template <int NSEC>
 __global__ __launch_bounds__(256) void k_pz_carry(const ZpParams P, int nb, int rows)
 {
@@ -411,6 +423,12 @@ struct HipBackend {
         Scope s(*this, ST_DEC_BLOCK);
         hipLaunchKernelGGL((k_pz_block<Q, S, EDGE, SHIFT>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
     }
+    template <int Q, int S, int EDGE, int FMT8, bool WIDE>
+    void pz_raw(const ZpParams &P, const void *iq, int64_t stride, int blk_first, int b_tail, int nblk, int rows)
+    {
+        Scope s(*this, ST_DEC_BLOCK);
+        hipLaunchKernelGGL((k_pz_raw<Q, S, EDGE, FMT8, WIDE>), dim3(nblk, rows), dim3(64), 0, stream, P, iq, stride, blk_first, b_tail);
+    }
     template <class Src>
     void lp2(const Lp2Params &P, const Src &src, int rows)
     {
@@ -527,10 +545,11 @@ struct DevZp {
 struct tdm_plan {
     RefPlanHost h;
     int rows = 0, fmt = 0, mode = 0, device = 0;
-    DevZp dec, lpf;
+    DevZp dec, lpf, dec_raw;
     double *d_y = nullptr, *d_z = nullptr, *d_partials = nullptr;
     double *d_zt = nullptr, *d_lp2p = nullptr, *d_lp2m = nullptr, *d_lp2s = nullptr, *d_lp2c = nullptr;   // lp2: phase-major filter output, chunk partials, lane matrices, seed rows
-    Lp2Params lp2{};
+    Lp2Params lp2{}, lp2_raw{};
+    double *d_lp2s_raw = nullptr, *d_lp2c_raw = nullptr;
     // TETRA mode
     TetraParams tp{};
     float2 *d_ty = nullptr, *d_tsym = nullptr, *d_tstat = nullptr;
@@ -554,7 +573,8 @@ static void plan_free(tdm_plan *p)
     (void)hipSetDevice(p->device);
     p->dec.destroy();
     p->lpf.destroy();
-    void *ptrs[] = {p->d_zt, p->d_lp2p, p->d_lp2m, p->d_lp2s, p->d_lp2c, p->d_y, p->d_z, p->d_partials, p->d_ty, p->d_tsym, p->d_tstat, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    p->dec_raw.destroy();
+    void *ptrs[] = {p->d_zt, p->d_lp2p, p->d_lp2m, p->d_lp2s, p->d_lp2c, p->d_lp2s_raw, p->d_lp2c_raw, p->d_y, p->d_z, p->d_partials, p->d_ty, p->d_tsym, p->d_tstat, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -647,7 +667,9 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         *out = p.release();
         return TDM_OK;
     }
-    p->h = build_ref_plan(sample_rate, n_samples);
+    // (TDM_NO_RAW=1: experiments / tests keep cu8 plans on the kernel that holds its samples as doubles)
+    const char *no_raw = std::getenv("TDM_NO_RAW");
+    p->h = build_ref_plan(sample_rate, n_samples, 25000.0, true, (no_raw && no_raw[0] == '1') ? -1 : in_fmt);
     const RefPlanHost &h = p->h;
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p->ev0));
@@ -657,7 +679,8 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     if (h.lp2.ok) {
         p->lp2 = h.lp2.p;
         HIP_TRY(hipMalloc(&p->d_zt, (size_t)n_carriers * h.sps * p->lp2.zt_k * 2 * sizeof(double)));
-        HIP_TRY(hipMalloc(&p->d_lp2p, (size_t)n_carriers * p->lp2.n_chunks * kMaxSps * sizeof(double)));
+        const int max_chunks = h.raw_S && h.lp2_raw.p.n_chunks > p->lp2.n_chunks ? h.lp2_raw.p.n_chunks : p->lp2.n_chunks;
+        HIP_TRY(hipMalloc(&p->d_lp2p, (size_t)n_carriers * max_chunks * kMaxSps * sizeof(double)));
         HIP_TRY(hipMalloc(&p->d_lp2m, h.lp2.lane_m.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(p->d_lp2m, h.lp2.lane_m.data(), h.lp2.lane_m.size() * sizeof(double), hipMemcpyHostToDevice));
         p->lp2.zt = p->d_zt;
@@ -670,6 +693,21 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             HIP_TRY(hipMalloc(&p->d_lp2s, h.lp2.seeds.size() * sizeof(double)));
             HIP_TRY(hipMemcpy(p->d_lp2s, h.lp2.seeds.data(), h.lp2.seeds.size() * sizeof(double), hipMemcpyHostToDevice));
             p->lp2.seeds = p->d_lp2s;
+        }
+        if (h.raw_S) {
+            // the raw-integer decimator's geometry: own tables and work buffers, same low-rate outputs
+            if ((rc = p->dec_raw.init(h.dec_raw, n_carriers))) return rc;
+            p->lp2_raw = h.lp2_raw.p;
+            p->lp2_raw.zt = p->d_zt;
+            p->lp2_raw.partials = p->d_lp2p;
+            p->lp2_raw.lane_m = p->d_lp2m;
+            // (the edge constants depend on the lane grid's offset, which follows the decimator's block geometry)
+            HIP_TRY(hipMalloc(&p->d_lp2c_raw, h.lp2_raw.cst.size() * sizeof(double)));
+            HIP_TRY(hipMemcpy(p->d_lp2c_raw, h.lp2_raw.cst.data(), h.lp2_raw.cst.size() * sizeof(double), hipMemcpyHostToDevice));
+            p->lp2_raw.cst = p->d_lp2c_raw;
+            HIP_TRY(hipMalloc(&p->d_lp2s_raw, h.lp2_raw.seeds.size() * sizeof(double)));
+            HIP_TRY(hipMemcpy(p->d_lp2s_raw, h.lp2_raw.seeds.data(), h.lp2_raw.seeds.size() * sizeof(double), hipMemcpyHostToDevice));
+            p->lp2_raw.seeds = p->d_lp2s_raw;
         }
     }
     // y: the low-rate signal when nothing downstream forms it on the fly (no decimation, or no channel filter);
@@ -767,6 +805,8 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     B.z = plan->d_z;
     B.partials = plan->d_partials;
     B.lp2 = plan->lp2;
+    B.dec_raw_params = plan->dec_raw.params;
+    B.lp2_raw = plan->lp2_raw;
     RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin};
     run_ref(be, plan->h, plan->rows, plan->fmt, B, io);
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
