@@ -181,14 +181,17 @@ struct EmuBackend {
                     pz_block_body<Q, S, EDGE>(P, ld, cm, lane, b, row);
                 });
     }
-    template <int Q, int S, int EDGE, int FMT8, bool WIDE>
-    void pz_raw(const ZpParams &P, const void *iq, int64_t stride, int blk_first, int b_tail, int nblk, int rows)
+    template <int Q, int S, int EDGE, int FMT8>
+    void pz_raw(const ZpParams &P, const void *iq, int64_t stride, int b_tail, int rows)
     {
         for (int row = 0; row < rows; ++row)
-            for (int idx = 0; idx < nblk; ++idx)
+            for (int blk = 0; blk < P.nb; ++blk)
                 run_group(kWave, [&](int lane, Group *g) {
                     EmuWaveComm cm{g, lane};
-                    pz_raw_body<Q, S, EDGE, FMT8, WIDE>(P, iq, stride, cm, lane, pz_raw_block(idx, blk_first, b_tail, WIDE), row);
+                    if (blk == 0 || blk >= b_tail)
+                        pz_raw_body<Q, S, EDGE, FMT8, true>(P, iq, stride, cm, lane, blk, row);
+                    else
+                        pz_raw_body<Q, S, EDGE, FMT8, false>(P, iq, stride, cm, lane, blk, row);
                 });
     }
     template <class Src>

@@ -60,35 +60,20 @@ void run_pz_block(BE &be, const RefPlanHost &h, const ZpParams &P, const RawLoad
 }
 
 // raw-integer decimator (cu8): blocks that hold no extension sample run on the bytes as they are, the first block and
-// the block(s) with the tail extension on int16 pairs
+// the block(s) with the tail extension (from b_tail on) on int16 pairs
 template <class BE>
 void run_pz_raw(BE &be, const RefPlanHost &h, const ZpParams &P, const void *iq, int64_t stride, int rows)
 {
     const int nb = P.nb, Bn = kWave * P.L;
     int b_tail = (int)((P.k0L + P.n) / Bn);   // block of the first position past the signal
     if (b_tail > nb - 1) b_tail = nb - 1;
-    const int n_narrow = b_tail - 1;           // blocks 1 .. b_tail-1
-    const int n_wide = b_tail >= 1 ? 1 + (nb - b_tail) : nb;
     switch (h.q) {
-#define TDM_PZR_CASE(Q, S)                                                                                  \
-    case Q:                                                                                                 \
-        if (n_narrow > 0) be.template pz_raw<Q, S, kEdgeSos, FMT_CU8, false>(P, iq, stride, 1, 0, n_narrow, rows); \
-        be.template pz_raw<Q, S, kEdgeSos, FMT_CU8, true>(P, iq, stride, 0, b_tail, n_wide, rows);           \
-        break;
+#define TDM_PZR_CASE(Q, S) case Q: be.template pz_raw<Q, S, kEdgeSos, FMT_CU8>(P, iq, stride, b_tail, rows); break;
         TDM_PZR_CASE(3, 16) TDM_PZR_CASE(4, 16) TDM_PZR_CASE(6, 16) TDM_PZR_CASE(7, 16) TDM_PZR_CASE(8, 15)
         TDM_PZR_CASE(10, 12) TDM_PZR_CASE(12, 10) TDM_PZR_CASE(13, 8) TDM_PZR_CASE(41, 2)
 #undef TDM_PZR_CASE
     default: break;
     }
-}
-
-// block index of workgroup `idx` of a pz_raw launch: narrow launches cover blk_first + idx; wide launches cover block 0
-// and then the blocks from b_tail on (all blocks in order when b_tail == 0)
-TDM_HD int pz_raw_block(int idx, int blk_first, int b_tail, bool wide)
-{
-    if (!wide) return blk_first + idx;
-    if (b_tail < 1) return idx;
-    return idx == 0 ? 0 : b_tail + idx - 1;
 }
 
 template <class BE, int FMT, bool SHIFT>

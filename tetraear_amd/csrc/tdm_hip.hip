@@ -237,15 +237,18 @@ __global__ __launch_bounds__(256) void k_zp_carry(const ZpParams P, int nb, int 
         zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
 }
 
-// raw-integer decimator (pz_raw_body): narrow = blocks without extension samples, wide = the others
-template <int Q, int S, int EDGE, int FMT8, bool WIDE>
-__global__ __launch_bounds__(64, (WIDE ? 1 : 2)) void k_pz_raw(const ZpParams P, const void *iq, int64_t stride, int blk_first,
-                                                                 int b_tail)
+// raw-integer decimator (pz_raw_body), one launch for all blocks of all rows: blocks without extension samples run the
+// narrow body (bytes as they come), the first block and the block(s) with the tail extension the wide one (int16 pairs)
+template <int Q, int S, int EDGE, int FMT8>
+__global__ __launch_bounds__(64, 2) void k_pz_raw(const ZpParams P, const void *iq, int64_t stride, int b_tail)
 {
-    __shared__ __attribute__((aligned(16))) double stg[WIDE ? PzEdgeGeom<Q * S, EDGE>::kDoubles : 2];
+    __shared__ __attribute__((aligned(16))) double stg[PzEdgeGeom<Q * S, EDGE>::kDoubles];
     WaveComm cm{stg};
-    pz_raw_body<Q, S, EDGE, FMT8, WIDE>(P, iq, stride, cm, (int)threadIdx.x, pz_raw_block((int)blockIdx.x, blk_first, b_tail, WIDE),
-                                        (int)blockIdx.y);
+    const int blk = (int)blockIdx.x;
+    if (blk == 0 || blk >= b_tail)
+        pz_raw_body<Q, S, EDGE, FMT8, true>(P, iq, stride, cm, (int)threadIdx.x, blk, (int)blockIdx.y);
+    else
+        pz_raw_body<Q, S, EDGE, FMT8, false>(P, iq, stride, cm, (int)threadIdx.x, blk, (int)blockIdx.y);
 }
 
 template <int NSEC>
@@ -423,11 +426,11 @@ struct HipBackend {
         Scope s(*this, ST_DEC_BLOCK);
         hipLaunchKernelGGL((k_pz_block<Q, S, EDGE, SHIFT>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
     }
-    template <int Q, int S, int EDGE, int FMT8, bool WIDE>
-    void pz_raw(const ZpParams &P, const void *iq, int64_t stride, int blk_first, int b_tail, int nblk, int rows)
+    template <int Q, int S, int EDGE, int FMT8>
+    void pz_raw(const ZpParams &P, const void *iq, int64_t stride, int b_tail, int rows)
     {
         Scope s(*this, ST_DEC_BLOCK);
-        hipLaunchKernelGGL((k_pz_raw<Q, S, EDGE, FMT8, WIDE>), dim3(nblk, rows), dim3(64), 0, stream, P, iq, stride, blk_first, b_tail);
+        hipLaunchKernelGGL((k_pz_raw<Q, S, EDGE, FMT8>), dim3(P.nb, rows), dim3(64), 0, stream, P, iq, stride, b_tail);
     }
     template <class Src>
     void lp2(const Lp2Params &P, const Src &src, int rows)
