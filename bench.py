@@ -475,8 +475,9 @@ def main_tetra(args):
 
 def leg_tetra(carriers, steps, warmup):
     """TETRA-mode leg (no reference oracle; SURVEY 8(d) 'tetra mode'): `carriers` channelised carriers,
-    cf32 at 72 kS/s (4 samples/symbol), chunks of 32768 samples.  Dominant kernel = RRC matched filter,
-    HBM-bound: algorithmic bytes 16 B/sample (8 in + 8 out, SURVEY 8(d) 'unfused')."""
+    cf32 at 72 kS/s (4 samples/symbol), chunks of 32768 samples.  ONE kernel (matched filter -> timing ->
+    Farrow -> carrier offset -> decisions), HBM-bound: algorithmic bytes = the input once + soft + hard symbols,
+    R*8 + 8 + 1 B/symbol (SURVEY 8(d) 'fused': 41 B/symbol at R = 4)."""
     from tetraear_amd import synth
     from tetraear_amd._lib import MODE_TETRA
     from tetraear_amd.batch import BatchDemodulator
@@ -501,9 +502,9 @@ def leg_tetra(carriers, steps, warmup):
     st = bd.stage_times()
     hard, soft, n_soft, tm, mm = bd.download()
     nsym = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
-    rrc_ms = st.get("tetra_rrc", float("nan"))
-    bytes_alg = rows * n * 16
-    traffic, traffic_src = measured_traffic(rows * n, "tetra-cf32", key="tetra_rrc")
+    rrc_ms = st.get("tetra_fused", float("nan"))
+    bytes_alg = rows * n * 8 + int(np.sum(n_soft.astype(np.int64))) * 9
+    traffic, traffic_src = measured_traffic(rows * n, "tetra-cf32", key="tetra_fused")
     out = {"metric": "Msymbols/s demodulated (TETRA mode: RRC + feed-forward timing + Farrow + quadrant slicer)",
            "value": nsym * steps / dt / 1e6, "unit": "Msym/s", "n_gpus": 1, "steps": steps,
            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -511,11 +512,12 @@ def leg_tetra(carriers, steps, warmup):
            "config": {"workload": f"{rows} channelised 25 kHz carriers, cf32 @72 kS/s, {n}-sample chunks", "mode": "tetra"},
            "realtime_carriers": nsym * steps / dt / 18000.0, "event_ms_per_step": ev_ms / steps,
            "stage_ms_per_launch": st,
-           "roofline": {"kernel": "k_tetra_rrc<33> (RRC matched filter, LDS-tiled)", "bound": "hbm",
+           "roofline": {"kernel": "k_tetra_fused<33> (RRC matched filter LDS-tiled -> timing -> Farrow -> slicer, one pass over the input)", "bound": "hbm",
                         "achieved": bytes_alg / (rrc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": bytes_alg / (rrc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                         "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": rrc_ms}}
+                        "algorithmic_bytes_per_launch": bytes_alg, "bytes_per_symbol": bytes_alg / max(nsym, 1),
+                        "avg_launch_ms": rrc_ms}}
     bd.close()
     return out
 

@@ -19,7 +19,7 @@
 #include "ref_pipeline.hpp"
 #include "resample_plan.hpp"
 #include "sync_kernels.hpp"
-#include "tetra_kernels.hpp"
+#include "tetra_params.hpp"
 #ifdef TDM_ZP_TIMING
 __device__ unsigned long long g_zp_dbg[16];
 #endif
@@ -366,10 +366,10 @@ __global__ __launch_bounds__(256) void k_shift(const double *x, double *y, int64
 // ------------------------------------------------------------------------------------------
 // stage timing (HIP events around each launch, on the stream the kernels run on)
 // ------------------------------------------------------------------------------------------
-enum Stage { ST_DEC_BLOCK = 0, ST_DEC_CARRY, ST_DEC_FIXUP, ST_CONVERT, ST_LPF_BLOCK, ST_LPF_CARRY, ST_LPF_FIXUP, ST_FINISH, ST_TETRA_RRC, ST_TETRA_SYM, ST_COUNT };
+enum Stage { ST_DEC_BLOCK = 0, ST_DEC_CARRY, ST_DEC_FIXUP, ST_CONVERT, ST_LPF_BLOCK, ST_LPF_CARRY, ST_LPF_FIXUP, ST_FINISH, ST_TETRA, ST_COUNT };
 static const char *kStageNames[ST_COUNT] = {"dec_block", "dec_carry", "dec_fixup", "convert",
                                             "lpf_block", "lpf_carry", "lpf_fixup", "finish",
-                                            "tetra_rrc", "tetra_sym"};
+                                            "tetra_fused"};
 
 struct StageTimer {
     bool on = false;
@@ -555,7 +555,6 @@ struct tdm_plan {
     double *d_lp2s_raw = nullptr, *d_lp2c_raw = nullptr;
     // TETRA mode
     TetraParams tp{};
-    float2 *d_ty = nullptr, *d_tsym = nullptr, *d_tstat = nullptr;
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -577,7 +576,7 @@ static void plan_free(tdm_plan *p)
     p->dec.destroy();
     p->lpf.destroy();
     p->dec_raw.destroy();
-    void *ptrs[] = {p->d_zt, p->d_lp2p, p->d_lp2m, p->d_lp2s, p->d_lp2c, p->d_lp2s_raw, p->d_lp2c_raw, p->d_y, p->d_z, p->d_partials, p->d_ty, p->d_tsym, p->d_tstat, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    void *ptrs[] = {p->d_zt, p->d_lp2p, p->d_lp2m, p->d_lp2s, p->d_lp2c, p->d_lp2s_raw, p->d_lp2c_raw, p->d_y, p->d_z, p->d_partials, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -647,11 +646,16 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         TetraParams &tp = p->tp;
         tp.n = (int32_t)n_samples;
         tp.ntaps = (int32_t)h.size();
-        tp.ystride = (int32_t)((n_samples + 1) & ~(int64_t)1);
         tp.sps = sps;
         tp.inv_sps = 1.0 / sps;
-        tp.step_c = (float)std::cos(-2.0 * M_PI / sps);
-        tp.step_s = (float)std::sin(-2.0 * M_PI / sps);
+        // symbol-clock phasors exp(-2 pi i g / sps) at g = 0..7 and g = one tile (argument reduced before the call)
+        auto clock = [&](double g, float &c, float &s_) {
+            const double ph = g / sps, fr = ph - std::floor(ph);
+            c = (float)std::cos(-2.0 * M_PI * fr);
+            s_ = (float)std::sin(-2.0 * M_PI * fr);
+        };
+        for (int v = 0; v < kRrcPerThread; ++v) clock((double)v, tp.ev_c[v], tp.ev_s[v]);
+        clock((double)kRrcTile, tp.tile_c, tp.tile_s);
         tp.max_soft = (int32_t)(n_samples / sps) + 4;
         for (size_t i = 0; i < h.size(); ++i) tp.taps[i] = (float)h[i];
         p->h.sample_rate = sample_rate;
@@ -664,9 +668,6 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&p->ev0));
         HIP_TRY(hipEventCreate(&p->ev1));
-        HIP_TRY(hipMalloc(&p->d_ty, (size_t)n_carriers * tp.ystride * sizeof(float2)));
-        HIP_TRY(hipMalloc(&p->d_tsym, (size_t)n_carriers * tp.max_soft * sizeof(float2)));
-        HIP_TRY(hipMalloc(&p->d_tstat, (size_t)n_carriers * kMaxTimingBlocks * sizeof(float2)));
         *out = p.release();
         return TDM_OK;
     }
@@ -782,21 +783,12 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
         if (carrier_stride_samples < plan->tp.n)
             return fail(TDM_ERR_INVALID, "TETRA mode: carrier stride shorter than the chunk");
         const TetraParams &tp = plan->tp;
-        const dim3 grid((tp.n + kRrcTile - 1) / kRrcTile, plan->rows);
         {
-            HipBackend::Scope s(be, ST_TETRA_RRC);
-            const float2 *x = (const float2 *)iq;
-            switch (tp.ntaps) {
-#define TDM_RRC_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_rrc<NT>), grid, dim3(kRrcThreads), 0, be.stream, x, carrier_stride_samples, plan->d_ty, plan->d_tstat, tp); break;
-                TDM_RRC_CASE(17) TDM_RRC_CASE(25) TDM_RRC_CASE(33) TDM_RRC_CASE(35) TDM_RRC_CASE(41) TDM_RRC_CASE(49) TDM_RRC_CASE(57) TDM_RRC_CASE(65)
-#undef TDM_RRC_CASE
-            default: return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
-            }
-        }
-        {
-            HipBackend::Scope s(be, ST_TETRA_SYM);
-            hipLaunchKernelGGL(k_tetra_sym, dim3(plan->rows), dim3(kSymThreads), 0, be.stream, plan->d_ty, plan->d_tstat, tp,
-                               (float2 *)soft, hard, n_soft, best_phase, min_margin);
+            // one kernel: matched filter, timing, Farrow, carrier-offset estimate and decisions; one workgroup per carrier
+            HipBackend::Scope s(be, ST_TETRA);
+            if (!tetra_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, hard, n_soft, best_phase,
+                              min_margin, be.stream))
+                return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
         }
         if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
         return TDM_OK;

@@ -1,155 +1,28 @@
 // TETRA mode (north-star receiver): per-carrier pi/4-DQPSK demodulation of channelised baseband.
 //
 // There is no reference implementation of this mode: the algorithm is defined by
-// oracle/tetra_np.py (fp64 numpy) and restated here in fp32 for gfx950:
-//   k_tetra_rrc : root-raised-cosine matched filter, LDS-tiled sliding window, one pass
-//                 HBM -> LDS -> registers -> LDS -> HBM (8 B in + 8 B out per sample, HBM-bound)
-//   k_tetra_sym : feed-forward square-law timing estimate (wavefront reductions + prefix sums),
-//                 cubic Farrow interpolation at the symbol instants, 4th-power carrier-offset
-//                 estimate, differential quadrant decision.  One workgroup per carrier chunk.
+// oracle/tetra_np.py (fp64 numpy) and restated here in fp32 for gfx950 as ONE kernel, k_tetra_fused:
+// a workgroup owns a carrier and walks its chunk tile by tile,
+//   HBM -> registers (next tile in flight) -> LDS -> sliding-window RRC matched filter in registers
+//       -> square-law (Oerder-Meyr) timing statistic of the tile's sub-blocks from the registers
+//       -> matched-filter output into an LDS ring (never to HBM)
+//       -> timing estimates of the sub-blocks whose averaging window is complete (one wavefront)
+//       -> cubic Farrow interpolation at the symbol instants out of the ring -> soft symbols to HBM,
+// then the 4th-power carrier-offset estimate over the carrier's symbols and the differential quadrant
+// decision.  HBM traffic = the input once + 9 bytes per symbol (SURVEY 8(d) "fused": R*8 + 8 + 1 B/symbol).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "tetra_params.hpp"
 
 namespace tdm {
-
-constexpr int kRrcMaxTaps = 96;
-constexpr int kRrcThreads = 256;
-constexpr int kRrcPerThread = 8;                          // consecutive outputs per thread
-constexpr int kRrcTile = kRrcThreads * kRrcPerThread;     // 2048 samples per workgroup
-constexpr int kTimingBlock = 256;                         // samples per timing sub-block (TB)
-constexpr int kTimingHalfWin = 2;                         // sub-blocks averaged each side (TW)
-constexpr int kMaxTimingBlocks = 512;
-constexpr int kSymThreads = 256;
-
-struct TetraParams {
-    int32_t n;          // samples per carrier chunk
-    int32_t ntaps;      // odd
-    int32_t max_soft;   // capacity of per-carrier symbol outputs
-    int32_t ystride;    // row stride of the matched-filter output (n rounded up to even: 16-byte rows)
-    double sps;         // samples per symbol (sample_rate / 18000)
-    double inv_sps;
-    float step_c, step_s;  // exp(-2 pi i / sps): symbol-clock phasor advance per sample
-    float taps[kRrcMaxTaps];
-};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// LDS index of tile sample s: one pad slot per 8 samples so that a thread's 8-sample-strided
-// window reads (ds_read_b64, lane stride 9 slots = 18 dwords) hit 32 distinct bank pairs.
-__device__ __forceinline__ int rrc_slot(int s) { return s + (s >> 3); }
-
-template <int NT>
-__global__ __launch_bounds__(kRrcThreads) void k_tetra_rrc(const float2 *__restrict__ x, int64_t in_stride,
-                                                            float2 *__restrict__ y, float2 *__restrict__ tstat,
-                                                            const TetraParams P)
-{
-    static_assert(kTimingBlock == 32 * kRrcPerThread, "one timing sub-block = 32 threads x 8 outputs");
-    constexpr int HALO = NT - 1;
-    constexpr int NS = kRrcTile + HALO;  // samples staged
-    __shared__ float2 lds[NS + NS / 8 + 2];
-    const int row = blockIdx.y;
-    const int n = P.n;
-    const int64_t base = (int64_t)blockIdx.x * kRrcTile;          // first output of the tile
-    const float2 *xr = x + (int64_t)row * in_stride;   // rows of the channeliser may carry a pitch
-    float2 *yr = y + (int64_t)row * P.ystride;
-    const int t = threadIdx.x;
-    // stage inputs base - HALO/2 .. base + tile + HALO/2 (zero outside the chunk), coalesced;
-    // 16 bytes per lane (two samples) when the tile start is 16-byte aligned in the row
-    if (((HALO / 2) & 1) == 0 && (in_stride & 1) == 0) {
-        const f32x4 *x4 = (const f32x4 *)xr;
-        for (int s2 = t; s2 < NS / 2; s2 += kRrcThreads) {
-            const int s = 2 * s2;
-            const int64_t g = base + s - HALO / 2;  // even
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g >= 0 && g + 1 < n) {
-                v = __builtin_nontemporal_load(x4 + (g >> 1));
-            } else if (g >= 0 && g < n) {   // last sample of an odd-length chunk
-                const float2 q = xr[g];
-                v.x = q.x;
-                v.y = q.y;
-            }
-            lds[rrc_slot(s)] = make_float2(v.x, v.y);
-            lds[rrc_slot(s + 1)] = make_float2(v.z, v.w);
-        }
-        if ((NS & 1) && t == 0) {
-            const int s = NS - 1;
-            const int64_t g = base + s - HALO / 2;
-            lds[rrc_slot(s)] = (g >= 0 && g < n) ? xr[g] : make_float2(0.f, 0.f);
-        }
-    } else {
-        for (int s = t; s < NS; s += kRrcThreads) {
-            const int64_t g = base + s - HALO / 2;
-            float2 v = make_float2(0.f, 0.f);
-            if (g >= 0 && g < n) v = xr[g];
-            lds[rrc_slot(s)] = v;
-        }
-    }
-    __syncthreads();
-    // sliding window in registers: outputs base + 8t + v need staged samples 8t + v .. 8t + v + NT-1
-    f32x2 w[kRrcPerThread + HALO];
-#pragma unroll
-    for (int j = 0; j < kRrcPerThread + HALO; ++j) {
-        const float2 q = lds[rrc_slot(kRrcPerThread * t + j)];
-        w[j] = f32x2{q.x, q.y};
-    }
-    f32x2 acc[kRrcPerThread];
-#pragma unroll
-    for (int v = 0; v < kRrcPerThread; ++v) acc[v] = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-        const f32x2 hh = {P.taps[k], P.taps[k]};
-#pragma unroll
-        for (int v = 0; v < kRrcPerThread; ++v) acc[v] = __builtin_elementwise_fma(hh, w[v + k], acc[v]);  // v_pk_fma_f32
-    }
-    // square-law timing statistic of this tile's 8 sub-blocks while the outputs are in registers:
-    // C_b = sum |y[g]|^2 exp(-2 pi i g / sps)   (Oerder-Meyr); 32 threads x 8 samples per sub-block
-    {
-        const int64_t g0 = base + kRrcPerThread * t;
-        const double ph = (double)g0 * P.inv_sps;
-        const float fr = (float)(ph - floor(ph));
-        float ps, pc;
-        sincospif(-2.f * fr, &ps, &pc);
-        float ar = 0.f, ai = 0.f;
-#pragma unroll
-        for (int v = 0; v < kRrcPerThread; ++v) {
-            if (g0 + v < n) {
-                const float p = acc[v].x * acc[v].x + acc[v].y * acc[v].y;
-                ar = fmaf(p, pc, ar);
-                ai = fmaf(p, ps, ai);
-            }
-            const float nc = pc * P.step_c - ps * P.step_s, ns = pc * P.step_s + ps * P.step_c;
-            pc = nc;
-            ps = ns;
-        }
-#pragma unroll
-        for (int d = 16; d >= 1; d >>= 1) {
-            ar += __shfl_xor(ar, d, 64);
-            ai += __shfl_xor(ai, d, 64);
-        }
-        const int nb = (n + kTimingBlock - 1) / kTimingBlock;
-        const int b = (int)(base / kTimingBlock) + (t >> 5);
-        if ((t & 31) == 0 && b < nb) tstat[(int64_t)row * nb + b] = make_float2(ar, ai);
-    }
-    __syncthreads();
-    // transpose through LDS so that the stores are coalesced
-#pragma unroll
-    for (int v = 0; v < kRrcPerThread; ++v) lds[rrc_slot(kRrcPerThread * t + v)] = make_float2(acc[v].x, acc[v].y);
-    __syncthreads();
-    f32x4 *y4 = (f32x4 *)yr;
-    for (int s2 = t; s2 < kRrcTile / 2; s2 += kRrcThreads) {
-        const int s = 2 * s2;
-        const int64_t g = base + s;
-        if (g + 1 < n) {
-            const float2 a = lds[rrc_slot(s)], b = lds[rrc_slot(s + 1)];
-            const f32x4 o = {a.x, a.y, b.x, b.y};
-            __builtin_nontemporal_store(o, y4 + (g >> 1));
-        } else if (g < n) {
-            yr[g] = lds[rrc_slot(s)];
-        }
-    }
-}
+// LDS index of sample s: one pad slot per kRrcPerThread samples so that a thread's strided accesses (ds_read_b64 /
+// ds_write_b64, lane stride 5 or 9 slots = 10 or 18 dwords) hit 32 distinct bank pairs.
+__device__ __forceinline__ int rrc_slot(int s) { return s + (s >> kRrcPadShift); }
 
 // ---- workgroup helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)
@@ -184,21 +57,11 @@ __device__ __forceinline__ float block_min(float v, float *sm)
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// cubic Lagrange (Farrow) interpolation at position t (1 <= t <= n-3), split into the four loads and
-// the arithmetic so that a thread can have the loads of several symbols in flight
+// cubic Lagrange (Farrow) interpolation between y0 and y1 at fraction mu
 struct FarrowTaps {
     float2 ym1, y0, y1, y2;
     float mu;
 };
-__device__ __forceinline__ void farrow_load(const float2 *y, double t, FarrowTaps &f)
-{
-    const int m = (int)floor(t);   // (callers keep 1 <= t <= n-3; tau is sanitised in k_tetra_sym)
-    f.mu = (float)(t - (double)m);
-    f.ym1 = y[m - 1];
-    f.y0 = y[m];
-    f.y1 = y[m + 1];
-    f.y2 = y[m + 2];
-}
 __device__ __forceinline__ float2 farrow_eval(const FarrowTaps &f)
 {
     const float2 ym1 = f.ym1, y0 = f.y0, y1 = f.y1, y2 = f.y2;
@@ -218,17 +81,10 @@ __device__ __forceinline__ float2 farrow_eval(const FarrowTaps &f)
     }
     return r;
 }
-__device__ __forceinline__ float2 farrow_at(const float2 *y, double t)
-{
-    FarrowTaps f;
-    farrow_load(y, t, f);
-    return farrow_eval(f);
-}
-
 // piecewise-linear timing estimate at sample position pos (sub-block centres at (b+0.5)*TB)
 __device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
 {
-    if (nb == 1) return tau[0];
+    if (nb == 1) return tau[0];   // (tau: ring of kTauRing estimates)
     const double u = pos / (double)kTimingBlock - 0.5;
     int b0 = (int)floor(u);
     if (b0 < 0) b0 = 0;
@@ -236,114 +92,406 @@ __device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
     double f = u - (double)b0;
     if (f < 0.0) f = 0.0;
     if (f > 1.0) f = 1.0;
-    return (float)((double)tau[b0] * (1.0 - f) + (double)tau[b0 + 1] * f);
+    return (float)((double)tau[b0 & (kTauRing - 1)] * (1.0 - f) + (double)tau[(b0 + 1) & (kTauRing - 1)] * f);
 }
 
-constexpr int kSymUnroll = 8;   // symbols per thread whose loads are in flight together
 
-__global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restrict__ y,
-                                                            const float2 *__restrict__ tstat, const TetraParams P,
-                                                            float2 *__restrict__ soft, uint8_t *__restrict__ hard,
-                                                            int32_t *n_soft, int32_t *timing_milli, double *min_margin)
+// atan2(y, x) / (2 pi), absolute error below 2e-6 turns (odd minimax polynomial on [0, 1] + octant folding): the timing
+// estimate it feeds is good to 1e-3 symbols at best
+__device__ __forceinline__ float atan2_turns(float y, float x)
 {
-    __shared__ float Cr[kMaxTimingBlocks + 1], Ci[kMaxTimingBlocks + 1];  // later: prefix sums
-    __shared__ float tau[kMaxTimingBlocks];
-    __shared__ float sm[kSymThreads / 64];
-    __shared__ int k_lo_s, n_sym_s;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+    const float a = hi > 0.f ? __fdividef(lo, hi) : 0.f;
+    const float s = a * a;
+    float r = a * (0.99997726f + s * (-0.33262347f + s * (0.19354346f + s * (-0.11643287f + s * (0.05265332f + s * -0.01172120f)))));
+    r *= 0.15915494309189535f;
+    if (ay > ax) r = 0.25f - r;
+    if (x < 0.f) r = 0.5f - r;
+    return y < 0.f ? -r : r;
+}
+
+// ring position of sample g (g >= 0)
+__device__ __forceinline__ int ring_slot(int p)   // p in [0, 2 kRing)
+{
+    if ((kRing & (kRing - 1)) == 0)
+        p &= kRing - 1;
+    else
+        p = (int)min((unsigned)p, (unsigned)(p - kRing));   // p >= kRing ? p - kRing : p
+    return rrc_slot(p);
+}
+
+// waves per SIMD the register allocation aims for (three workgroups per CU fit in LDS)
+#ifndef TDM_TETRA_WAVES
+#define TDM_TETRA_WAVES(NT) 3
+#endif
+
+#ifdef TDM_TETRA_TIMING
+__device__ unsigned long long g_tetra_dbg[16];
+#define TT_MARK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tt[i] += t_ - tt_last; tt_last = t_; }
+#else
+#define TT_MARK(i)
+#endif
+
+constexpr int kSymUnroll = 8;   // symbols per thread whose loads are in flight together (final passes)
+
+template <int NT>
+__global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fused(const float2 *__restrict__ x, int64_t in_stride,
+                                                              const TetraParams P, float2 *__restrict__ soft,
+                                                              uint8_t *__restrict__ hard, int32_t *n_soft,
+                                                              int32_t *timing_milli, double *min_margin)
+{
+    static_assert(kRrcPerThread == 4 || kRrcPerThread == 8, "a timing sub-block = one wavefront (4 outputs per thread) or half of one (8)");
+    static_assert(kRing % kRrcPerThread == 0 && kRing - kRrcTile - kTimingBlock * (2 * kTimingHalfWin + 1) / 2 >= kTimingBlock, "ring too short");
+    constexpr int PER = kRrcPerThread;
+    constexpr int HALO = NT - 1, H2 = HALO / 2;
+    constexpr int OFF = ((H2 + 1) & ~1) + 1;              // the staged window starts at tile base - OFF (odd: see fetch)
+    constexpr int D0 = OFF - H2;                          // staged index of the first tap of output 0
+    constexpr int NS = (kRrcTile + OFF + H2 + 2) & ~1;    // samples staged per tile
+    constexpr int NP = (NS / 2 + kRrcThreads - 1) / kRrcThreads;   // 16-byte sample pairs per thread
+    constexpr int NW = kRrcPerThread + HALO;
+    __shared__ float2 xs[NS + (NS >> kRrcPadShift) + 2];
+    __shared__ float2 yring[kRing + (kRing >> kRrcPadShift)];
+    __shared__ float2 Cst[2 * kTileBlocks];   // the statistic of two tiles' sub-blocks
+    __shared__ float tau[kTauRing];
+    __shared__ float tau_mid_s;
+    __shared__ float sm[kRrcThreads / 64];
     __shared__ float delta_s;
     const int row = blockIdx.x;
+    const int tid = threadIdx.x;
     const int n = P.n;
     const double sps = P.sps;
-    const float2 *yr = y + (int64_t)row * P.ystride;
-    float2 *sr = soft + (int64_t)row * P.max_soft;  // soft symbols (cf32) double as the scratch of step 4
-    const int tid = threadIdx.x;
+    const float2 *xr = x + (int64_t)row * in_stride;     // rows of the channeliser may carry a pitch
+    float2 *sr = soft + (int64_t)row * P.max_soft;
     const int nb = (n + kTimingBlock - 1) / kTimingBlock;
-    // 1. square-law timing statistic per sub-block: produced by k_tetra_rrc
-    for (int b = tid; b < nb; b += kSymThreads) {
-        const float2 c = tstat[(int64_t)row * nb + b];
-        Cr[b + 1] = c.x;
-        Ci[b + 1] = c.y;
-    }
-    __syncthreads();
-    // 2. prefix sums (one thread), vector average over +-TW sub-blocks and its argument (one thread per
-    //    sub-block), unwrap (one thread: a short chain of roundings)
-    if (tid == 0) {
-        Cr[0] = 0.f; Ci[0] = 0.f;
-        float ar = 0.f, ai = 0.f;
-        for (int b = 1; b <= nb; ++b) {
-            ar += Cr[b];
-            ai += Ci[b];
-            Cr[b] = ar;
-            Ci[b] = ai;
-        }
-    }
-    __syncthreads();
-    for (int b = tid; b < nb; b += kSymThreads) {
-        const int hi = min(nb, b + kTimingHalfWin + 1), lo = max(0, b - kTimingHalfWin);
-        const float cr = Cr[hi] - Cr[lo], ci = Ci[hi] - Ci[lo];
-        float tb = -atan2f(ci, cr) * 0.15915494309189535f;  // / (2 pi)
-        // a non-finite input sample makes the statistic NaN and the prefix sums carry it to every later sub-block:
-        // such a carrier demodulates garbage, but it must not index outside its row (the range checks below are
-        // false for NaN)
-        if (!(fabsf(tb) <= 1.0f)) tb = 0.f;
-        tau[b] = tb;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float prev = 0.f;
-        for (int b = 0; b < nb; ++b) {
-            float tb = tau[b];
-            if (b > 0) tb += rintf(prev - tb);
-            tau[b] = tb;
-            prev = tb;
-        }
-        // symbol index range: t_k = (k + tau(k*sps)) * sps must lie in [1, n-3]
-        int k_lo = 0;
-        while (k_lo < 8 && ((double)k_lo + (double)tau_at(tau, nb, k_lo * sps)) * sps < 1.0) ++k_lo;
-        int k_hi = (int)floor((double)n / sps) + 1;
-        while (k_hi >= k_lo && ((double)k_hi + (double)tau_at(tau, nb, k_hi * sps)) * sps > (double)n - 3.0) --k_hi;
-        int ns = k_hi - k_lo + 1;
-        if (ns < 0) ns = 0;
-        if (ns > P.max_soft) ns = P.max_soft;
-        k_lo_s = k_lo;
-        n_sym_s = ns;
-    }
-    __syncthreads();
-    const int k_lo = k_lo_s, ns = n_sym_s;
-    // 3. interpolate the matched-filter output at the symbol instants (kSymUnroll symbols per thread with
-    //    all their loads in flight: the loops of this kernel are bound by memory latency, not bandwidth)
-    constexpr int U = kSymUnroll;
-    for (int i0 = tid; i0 < ns; i0 += kSymThreads * U) {
-        FarrowTaps f[U];
+    const int ntiles = (n + kRrcTile - 1) / kRrcTile;
+    // ---- input: a tile's samples base - OFF .. base - OFF + NS (zero outside the chunk) travel HBM -> registers one
+    // tile ahead of their use, as 16-byte pairs.  A row starts on an 8-byte boundary (pitched channeliser rows, odd
+    // offsets): pairs begin at the samples whose address is a multiple of 16 (index parity `par`), the one sample a
+    // clamped pair can miss at either end of the chunk is read once up front.  fetch() only issues loads (clamped
+    // addresses, no branch, nothing that consumes a loaded value: a use would wait for the load on the spot);
+    // stage() masks what lies outside the chunk and writes LDS.
+    const int par = (int)(((uintptr_t)xr >> 3) & 1);
+    const int gmaxp = ((n - 2 - par) & ~1) + par;         // last pair start inside the chunk
+    const float2 x_first = xr[0], x_last = xr[n - 1];
+    f32x4 pf[NP];
+    auto fetch = [&](int tile) {
+        const int g0 = tile * kRrcTile - OFF + 1 - par;   // = par (mod 2)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * kSymThreads;
-            if (i < ns) {
-                const int k = k_lo + i;
-                const double t = ((double)k + (double)tau_at(tau, nb, (double)k * sps)) * sps;
-                farrow_load(yr, t, f[u]);
+        for (int j = 0; j < NP; ++j) {
+            const int g = g0 + 2 * (tid + j * kRrcThreads);
+            pf[j] = __builtin_nontemporal_load((const f32x4 *)(xr + min(max(g, par), gmaxp)));
+        }
+    };
+    auto stage = [&](int tile) {
+        const int g0 = tile * kRrcTile - OFF;
+        if (g0 >= 2 * par && g0 + NS + 1 <= gmaxp) {   // every pair of the tile lies inside the chunk: no masks
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int q = 2 * (tid + j * kRrcThreads) + 1 - par;
+                const f32x4 v = pf[j];
+                if (j < NP - 1 || q < NS) xs[rrc_slot(q)] = make_float2(v.x, v.y);
+                if (j < NP - 1 || q + 1 < NS) xs[rrc_slot(q + 1)] = make_float2(v.z, v.w);
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int q = 2 * (tid + j * kRrcThreads) + 1 - par;   // staged index of the pair's first sample
+            const int g = g0 + q;
+            const bool in = g >= par && g <= gmaxp;
+            const f32x4 v = pf[j];
+            const float2 e0 = in ? make_float2(v.x, v.y) : (g == n - 1 ? x_last : make_float2(0.f, 0.f));
+            const float2 e1 = in ? make_float2(v.z, v.w) : (g == -1 ? x_first : make_float2(0.f, 0.f));
+            if (j < NP - 1 || q < NS) xs[rrc_slot(q)] = e0;
+            if (j < NP - 1 || q + 1 < NS) xs[rrc_slot(q + 1)] = e1;
+        }
+    };
+
+    // symbol-clock phasor exp(-2 pi i g / sps) at the thread's first output of the current tile
+    float pc, ps;
+    {
+        const double ph = (double)(kRrcPerThread * tid) * P.inv_sps;
+        sincospif(-2.f * (float)(ph - floor(ph)), &ps, &pc);
+    }
+    float tau_prev = 0.f;   // (wave 0) last unwrapped estimate
+    int b_done = 0;         // sub-blocks whose estimate is final
+    int k_lo = 0, k_begin = 0, ns = 0;
+
+#ifdef TDM_TETRA_TIMING
+    unsigned long long tt[12] = {0}, tt_last = __builtin_readcyclecounter();
+#endif
+    fetch(0);
+    stage(0);
+    if (ntiles > 1) fetch(1);
+    for (int i = 0; i < ntiles; ++i) {
+        const bool last = i == ntiles - 1;
+        const int base = i * kRrcTile;
+        TT_MARK(0)
+        __syncthreads();   // tile i staged; the previous round's ring reads are done
+        TT_MARK(1)
+        // ---- matched filter: outputs base + 8 tid + v need staged samples 8 tid + v + D0 .. + NT - 1
+        // Taps as 64-bit scalar pairs, one half broadcast per instruction (the compiler's own form spends two scalar
+        // registers per tap and spills them); window addresses are one base + compile-time offsets.  The window slides
+        // through the registers in chunks of 8 taps: a chunk needs PER + 7 samples, the 8 new ones of the next chunk are
+        // loaded while this chunk's 64 multiply-adds run (scheduling fences keep that order), so PER + 15 window samples
+        // are live at a time instead of all NT + PER - 1.
+        f32x2 acc[kRrcPerThread];
+        {
+            f32x2 w[NW];
+            const float2 *wb = xs + (PER + 1) * tid;
+            auto wload = [&](int j) {
+                const float2 q = wb[j + D0 + ((j + D0) >> kRrcPadShift)];
+                w[j] = f32x2{q.x, q.y};
+            };
+#pragma unroll
+            for (int j = 0; j < (NW < PER + 7 ? NW : PER + 7); ++j) wload(j);
+#pragma unroll
+            for (int c = 0; 8 * c < NT; ++c) {
+#pragma unroll
+                for (int j = 8 * c + PER + 7; j < 8 * c + PER + 15; ++j)
+                    if (j < NW) wload(j);
+#pragma unroll
+                for (int k = 8 * c; k < 8 * c + 8 && k < NT; k += 2) {
+                    uint64_t tp;
+                    __builtin_memcpy(&tp, &P.taps[k], 8);
+#pragma unroll
+                    for (int v = 0; v < kRrcPerThread; ++v) {
+                        if (k == 0)
+                            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc[v]) : "s"(tp), "v"(w[v]));
+                        else
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[v]) : "s"(tp), "v"(w[v + k]));
+                    }
+                    if (k + 1 < NT) {
+#pragma unroll
+                        for (int v = 0; v < kRrcPerThread; ++v)
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[v]) : "s"(tp), "v"(w[v + k + 1]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        TT_MARK(2)
+        // ---- square-law timing statistic of the tile's sub-blocks, C_b = sum |y[g]|^2 exp(-2 pi i g / sps):
+        // 32 threads x 8 samples per sub-block, the phasor inside a thread's run is a constant table
+        {
+            const int g0 = base + kRrcPerThread * tid;
+            float qr = 0.f, qi = 0.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * kSymThreads;
-            if (i < ns) sr[i] = farrow_eval(f[u]);
+            for (int v = 0; v < kRrcPerThread; ++v) {
+                float p = acc[v].x * acc[v].x + acc[v].y * acc[v].y;
+                if (last && g0 + v >= n) p = 0.f;
+                qr = fmaf(p, P.ev_c[v], qr);
+                qi = fmaf(p, P.ev_s[v], qi);
+            }
+            float ar = qr * pc - qi * ps, ai = qr * ps + qi * pc;
+            const float nc = pc * P.tile_c - ps * P.tile_s, nsn = pc * P.tile_s + ps * P.tile_c;
+            pc = nc;
+            ps = nsn;
+            // sum over each 16-lane row with DPP (no LDS round trips), then across the rows of the sub-block's lanes
+#define TDM_DPP_ADD(X, CTRL, ROWS, BC) X += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X), CTRL, ROWS, 0xf, BC));
+            TDM_DPP_ADD(ar, 0xB1, 0xf, true) TDM_DPP_ADD(ai, 0xB1, 0xf, true)     // quad_perm [1,0,3,2]
+            TDM_DPP_ADD(ar, 0x4E, 0xf, true) TDM_DPP_ADD(ai, 0x4E, 0xf, true)     // quad_perm [2,3,0,1]
+            TDM_DPP_ADD(ar, 0x141, 0xf, true) TDM_DPP_ADD(ai, 0x141, 0xf, true)   // row_half_mirror
+            TDM_DPP_ADD(ar, 0x140, 0xf, true) TDM_DPP_ADD(ai, 0x140, 0xf, true)   // row_mirror
+            TDM_DPP_ADD(ar, 0x142, 0xa, false) TDM_DPP_ADD(ai, 0x142, 0xa, false) // row_bcast:15 into rows 1, 3
+            if (PER == 4) { TDM_DPP_ADD(ar, 0x143, 0xc, false) TDM_DPP_ADD(ai, 0x143, 0xc, false) }   // row_bcast:31 into rows 2, 3
+#undef TDM_DPP_ADD
+            constexpr int LPB = kTimingBlock / PER;   // lanes per sub-block: 64 or 32
+            const int b = i * kTileBlocks + tid / LPB;
+            if ((tid & (LPB - 1)) == (PER == 4 ? 63 : 16) && b < nb) Cst[b & (2 * kTileBlocks - 1)] = make_float2(ar, ai);
         }
+        TT_MARK(3)
+        // ---- matched-filter output into the ring
+        {
+            const int p0 = (base + kRrcPerThread * tid) % kRing;   // a thread's outputs never straddle the end
+#pragma unroll
+            for (int v = 0; v < kRrcPerThread; ++v) yring[rrc_slot(p0) + v] = make_float2(acc[v].x, acc[v].y);
+        }
+        TT_MARK(4)
+        __syncthreads();   // ring, statistic visible; staging buffer free
+        TT_MARK(5)
+        if (!last) {
+            stage(i + 1);
+            if (i + 2 < ntiles) fetch(i + 2);
+        }
+        TT_MARK(6)
+        // ---- timing estimates that are final now: vector average over +-TW sub-blocks, argument, unwrap
+        const int b_known = last ? nb - 1 : (i + 1) * kTileBlocks - 1 - kTimingHalfWin;
+        // (every wavefront computes them, identically, in its first lanes: cheaper than a barrier around one that does)
+        {
+            const int lane = tid & 63;
+            const int cnt = b_known - b_done + 1;   // <= 10
+            const int b = b_done + lane;
+            float cr = 0.f, ci = 0.f;
+            const int lo = max(0, b - kTimingHalfWin), hi = min(nb - 1, b + kTimingHalfWin);
+#pragma unroll
+            for (int e = 0; e < 2 * kTimingHalfWin + 1; ++e) {   // loaded unconditionally (one LDS round trip), masked
+                const int j = b - kTimingHalfWin + e;
+                const float2 c = Cst[j & (2 * kTileBlocks - 1)];
+                const bool ok = j >= lo && j <= hi;
+                cr += ok ? c.x : 0.f;
+                ci += ok ? c.y : 0.f;
+            }
+            float tb = -atan2_turns(ci, cr);
+            // a non-finite input sample makes the statistic NaN: such a carrier demodulates garbage, but it must
+            // not index outside its row
+            if (!(fabsf(tb) <= 1.0f) || lane >= cnt) tb = 0.f;
+            // unwrap: tau_b = raw_b + N_b, N_b = N_{b-1} + rint(raw_{b-1} - raw_b) (whole symbols), as an inclusive scan
+            // over the (<= 10) new sub-blocks in the first row of the wavefront (DPP row shifts)
+            const float rawp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tb), 0x111, 0xf, 0xf, true));   // row_shr:1
+            float stp = lane == 0 ? (b_done > 0 ? rintf(tau_prev - tb) : 0.f) : rintf(rawp - tb);
+#define TDM_ROW_SHR_ADD(D) stp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, stp), 0x110 + D, 0xf, 0xf, true));   // row_shr:D, zero shifted in
+            TDM_ROW_SHR_ADD(1) TDM_ROW_SHR_ADD(2) TDM_ROW_SHR_ADD(4) TDM_ROW_SHR_ADD(8)
+#undef TDM_ROW_SHR_ADD
+            tb += stp;
+            tau_prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb), cnt - 1));
+            if (lane < cnt) {
+                tau[b & (kTauRing - 1)] = tb;
+                if (b == nb / 2) tau_mid_s = tb;
+            }
+        }
+        b_done = b_known + 1;
+        TT_MARK(7)
+        TT_MARK(8)
+        // ---- symbols whose two timing estimates are final: t_k = (k + tau(k sps)) sps, in [1, n-3]
+        if (i == 0) {
+            while (k_lo < 8 && ((double)k_lo + (double)tau_at(tau, nb, k_lo * sps)) * sps < 1.0) ++k_lo;
+            k_begin = k_lo;
+        }
+        int k_end;
+        if (last) {
+            int k_hi = (int)floor((double)n / sps) + 1;
+            while (k_hi >= k_lo && ((double)k_hi + (double)tau_at(tau, nb, k_hi * sps)) * sps > (double)n - 3.0) --k_hi;
+            ns = k_hi - k_lo + 1;
+            if (ns < 0) ns = 0;
+            if (ns > P.max_soft) ns = P.max_soft;
+            k_end = k_lo + ns;
+        } else {
+            // the symbols whose nominal position k sps lies below the centre of the first sub-block without a final
+            // estimate (the interpolation below never reads past b_known, so a rounding of this bound only moves a
+            // symbol into the next round)
+            k_end = min((int)(((double)b_known + 0.5) * (double)kTimingBlock * P.inv_sps), k_lo + P.max_soft);
+        }
+        TT_MARK(9)
+        const int ring_lo = max(0, base + kRrcTile - kRing), ring_hi = base + kRrcTile;
+        const int ring_off = ring_lo % kRing;
+        const int b0_max = min(nb - 2, b_known - 1);
+        const float sps_f = (float)sps;
+        constexpr int SU = PER / 4;   // symbols per thread in flight together
+        // whole sample m and fraction mu of the instant t_k = (k + tau(k sps)) sps; SU symbols side by side so that their
+        // LDS round trips (two timing estimates, then four ring samples) overlap
+        auto instants = [&](int k0, int (&mm)[SU], float (&mu)[SU]) {
+            float tk[SU], uf[SU], ta[SU], tb2[SU], ff[SU];
+            int mk[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int k = min(k0 + u * kRrcThreads, k_end - 1);
+                const double kd = (double)k * sps;          // nominal position, exact split into whole samples + fraction
+                mk[u] = (int)kd;
+                tk[u] = (float)(kd - (double)mk[u]);
+                uf[u] = ((float)mk[u] + tk[u]) * (1.f / (float)kTimingBlock) - 0.5f;
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                // piecewise-linear timing estimate between sub-block centres (both estimates final: b0 + 1 <= b_known)
+                const int b0 = max(min((int)floorf(uf[u]), b0_max), 0);
+                ff[u] = fminf(fmaxf(uf[u] - (float)b0, 0.f), 1.f);
+                ta[u] = tau[b0 & (kTauRing - 1)];
+                tb2[u] = tau[min(b0 + 1, nb - 1) & (kTauRing - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const float tauk = ta[u] * (1.f - ff[u]) + tb2[u] * ff[u];
+                const float ts = tk[u] + tauk * sps_f;      // t_k relative to the whole sample mk
+                const float fl = floorf(ts);
+                mu[u] = ts - fl;
+                mm[u] = min(max(mk[u] + (int)fl, 1), n - 3);
+            }
+        };
+        bool any_direct = false;
+        for (int k0 = k_begin + tid; k0 < k_end; k0 += kRrcThreads * SU) {
+            FarrowTaps f[SU];
+            int mm[SU];
+            float mu[SU];
+            instants(k0, mm, mu);
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int m = mm[u];
+                f[u].mu = mu[u];
+                any_direct |= !(m - 1 >= ring_lo && m + 2 < ring_hi) && k0 + u * kRrcThreads < k_end;
+                const int p = min(max(m - 1, ring_lo), ring_hi - 4) - ring_lo + ring_off;   // < 2 kRing
+                f[u].ym1 = yring[ring_slot(p)];
+                f[u].y0 = yring[ring_slot(p + 1)];
+                f[u].y1 = yring[ring_slot(p + 2)];
+                f[u].y2 = yring[ring_slot(p + 3)];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int k = k0 + u * kRrcThreads;
+                if (k < k_end) sr[k - k_lo] = farrow_eval(f[u]);
+            }
+        }
+        if (any_direct) {
+            // the timing estimate has carried some instants out of the ring (more than 48 symbols from their nominal
+            // positions): their four filter outputs again from the input.  Rare, rolled, and kept apart from the loop
+            // above so that its loads never order that loop's registers; the explicit wait leaves nothing pending.
+            for (int k0 = k_begin + tid; k0 < k_end; k0 += kRrcThreads * SU) {
+                int mm[SU];
+                float mu[SU];
+                instants(k0, mm, mu);
+#pragma unroll 1
+                for (int u = 0; u < SU; ++u) {
+                    const int m = mm[u], k = k0 + u * kRrcThreads;
+                    if ((m - 1 >= ring_lo && m + 2 < ring_hi) || k >= k_end) continue;
+                    float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f, a3x = 0.f, a3y = 0.f;
+                    float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;   // sliding window x[idx - 3 .. idx - 1]
+                    const int first = m - 1 - H2;
+#pragma unroll 1
+                    for (int k2 = -3; k2 < NT; ++k2) {
+                        const int idx = first + k2 + 3;
+                        float2 q3 = make_float2(0.f, 0.f);
+                        if (idx >= 0 && idx < n) q3 = xr[idx];
+                        if (k2 >= 0) {   // tap k2 multiplies x[first + k2 + e] for output e
+                            const float h = P.taps[k2];
+                            a0x = fmaf(h, q0.x, a0x); a0y = fmaf(h, q0.y, a0y);
+                            a1x = fmaf(h, q1.x, a1x); a1y = fmaf(h, q1.y, a1y);
+                            a2x = fmaf(h, q2.x, a2x); a2y = fmaf(h, q2.y, a2y);
+                            a3x = fmaf(h, q3.x, a3x); a3y = fmaf(h, q3.y, a3y);
+                        }
+                        q0 = q1; q1 = q2; q2 = q3;
+                    }
+                    FarrowTaps f;
+                    f.mu = mu[u];
+                    f.ym1 = make_float2(a0x, a0y);
+                    f.y0 = make_float2(a1x, a1y);
+                    f.y1 = make_float2(a2x, a2y);
+                    f.y2 = make_float2(a3x, a3y);
+                    sr[k - k_lo] = farrow_eval(f);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+        }
+        k_begin = max(k_begin, k_end);
+        TT_MARK(10)
     }
-    __syncthreads();
-    // 4. differential products and the 4th-power carrier-offset estimate (per-thread sums in index order)
+    __syncthreads();   // the carrier's soft symbols are visible to the whole workgroup
+    // ---- differential products and the 4th-power carrier-offset estimate (per-thread sums in index order).  The
+    // carrier's soft symbols come back from L2: every load is unconditional (clamped index) so that a thread's
+    // 2 U loads are in flight together.
+    constexpr int U = kSymUnroll;
     float a4r = 0.f, a4i = 0.f;
-    for (int i0 = 1 + tid; i0 < ns; i0 += kSymThreads * U) {
+    for (int i0 = 1 + tid; i0 < ns; i0 += kRrcThreads * U) {
         float2 c[U], p[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * kSymThreads;
-            if (i < ns) { c[u] = sr[i]; p[u] = sr[i - 1]; }
+            const int i = min(i0 + u * kRrcThreads, ns - 1);
+            c[u] = sr[i];
+            p[u] = sr[i - 1];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * kSymThreads;
-            if (i < ns) {
+            if (i0 + u * kRrcThreads < ns) {
                 const float2 d = make_float2(c[u].x * p[u].x + c[u].y * p[u].y, c[u].y * p[u].x - c[u].x * p[u].y);
                 const float2 d2 = cmulf(d, d);
                 const float2 d4 = cmulf(d2, d2);
@@ -357,34 +505,41 @@ __global__ __launch_bounds__(kSymThreads) void k_tetra_sym(const float2 *__restr
     if (tid == 0) delta_s = (a4r == 0.f && a4i == 0.f) ? 0.f : atan2f(-a4i, -a4r) * 0.25f;
     __syncthreads();
     float rs, rc;
-    sincosf(-delta_s, &rs, &rc);
-    // 5. quadrant decision of d_k exp(-i delta): +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3
-    float margin = 3.4e38f;
-    for (int i0 = 1 + tid; i0 < ns; i0 += kSymThreads * U) {
+    __sincosf(-delta_s, &rs, &rc);   // |delta| <= pi/4
+    // ---- quadrant decision of d_k exp(-i delta): +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3
+    float mratio = 3.4e38f;   // smallest min(|re|,|im|) / max(|re|,|im|): the angular distance to the nearest boundary is its atan
+    uint8_t *hr = hard + (int64_t)row * P.max_soft;
+    auto decide = [&](float2 d, int i) {
+        const float2 dd = make_float2(d.x * rc - d.y * rs, d.x * rs + d.y * rc);
+        hr[i - 1] = dd.y >= 0.f ? (dd.x >= 0.f ? 0 : 1) : (dd.x >= 0.f ? 2 : 3);
+        const float ax = fabsf(dd.x), ay = fabsf(dd.y);
+        const float lo = fminf(ax, ay), hi = fmaxf(ax, ay);
+        mratio = fminf(mratio, hi > 0.f ? __fdividef(lo, hi) : 0.f);
+    };
+    for (int i0 = 1 + tid; i0 < ns; i0 += kRrcThreads * U) {
         float2 c[U], p[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * kSymThreads;
-            if (i < ns) { c[u] = sr[i]; p[u] = sr[i - 1]; }
+            const int i = min(i0 + u * kRrcThreads, ns - 1);
+            c[u] = sr[i];
+            p[u] = sr[i - 1];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * kSymThreads;
-            if (i < ns) {
-                const float2 d = make_float2(c[u].x * p[u].x + c[u].y * p[u].y, c[u].y * p[u].x - c[u].x * p[u].y);
-                const float2 dd = make_float2(d.x * rc - d.y * rs, d.x * rs + d.y * rc);
-                const uint8_t h = dd.y >= 0.f ? (dd.x >= 0.f ? 0 : 1) : (dd.x >= 0.f ? 2 : 3);
-                hard[(int64_t)row * P.max_soft + i - 1] = h;
-                // angular distance to the nearest decision boundary (an axis)
-                const float ang = atan2f(fabsf(dd.y), fabsf(dd.x));      // 0 .. pi/2
-                margin = fminf(margin, fminf(ang, 1.5707963267948966f - ang));
-            }
+            const int i = i0 + u * kRrcThreads;
+            if (i < ns) decide(make_float2(c[u].x * p[u].x + c[u].y * p[u].y, c[u].y * p[u].x - c[u].x * p[u].y), i);
         }
     }
+    float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;   // (a NaN ratio never replaces the running minimum)
     margin = block_min(margin, sm);
+    TT_MARK(11)
+#ifdef TDM_TETRA_TIMING
+    if ((tid & 63) == 0 && row % 64 == 0)
+        for (int q = 0; q < 12; ++q) atomicAdd(&g_tetra_dbg[q], tt[q]);
+#endif
     if (tid == 0) {
         n_soft[row] = ns;
-        if (timing_milli) timing_milli[row] = (int32_t)rintf(tau[nb / 2] * 1000.f);
+        if (timing_milli) timing_milli[row] = (int32_t)rintf(tau_mid_s * 1000.f);
         if (min_margin) min_margin[row] = (double)margin;
     }
 }

@@ -1,0 +1,45 @@
+// TETRA mode: constants, kernel parameters and the launch entry (the kernels live in tetra_kernels.hpp, compiled in
+// tdm_tetra.hip; the rest of the library sees only this header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tdm {
+
+constexpr int kRrcMaxTaps = 96;
+constexpr int kRrcThreads = 256;
+#ifndef TDM_TETRA_PER
+#define TDM_TETRA_PER 8
+#endif
+constexpr int kRrcPerThread = TDM_TETRA_PER;              // consecutive outputs per thread (4 or 8)
+constexpr int kRrcPadShift = kRrcPerThread == 4 ? 2 : 3;  // LDS: one pad slot per kRrcPerThread samples
+constexpr int kRrcTile = kRrcThreads * kRrcPerThread;     // samples per round of a workgroup
+constexpr int kTimingBlock = 256;                         // samples per timing sub-block (TB)
+constexpr int kTimingHalfWin = 2;                         // sub-blocks averaged each side (TW)
+constexpr int kMaxTimingBlocks = 512;
+constexpr int kTileBlocks = kRrcTile / kTimingBlock;      // sub-blocks per tile
+// Matched-filter outputs kept in LDS: after tile i the ring holds samples [T(i+1) - kRing, T(i+1)), T = kRrcTile.  Round
+// i emits the symbols whose nominal position lies in [T i - 640, T(i+1) - 640) (640 = 2.5 sub-blocks: their two timing
+// estimates are final then), so the ring covers them with kRing - T - 640 samples to spare below and 640 above: that
+// is how far the unwrapped timing estimate may carry a symbol instant from its nominal position (48 symbols at 8
+// samples/symbol) before the symbol takes the direct path (its four filter outputs recomputed from the input).
+constexpr int kRing = kRrcPerThread == 4 ? 2048 : 3072;
+constexpr int kTauRing = 32;                              // timing estimates kept (a round reads at most kTileBlocks + 2 of them)
+
+struct TetraParams {
+    int32_t n;          // samples per carrier chunk
+    int32_t ntaps;      // odd
+    int32_t max_soft;   // capacity of per-carrier symbol outputs
+    int32_t pad_;
+    double sps;         // samples per symbol (sample_rate / 18000)
+    double inv_sps;
+    float ev_c[kRrcPerThread], ev_s[kRrcPerThread];   // exp(-2 pi i v / sps), v < kRrcPerThread: symbol-clock phasor inside a thread's run
+    float tile_c, tile_s;                             // exp(-2 pi i kRrcTile / sps): advance per tile
+    float taps[kRrcMaxTaps];
+};
+
+// one launch of the fused receiver on `rows` carriers; returns false when no kernel is instantiated for tp.ntaps
+bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, uint8_t *hard,
+                  int32_t *n_soft, int32_t *timing_milli, double *min_margin, hipStream_t stream);
+
+}  // namespace tdm

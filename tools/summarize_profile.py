@@ -56,9 +56,9 @@ def main():
     t = traffic(os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write"), "k_lp2<", 1024 * 26215)
     if t:
         prof["lp2"] = t
-    t = traffic(os.path.join(src, "pmc_tetra_fetch"), os.path.join(src, "pmc_tetra_write"), "k_tetra_rrc", 4096 * 32768)
+    t = traffic(os.path.join(src, "pmc_tetra_fetch"), os.path.join(src, "pmc_tetra_write"), "k_tetra_fused", 4096 * 32768)
     if t:
-        prof["tetra_rrc"] = t
+        prof["tetra_fused"] = t
     t = traffic(os.path.join(src, "pmc_pfb_fetch"), os.path.join(src, "pmc_pfb_write"), "k_pfb_fft", 32 * 1048576)
     if t:
         prof["pfb"] = t
@@ -69,7 +69,7 @@ def main():
     with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as f:
         json.dump(prof, f, indent=1)
     print(json.dumps({k: (v.get("hbm_bytes_per_input_sample") if isinstance(v, dict) else None)
-                      for k, v in prof.items() if k in ("k1", "tetra_rrc", "pfb")}))
+                      for k, v in prof.items() if k in ("k1", "tetra_fused", "pfb")}))
 
 
 if __name__ == "__main__":
