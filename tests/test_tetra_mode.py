@@ -115,6 +115,42 @@ def test_gpu_tetra_every_rate_in_the_contract_and_nonfinite_input():
     bd.close()
 
 
+@pytest.mark.gpu
+def test_gpu_tetra_instants_beyond_the_ring():
+    """Symbol instants that leave the matched-filter ring in LDS (48 symbols below, 80 above their nominal positions at
+    8 samples/symbol) take the kernel's direct path (filter outputs recomputed from the input).
+    (a) A sampling-clock offset of -0.4 % walks the instants 65 symbols early over a 131 072-sample chunk; the fp64
+        definition tracks the drift through its unwrap and the device follows it symbol for symbol.
+    (b) No trackable clock offset reaches 80 symbols late, so two tones whose beat sits just off the symbol rate turn
+        the timing statistic by 0.3 cycles per sub-block: the estimate runs to +-150 symbols, deterministically and
+        with wide decision margins, and device and definition must agree exactly."""
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    fs, n = 144000.0, 131072
+    sps = fs / 18000.0
+    x, dib = make_signal(n, fs * (1 - 0.004), 4321, 0.1, 20.0, 25.0)
+    cases = [(x, 384, 1e-3, 1e-3)]
+    t = np.arange(n)
+    for eps in (-0.3 / 256, 0.3 / 256):
+        fb = 1 / sps + eps
+        tone = (np.exp(2j * np.pi * (fb / 2) * t) + 0.8 * np.exp(-2j * np.pi * (fb / 2) * t + 0.4j)).astype(np.complex64)
+        cases.append((tone, 640, 2e-4, 0.0))
+    for x, reach, soft_tol, hard_tol in cases:
+        ref_hard, _, info = tetra_np.demod(x.astype(np.complex128), fs)
+        assert abs(info["tau"][-1]) * sps > reach + 100, info["tau"][-1]     # the instants do leave the ring
+        bd = BatchDemodulator(fs, n, 2, "cf32", mode=MODE_TETRA)
+        hards, softs, timing, margin = bd.process(np.concatenate([x, x]))
+        bd.close()
+        for r in range(2):
+            assert len(softs[r]) == info["n_sym"], (len(softs[r]), info["n_sym"])
+            scale = np.max(np.abs(info["sym"]))
+            assert np.max(np.abs(softs[r] - info["sym"])) < soft_tol * scale
+            # ((a): interpolating under a moving clock leaves a raw error rate of a few 1e-3, decisions next to a
+            # boundary may differ between fp32 and fp64)
+            assert np.mean(hards[r] != ref_hard) <= hard_tol
+        np.testing.assert_array_equal(hards[0], hards[1])
+
+
 def _wideband(n, fs, ks, M, seed0=300, snr_db=25.0):
     """Sum of pi/4-DQPSK carriers on the channeliser grid (channel index k -> k*fs/M, k >= M/2 negative)."""
     acc = np.zeros(n, dtype=np.complex128)
