@@ -93,6 +93,14 @@ TDM_API int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_car
                     int32_t mode, int32_t device, tdm_plan **out);
 TDM_API int tdm_plan_destroy(tdm_plan *plan);
 TDM_API int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
+/* Serve another chunk length with the same plan (TDM_MODE_REFERENCE): the reference designs its filters inside every
+ * process() call (processor.py:78, :254), so its callers read whatever lengths they like (ui/modern.py:1912 128 Ki,
+ * scanner.py:347 min(fs*dwell, 256 Ki), rtl_auto_capture.py:182 args.chunk).  Only the last block's tables and the edge
+ * maps depend on the length: the first call for a length builds and uploads those (a fraction of a millisecond, one
+ * allocation), a length seen before is a look-up; the large tables are uploaded once per plan and the work buffers are
+ * shared between lengths (they grow when a longer chunk arrives).  tdm_plan_get_info then describes the new length.
+ * Kernels already enqueued keep running; do not call it concurrently with a process call on the same plan.        */
+TDM_API int tdm_plan_resize(tdm_plan *plan, int64_t n_samples);
 
 /* ---- SignalProcessor.process (processor.py:221-273), batched over carriers ----------------
  *  iq            [n_carriers] streams of n_samples in the plan's format; carrier c starts at

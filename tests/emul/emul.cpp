@@ -264,7 +264,7 @@ struct HostZp {
     {
         ZpParams &p = t.p;
         const int D = p.nsec * p.K;
-        t.bind(p, t.blob.data());
+        t.bind(p, t.blob.data(), t.shared ? t.shared->blob.data() : nullptr);
         const double nan = std::numeric_limits<double>::quiet_NaN();
         y0.assign((size_t)rows * p.n_out * 2 + 2, nan);
         Ef.assign((size_t)rows * p.nb * D * 2, nan);
@@ -314,7 +314,7 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
     HostZp dec, lpf, dec_raw;
     RefBuffers B;
     if (h.decimated) { dec.t = h.dec; dec.bind(rows); B.dec_params = dec.t.p; }
-    if (h.lpf) { lpf.t = h.lpf_t; lpf.bind(rows); B.lpf_params = lpf.t.p; }
+    if (h.lpf && !h.lp2.ok) { lpf.t = h.lpf_t; lpf.bind(rows); B.lpf_params = lpf.t.p; }
     std::vector<double> zt, lp2p;
     if (h.lp2.ok) {
         B.lp2 = h.lp2.p;
@@ -447,7 +447,7 @@ int emu_carry_terms(double sample_rate, int64_t n, int32_t *dec_terms, int32_t *
 {
     RefPlanHost h = build_ref_plan(sample_rate, n);
     *dec_terms = h.decimated ? h.dec.p.carry_terms : 0;
-    *lpf_terms = h.lpf ? h.lpf_t.p.carry_terms : 0;
+    *lpf_terms = (h.lpf && !h.lp2.ok) ? h.lpf_t.p.carry_terms : 0;   // (the one-kernel low-rate stage has no carries)
     *nb_dec = h.decimated ? h.dec.p.nb : 0;
     return 0;
 }

@@ -358,3 +358,56 @@ def test_decimate_entry_vs_goldens(gold_stages):
     import scipy.signal as sg                     # (present on the GPU box as in this container; the goldens above do not need it)
     ref = sg.decimate(x, 23)
     assert np.max(np.abs(dec(23) - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+def test_one_plan_serves_ragged_lengths():
+    """tdm_plan_resize: one 3-carrier plan walks through 48 chunk lengths (more than it keeps variants for), shorter and
+    longer than the length it was made for (work buffers grow), revisits lengths, and every call equals the C oracle;
+    fresh SignalProcessor objects (signal/scanner.py:164 makes one per call) share one plan."""
+    import time
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    from tetraear_amd.batch import BatchDemodulator
+    from tetraear_amd.signal import processor as P
+    fs, rows = 2.4e6, 3
+    rng = np.random.default_rng(5)
+    lens = [40000, 131072, 28, 5000, 262144, 16, 131072, 40000, 300001] + [int(x) for x in rng.integers(100, 200000, 39)]
+    bd = BatchDemodulator(fs, lens[0], rows, "cu8")
+    ref = OracleSignalProcessor(fs)
+    t_new, t_hit, seen = [], [], set()
+    for it, n in enumerate(lens):
+        t0 = time.perf_counter()
+        bd.resize(n)
+        dt = (time.perf_counter() - t0) * 1e3
+        if n not in seen:
+            t_new.append(dt)
+        seen.add(n)
+        assert bd.info.n_samples == n
+        u8 = np.stack([synth.noise_cu8(n, 900 + 7 * it + r) for r in range(rows)])
+        fo = [0.0, 1234.5, -3000.25]
+        hards, softs, bp, mm = bd.process(u8, freq_offsets=fo)
+        for r in range(rows):
+            want = ref.process(synth.cu8_to_c128(u8[r]), fo[r])
+            np.testing.assert_array_equal(hards[r], want)
+            assert len(softs[r]) == len(ref.symbols)
+            if len(ref.symbols):
+                assert np.max(np.abs(softs[r] - ref.symbols)) <= 1e-10 * (np.max(np.abs(ref.symbols)) or 1.0), (n, r)
+    t_hit = []
+    for n in lens[-6:]:   # (no buffer growth since these were made: look-ups)
+        t0 = time.perf_counter()
+        bd.resize(n)
+        t_hit.append((time.perf_counter() - t0) * 1e3)
+    bd.close()
+    print(f"resize: new length {np.median(t_new):.3f} ms (median of {len(t_new)}), seen length {np.median(t_hit):.4f} ms")
+    assert np.median(t_new) < 5.0 and np.median(t_hit) < 0.2
+    # instances share the plan of their (device, rate, format)
+    P.close_plans()
+    a, b = P.SignalProcessor(fs), P.SignalProcessor(fs)
+    u8 = synth.noise_cu8(30000, 1)
+    ha = a.process_cu8(u8)
+    t0 = time.perf_counter()
+    hb = b.process_cu8(u8)
+    dt = (time.perf_counter() - t0) * 1e3
+    np.testing.assert_array_equal(ha, hb)
+    assert len(P._PLANS) == 1
+    print(f"second instance, same length: {dt:.3f} ms per process_cu8 call (no plan built)")

@@ -39,6 +39,7 @@ SIGNATURES = {
     "tdm_plan_create": (C.c_int, [_f64, _i64, _i32, _i32, _i32, _i32, _P(_vp)]),
     "tdm_plan_destroy": (C.c_int, [_vp]),
     "tdm_plan_get_info": (C.c_int, [_vp, _P(PlanInfo)]),
+    "tdm_plan_resize": (C.c_int, [_vp, _i64]),
     "tdm_process": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_process_device": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_plan_sync": (C.c_int, [_vp]),

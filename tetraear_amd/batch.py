@@ -64,6 +64,17 @@ class BatchDemodulator:
         self.mode = mode
         self.soft_dtype = np.complex64 if mode == _lib.MODE_TETRA else np.complex128
 
+    def resize(self, n_samples):
+        """Serve another chunk length with this plan (tdm_plan_resize): tables of a new length are built once (a fraction of
+        a millisecond), a length seen before is a look-up; `info` then describes the new length.  Device I/O buffers made
+        by alloc_device_io keep their size: call it again if the new length needs more."""
+        n_samples = int(n_samples)
+        if n_samples != self.n_samples:
+            check(self.lib.tdm_plan_resize(self.handle, n_samples))
+            check(self.lib.tdm_plan_get_info(self.handle, C.byref(self.info)))
+            self.n_samples = n_samples
+        return self
+
     # ---- host-pointer path ------------------------------------------------------------------
     def process(self, iq, freq_offsets=None, pre_shifts=None, shared_input=False):
         """iq: array holding the carriers back to back (or one shared stream). Returns

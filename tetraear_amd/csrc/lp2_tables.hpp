@@ -104,8 +104,8 @@ inline Lp2Host build_lp2(const double (*sos)[6], int64_t n, int edge, int sps, c
         p.seed_groups = groups + 1;
         h.seeds.assign((size_t)2 * p.seed_groups * kLp2SeedDoubles, 0.0);
         for (int v = 0; v < 2; ++v) {
-            const double *T1 = dec_t->blob.data() + (v ? dec_t->off_T1last : dec_t->off_T1reg);
-            const double *T2 = dec_t->blob.data() + (v ? dec_t->off_T2last : dec_t->off_T2reg);
+            const double *T1 = v ? dec_t->blob.data() + dec_t->off_T1last : dec_t->reg_tables() + dec_t->off_T1reg;
+            const double *T2 = v ? dec_t->blob.data() + dec_t->off_T2last : dec_t->reg_tables() + dec_t->off_T2reg;
             const int R = v ? dec->R_last : dec->R_reg;
             for (int t = 0; t < p.seed_groups; ++t) {
                 double *o = &h.seeds[((size_t)v * p.seed_groups + t) * kLp2SeedDoubles];

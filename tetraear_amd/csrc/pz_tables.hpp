@@ -159,24 +159,153 @@ inline PzDesign design_pz(const double (*sos)[6], int nsec)
     return d;
 }
 
-// L = samples per lane (a multiple of out_stride whenever S > 0 outputs per lane are tabulated), S = outputs per
-// lane of the in-lane tables.
+// ---- tables.  L = samples per lane (a multiple of out_stride whenever S > 0 outputs per lane are tabulated), S =
+// outputs per lane of the in-lane tables.
 // in_scale / in_offset: the kernel runs on u with x = in_scale*u - in_offset (raw-integer kernel; 1 and 0 otherwise):
 // every output-side coefficient carries in_scale, and off_yc holds in_offset * H(1)^2.
-inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n, int edge, int L, int S,
-                                    int64_t n_out, int out_stride, double in_scale = 1.0, double in_offset = 0.0)
+//
+// Everything that does not depend on the row length n is built once (PzShared: the design, the unit-state response
+// sequences in long double, the scan / transition matrices and the full blocks' carry tables); the tables of a given
+// length (last block's carry tables, edge maps, geometry) come from it in a fraction of the time, so that one plan
+// serves ragged read sizes (scanner.py:347, rtl_auto_capture.py:182) without rebuilding or re-uploading the large tables.
+struct PzShared : ZpSharedTables {
+    int nsec = 0, edge = 0, L = 0, S = 0, qs = 1;
+    double in_offset = 0;
+    double sos_a[kMaxSec][3];
+    PzDesign dz;                       // b0, b1, dx already scaled by in_scale
+    detail::ldbl h1 = 1;               // H(1)
+    std::vector<detail::ldbl> ubuf;    // [D][ulen] unit-state responses u[-ext-1 .. Bn+ext+1]
+    size_t ulen = 0;
+    int64_t ext = 0;
+    size_t off_Mpow = 0, off_T1reg = 0, off_T2reg = 0, off_Mf = 0, off_Ureg = 0;
+    std::vector<double> pz;            // the constant block with every length-independent entry filled in
+    const detail::ldbl *useq(int k) const { return ubuf.data() + (size_t)k * ulen + ext + 1; }
+};
+
+namespace detail {
+// carry-response tables of a block of `len` positions (+ `extra` positions past its end), phase-major rows of D doubles:
+//   causal carry (w[-1], w[-2]) = e_kappa     -> output at offset m: b0 u_{m+1} + b1 u_m
+//   anticausal carry (w'[len], w'[len+1])     -> output at offset m: b0 u_{len-m} + b1 u_{len-m-1}
+inline void pz_fill_carry_tables(const PzShared &h, int len, int64_t extra, int R, double *o1, double *o2)
+{
+    const int D = 2 * h.nsec, qs = h.qs;
+    const int64_t mend = len + extra;
+    int ph = 0, r = 0;   // m = r*qs + ph
+    for (int64_t m = 0; m < mend; ++m) {
+        double *r1 = o1 + ((size_t)ph * R + r) * D, *r2 = o2 + ((size_t)ph * R + r) * D;
+        for (int k = 0; k < D; ++k) {
+            const ldbl *u = h.useq(k);
+            const ldbl b0 = h.dz.b0[k >> 1], b1 = h.dz.b1[k >> 1];
+            r1[k] = (double)(b0 * u[m + 1] + b1 * u[m]);
+            r2[k] = (double)(b0 * u[len - m] + b1 * u[len - m - 1]);
+        }
+        if (++ph == qs) { ph = 0; ++r; }
+    }
+}
+}  // namespace detail
+
+inline std::shared_ptr<const PzShared> build_pz_shared(const double (*sos)[6], int nsec, int edge, int L, int S, int out_stride,
+                                                       double in_scale = 1.0, double in_offset = 0.0)
 {
     using namespace detail;
+    auto sh = std::make_shared<PzShared>();
+    PzShared &h = *sh;
+    const int NP = nsec, D = 2 * nsec, qs = out_stride;
+    h.nsec = nsec; h.edge = edge; h.L = L; h.S = S; h.qs = qs; h.in_offset = in_offset;
+    for (int s = 0; s < nsec; ++s)
+        for (int k = 0; k < 3; ++k) h.sos_a[s][k] = sos[s][3 + k];
+    h.dz = design_pz(sos, nsec);
+    PzDesign &dz = h.dz;
+    for (int s = 0; s < nsec; ++s) h.h1 *= (ldbl)sos[s][0] * 4 / (1 + dz.a1[s] + dz.a2[s]);   // H(1) = prod g_s * 4 / (1 + a1 + a2)
+    for (int s = 0; s < nsec; ++s) { dz.b0[s] *= (ldbl)in_scale; dz.b1[s] *= (ldbl)in_scale; }
+    dz.dx *= (ldbl)in_scale;
+    const std::vector<ldbl> &a1 = dz.a1, &a2 = dz.a2, &b0 = dz.b0, &b1 = dz.b1;
+    const std::vector<M2> &C = dz.C;
+    const int64_t Bn = (int64_t)kWave * L;
+    const int R_reg = (int)((Bn + qs - 1) / qs);
+
+    size_t total = 0;
+    auto reserve = [&](size_t cnt) { size_t o = total; total += cnt; return o; };
+    h.off_Mpow = reserve((size_t)nsec * kScanSteps * 4);
+    h.off_T1reg = reserve((size_t)qs * R_reg * D);
+    h.off_T2reg = reserve((size_t)qs * R_reg * D);
+    h.off_Mf = reserve((size_t)D * D);
+    h.off_Ureg = reserve((size_t)D * D);   // stays zero: the two banks do not couple
+    h.blob.assign(total, 0.0);
+    std::vector<double> &blob = h.blob;
+    h.pz.assign((size_t)PzLayout::size(S), 0.0);
+    double *pz = h.pz.data();
+
+    // ---- scan matrices C^(L 2^j); lane-distance matrices of the cross-row scan steps; block transition
+    for (int s = 0; s < NP; ++s) {
+        for (int r = 0; r < 16; ++r) {
+            const M2 m = m2pow(C[s], (long)L * (r + 1));
+            double *o = &pz[PzLayout::off_rowm(S) + ((size_t)r * PzLayout::kMaxPairs + s) * 4];
+            o[0] = (double)m.a; o[1] = (double)m.b; o[2] = (double)m.c; o[3] = (double)m.d;
+        }
+        for (int j = 0; j < kScanSteps; ++j) {
+            const M2 m = m2pow(C[s], (long)L << j);
+            double *o = &blob[h.off_Mpow + ((size_t)s * kScanSteps + j) * 4];
+            o[0] = (double)m.a; o[1] = (double)m.b; o[2] = (double)m.c; o[3] = (double)m.d;
+        }
+        const M2 mf = m2pow(C[s], (long)Bn);
+        blob[h.off_Mf + (2 * s) * D + 2 * s] = (double)mf.a;
+        blob[h.off_Mf + (2 * s) * D + 2 * s + 1] = (double)mf.b;
+        blob[h.off_Mf + (2 * s + 1) * D + 2 * s] = (double)mf.c;
+        blob[h.off_Mf + (2 * s + 1) * D + 2 * s + 1] = (double)mf.d;
+    }
+    // ---- unit-state responses u_m = C^m e_kappa (first component), all D of them
+    h.ext = (int64_t)kPzExtraRows * qs;
+    h.ulen = (size_t)(Bn + 2 * h.ext + 4);
+    h.ubuf.resize(h.ulen * D);
+    for (int s = 0; s < NP; ++s)
+        for (int kap = 0; kap < 2; ++kap) {
+            ldbl *u = h.ubuf.data() + (size_t)(2 * s + kap) * h.ulen + h.ext + 1;
+            ldbl v0 = kap == 0 ? 1 : 0, v1 = kap == 0 ? 0 : 1;   // (w[n], w[n-1]) pair; u_0 = first comp of e_kappa
+            for (int64_t m = 0; m <= Bn + h.ext + 1; ++m) {
+                u[m] = v0;
+                const ldbl nv = -a1[s] * v0 - a2[s] * v1;
+                v1 = v0;
+                v0 = nv;
+            }
+            // the same sequence continued to negative indices: u[k-1] = -(u[k+1] + a1 u[k]) / a2
+            for (int64_t m = 0; m >= -h.ext; --m) u[m - 1] = -(u[m + 1] + a1[s] * u[m]) / a2[s];
+            // in-lane tables: outputs of a lane at local positions t*qs
+            for (int tt = 0; tt < S; ++tt) {
+                const int m = tt * qs;
+                pz[PzLayout::off_zf + (s * S + tt) * 2 + kap] = (double)(b0[s] * u[m + 1] + b1[s] * u[m]);
+                pz[PzLayout::off_zb(S) + (s * S + tt) * 2 + kap] = (double)(b0[s] * u[L - m] + b1[s] * u[L - m - 1]);
+            }
+        }
+    for (int s = 0; s < NP; ++s) {
+        pz[PzLayout::off_a1 + s] = (double)a1[s];
+        pz[PzLayout::off_a2 + s] = (double)a2[s];
+        pz[PzLayout::off_b0 + s] = (double)b0[s];
+        pz[PzLayout::off_b1 + s] = (double)b1[s];
+        pz[PzLayout::off_g + s] = (double)(1 / (1 + a1[s] + a2[s]));
+    }
+    pz[PzLayout::off_dx] = (double)dz.dx;
+    pz[PzLayout::off_yc] = (double)((ldbl)in_offset * h.h1 * h.h1);
+    for (int r = 0; r < D; ++r) pz[PzLayout::off_wx(S) + r] = (double)dz.AE[(size_t)r * (D + 1) + D];
+    pz_fill_carry_tables(h, (int)Bn, 0, R_reg, &blob[h.off_T1reg], &blob[h.off_T2reg]);   // the full blocks' carry tables
+    return sh;
+}
+
+// tables of one row length from the shared part
+inline ZpHostTables build_pz_tables(const std::shared_ptr<const PzShared> &sh, int64_t n, int64_t n_out)
+{
+    using namespace detail;
+    const PzShared &h = *sh;
     ZpHostTables t;
     std::memset(&t.p, 0, sizeof(t.p));
     ZpParams &p = t.p;
-    const int NP = nsec, D = 2 * nsec;
+    const int nsec = h.nsec, NP = nsec, D = 2 * nsec, L = h.L, S = h.S, edge = h.edge;
     p.nsec = nsec;
     p.K = 2;
     p.pform = 1;
     for (int s = 0; s < nsec; ++s) {
         p.b[s][0] = 1; p.b[s][1] = 2; p.b[s][2] = 1;
-        for (int k = 0; k < 3; ++k) p.a[s][k] = sos[s][3 + k];
+        for (int k = 0; k < 3; ++k) p.a[s][k] = h.sos_a[s][k];
     }
     p.in_gain = 1.0;
     p.n = n;
@@ -189,126 +318,53 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
     p.nb = (int32_t)((p.Ne + Bn - 1) / Bn);
     p.len_last = (int32_t)(p.Ne - (int64_t)(p.nb - 1) * Bn);
     p.n_out = n_out;
-    p.out_stride = out_stride;
-    const int qs = out_stride, len_last = p.len_last;
-    PzDesign dz = design_pz(sos, nsec);
-    ldbl h1 = 1;   // H(1) = prod g_s * 4 / (1 + a1 + a2)
-    for (int s = 0; s < nsec; ++s) h1 *= (ldbl)sos[s][0] * 4 / (1 + dz.a1[s] + dz.a2[s]);
-    for (int s = 0; s < nsec; ++s) { dz.b0[s] *= (ldbl)in_scale; dz.b1[s] *= (ldbl)in_scale; }
-    dz.dx *= (ldbl)in_scale;
-    const std::vector<ldbl> &a1 = dz.a1, &a2 = dz.a2, &b0 = dz.b0, &b1 = dz.b1;
-    const std::vector<M2> &C = dz.C;
+    p.out_stride = h.qs;
+    const int qs = h.qs, len_last = p.len_last;
+    const std::vector<M2> &C = h.dz.C;
+    t.shared = sh;
+    t.off_Mpow = h.off_Mpow; t.off_T1reg = h.off_T1reg; t.off_T2reg = h.off_T2reg; t.off_Mf = h.off_Mf; t.off_Ureg = h.off_Ureg;
 
-    std::vector<double> &blob = t.blob;
-    auto reserve = [&](size_t cnt) { size_t o = blob.size(); blob.resize(o + cnt, 0.0); return o; };
-    t.off_Mpow = reserve((size_t)nsec * kScanSteps * 4);
-    t.off_zirh = reserve(1);
     // the last block's tables run kPzExtraRows outputs past its end (both responses continued by their own recurrence):
     // a consumer that walks whole groups of outputs (lp2_kernels.hpp) may then read rows of outputs the row does not have
     p.R_reg = (int32_t)((Bn + qs - 1) / qs);
     p.R_last = (len_last + qs - 1) / qs + kPzExtraRows;
+    size_t total = 0;
+    auto reserve = [&](size_t cnt) { size_t o = total; total += cnt; return o; };
+    t.off_zirh = reserve(1);
     t.off_cflast = reserve((size_t)D);
-    t.off_T1reg = reserve((size_t)qs * p.R_reg * D);
-    t.off_T2reg = reserve((size_t)qs * p.R_reg * D);
+    reserve(1);   // (keeps the tables below on 16-byte boundaries)
     t.off_T1last = reserve((size_t)qs * p.R_last * D);
     t.off_T2last = reserve((size_t)qs * p.R_last * D);
-    t.off_Mf = reserve((size_t)D * D);
     t.off_Mblast = reserve((size_t)D * D);
-    t.off_Ureg = reserve((size_t)D * D);   // stays zero: the two banks do not couple
     t.off_Ulast = reserve((size_t)D * D);
-    if (blob.size() & 1) reserve(1);   // 16-byte alignment of the block (its lane tables are read as pairs)
-    t.off_pz = reserve((size_t)PzLayout::size(S));
-    auto prow = [&](int m, int R) { return (size_t)(m % qs) * R + (size_t)(m / qs); };
-
-    // ---- scan matrices C^(L 2^j); lane-distance matrices of the cross-row scan steps; block transitions
+    t.off_pz = reserve((size_t)PzLayout::size(S));   // 16-byte aligned: its lane tables are read as pairs
+    t.blob.assign(total, 0.0);
+    std::vector<double> &blob = t.blob;
     for (int s = 0; s < NP; ++s) {
-        for (int r = 0; r < 16; ++r) {
-            const M2 m = m2pow(C[s], (long)L * (r + 1));
-            double *o = &blob[t.off_pz + PzLayout::off_rowm(S) + ((size_t)r * PzLayout::kMaxPairs + s) * 4];
-            o[0] = (double)m.a; o[1] = (double)m.b; o[2] = (double)m.c; o[3] = (double)m.d;
-        }
-        for (int j = 0; j < kScanSteps; ++j) {
-            const M2 m = m2pow(C[s], (long)L << j);
-            double *o = &blob[t.off_Mpow + ((size_t)s * kScanSteps + j) * 4];
-            o[0] = (double)m.a; o[1] = (double)m.b; o[2] = (double)m.c; o[3] = (double)m.d;
-        }
-        const M2 mf = m2pow(C[s], (long)Bn), ml = m2pow(C[s], (long)len_last);
-        auto put = [&](size_t off, const M2 &m) {
-            blob[off + (2 * s) * D + 2 * s] = (double)m.a;
-            blob[off + (2 * s) * D + 2 * s + 1] = (double)m.b;
-            blob[off + (2 * s + 1) * D + 2 * s] = (double)m.c;
-            blob[off + (2 * s + 1) * D + 2 * s + 1] = (double)m.d;
-        };
-        put(t.off_Mf, mf);
-        put(t.off_Mblast, ml);
+        const M2 ml = m2pow(C[s], (long)len_last);
+        blob[t.off_Mblast + (2 * s) * D + 2 * s] = (double)ml.a;
+        blob[t.off_Mblast + (2 * s) * D + 2 * s + 1] = (double)ml.b;
+        blob[t.off_Mblast + (2 * s + 1) * D + 2 * s] = (double)ml.c;
+        blob[t.off_Mblast + (2 * s + 1) * D + 2 * s + 1] = (double)ml.d;
     }
-    // ---- carry-response tables.  u_m = C^m e_kappa (first component):
-    //   causal carry (w[-1], w[-2]) = e_kappa     -> output at offset m: b0 u_{m+1} + b1 u_m
-    //   anticausal carry (w'[len], w'[len+1])     -> output at offset m: b0 u_{len-m} + b1 u_{len-m-1}
-    const int64_t ext = (int64_t)kPzExtraRows * qs;
-    std::vector<ldbl> ubuf((size_t)(Bn + 2 * ext + 4));
-    ldbl *u = ubuf.data() + ext + 1;   // u[-ext-1 .. Bn+ext+1]
-    for (int s = 0; s < NP; ++s)
-        for (int kap = 0; kap < 2; ++kap) {
-            ldbl v0 = kap == 0 ? 1 : 0, v1 = kap == 0 ? 0 : 1;   // (w[n], w[n-1]) pair; u_0 = first comp of e_kappa
-            for (int64_t m = 0; m <= Bn + ext + 1; ++m) {
-                u[m] = v0;
-                const ldbl nv = -a1[s] * v0 - a2[s] * v1;
-                v1 = v0;
-                v0 = nv;
-            }
-            // the same sequence continued to negative indices: u[k-1] = -(u[k+1] + a1 u[k]) / a2
-            for (int64_t m = 0; m >= -ext; --m) u[m - 1] = -(u[m + 1] + a1[s] * u[m]) / a2[s];
-            const int k = 2 * s + kap;
-            for (int v = 0; v < 2; ++v) {
-                const int len = v ? len_last : (int)Bn;
-                const int R = v ? p.R_last : p.R_reg;
-                const size_t o1 = v ? t.off_T1last : t.off_T1reg, o2 = v ? t.off_T2last : t.off_T2reg;
-                const int64_t mend = v ? len + ext : len;
-                for (int64_t m = 0; m < mend; ++m) {
-                    blob[o1 + prow((int)m, R) * D + k] = (double)(b0[s] * u[m + 1] + b1[s] * u[m]);
-                    blob[o2 + prow((int)m, R) * D + k] = (double)(b0[s] * u[len - m] + b1[s] * u[len - m - 1]);
-                }
-            }
-            // in-lane tables: outputs of a lane at local positions t*qs
-            double *pz = &blob[t.off_pz];
-            for (int tt = 0; tt < S; ++tt) {
-                const int m = tt * qs;
-                pz[PzLayout::off_zf + (s * S + tt) * 2 + kap] =
-                    (double)(b0[s] * u[m + 1] + b1[s] * u[m]);
-                pz[PzLayout::off_zb(S) + (s * S + tt) * 2 + kap] =
-                    (double)(b0[s] * u[L - m] + b1[s] * u[L - m - 1]);
-            }
-        }
+    pz_fill_carry_tables(h, len_last, h.ext, p.R_last, &blob[t.off_T1last], &blob[t.off_T2last]);
+    double *pz = &blob[t.off_pz];
+    std::memcpy(pz, h.pz.data(), h.pz.size() * sizeof(double));
     {
-        double *pz = &blob[t.off_pz];
-        for (int s = 0; s < NP; ++s) {
-            pz[PzLayout::off_a1 + s] = (double)a1[s];
-            pz[PzLayout::off_a2 + s] = (double)a2[s];
-            pz[PzLayout::off_b0 + s] = (double)b0[s];
-            pz[PzLayout::off_b1 + s] = (double)b1[s];
-            pz[PzLayout::off_g + s] = (double)(1 / (1 + a1[s] + a2[s]));
-        }
-        pz[PzLayout::off_dx] = (double)dz.dx;
-        pz[PzLayout::off_yc] = (double)((ldbl)in_offset * h1 * h1);
-    }
-    {
-        const std::vector<ldbl> &AE = dz.AE;
+        const std::vector<ldbl> &AE = h.dz.AE;
         // the kernel exports the inclusive scan state of the lane that holds the last position, i.e. the state
         // after that lane's zero-padded tail: undo the kinv padded steps (a few dozen at most, mildly expanding)
         const int kinv = L - 1 - (len_last - 1) % L;
-        double *pz = &blob[t.off_pz];
-        for (int r = 0; r < D; ++r) {
-            for (int s = 0; s < NP; ++s) {
-                const M2 ml = m2pow(C[s], (long)len_last);
-                const M2 ci = m2pow(m2inv(C[s]), (long)kinv);
+        for (int s = 0; s < NP; ++s) {
+            const M2 ml = m2pow(C[s], (long)len_last);
+            const M2 ci = m2pow(m2inv(C[s]), (long)kinv);
+            for (int r = 0; r < D; ++r) {
                 const ldbl e0 = AE[(size_t)r * (D + 1) + 2 * s], e1 = AE[(size_t)r * (D + 1) + 2 * s + 1];
                 pz[PzLayout::off_AG(S) + r * D + 2 * s] = (double)(e0 * ml.a + e1 * ml.c);
                 pz[PzLayout::off_AG(S) + r * D + 2 * s + 1] = (double)(e0 * ml.b + e1 * ml.d);
                 pz[PzLayout::off_AE(S) + r * D + 2 * s] = (double)(e0 * ci.a + e1 * ci.c);
                 pz[PzLayout::off_AE(S) + r * D + 2 * s + 1] = (double)(e0 * ci.b + e1 * ci.d);
             }
-            pz[PzLayout::off_wx(S) + r] = (double)AE[(size_t)r * (D + 1) + D];
         }
     }
     // carry series length: smallest t with max|Mf^t| < 1e-30, capped at nb
@@ -328,6 +384,14 @@ inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n,
         p.carry_terms = terms;
     }
     return t;
+}
+
+// both parts at once (single-length users: the stand-alone decimate entry, tests)
+inline ZpHostTables build_pz_tables(const double (*sos)[6], int nsec, int64_t n, int edge, int L, int S,
+                                    int64_t n_out, int out_stride, double in_scale = 1.0, double in_offset = 0.0)
+{
+    auto sh = build_pz_shared(sos, nsec, edge, L, S, out_stride, in_scale, in_offset);
+    return build_pz_tables(sh, n, n_out);
 }
 
 }  // namespace tdm

@@ -51,9 +51,7 @@ void run_pz_block(BE &be, const RefPlanHost &h, const ZpParams &P, const RawLoad
     const int nb = h.dec.p.nb;
     switch (h.q) {
 #define TDM_PZ_CASE(Q, S) case Q: be.template pz_block<Q, S, kEdgeSos>(P, ld, nb, rows); break;
-        TDM_PZ_CASE(2, 16) TDM_PZ_CASE(3, 10) TDM_PZ_CASE(4, 8) TDM_PZ_CASE(5, 6) TDM_PZ_CASE(6, 5) TDM_PZ_CASE(7, 4)
-        TDM_PZ_CASE(8, 4) TDM_PZ_CASE(9, 3) TDM_PZ_CASE(10, 3) TDM_PZ_CASE(11, 2) TDM_PZ_CASE(12, 2) TDM_PZ_CASE(13, 2)
-        TDM_PZ_CASE(14, 2) TDM_PZ_CASE(15, 2) TDM_PZ_CASE(16, 2) TDM_PZ_CASE(41, 1)
+        TDM_PZ_CASES(TDM_PZ_CASE)
 #undef TDM_PZ_CASE
     default: break;   // (build_ref_plan only sets pz_S for the factors above)
     }
@@ -69,8 +67,7 @@ void run_pz_raw(BE &be, const RefPlanHost &h, const ZpParams &P, const void *iq,
     if (b_tail > nb - 1) b_tail = nb - 1;
     switch (h.q) {
 #define TDM_PZR_CASE(Q, S) case Q: be.template pz_raw<Q, S, kEdgeSos, FMT_CU8>(P, iq, stride, b_tail, rows); break;
-        TDM_PZR_CASE(3, 16) TDM_PZR_CASE(4, 16) TDM_PZR_CASE(6, 16) TDM_PZR_CASE(7, 16) TDM_PZR_CASE(8, 15)
-        TDM_PZR_CASE(10, 12) TDM_PZR_CASE(12, 10) TDM_PZR_CASE(13, 8) TDM_PZR_CASE(41, 2)
+        TDM_PZR_CASES(TDM_PZR_CASE)
 #undef TDM_PZR_CASE
     default: break;
     }

@@ -23,27 +23,21 @@ constexpr int kEdgeSos = 27;  // sosfiltfilt pad for 4 sections: 3*(2*4+1)
 constexpr int kEdgeTf = 15;   // filtfilt pad for order 4: 3*5
 constexpr double kSymbolRate = 18000.0;
 
+// (decimation factor, outputs per lane) of the parallel-form decimator kernels, samples as doubles / raw bytes: the one
+// list the launch switches (ref_pipeline.hpp), the instantiations (tdm_k_pz.hip, tdm_k_raw.hip) and the tables below share
+#define TDM_PZ_CASES(X) X(2, 16) X(3, 10) X(4, 8) X(5, 6) X(6, 5) X(7, 4) X(8, 4) X(9, 3) X(10, 3) X(11, 2) X(12, 2) X(13, 2) X(14, 2) X(15, 2) X(16, 2) X(41, 1)
+#define TDM_PZR_CASES_A(X) X(3, 16) X(6, 16) X(8, 15) X(12, 10) X(41, 2)
+#define TDM_PZR_CASES_B(X) X(4, 16) X(7, 16) X(10, 12) X(13, 8)
+#define TDM_PZR_CASES(X) TDM_PZR_CASES_A(X) TDM_PZR_CASES_B(X)
+
 // Parallel-form decimator kernels exist for these decimation factors; S = outputs per lane (lane length
 // S*q <= 32 samples, 41 for the 10 MS/s case).  Any other factor runs on the cascade engine.
 inline int pz_outputs_per_lane(int q)
 {
     switch (q) {
-    case 2: return 16;
-    case 3: return 10;
-    case 4: return 8;
-    case 5: return 6;
-    case 6: return 5;
-    case 7: return 4;
-    case 8: return 4;
-    case 9: return 3;
-    case 10: return 3;
-    case 11: return 2;
-    case 12: return 2;
-    case 13: return 2;
-    case 14: return 2;
-    case 15: return 2;
-    case 16: return 2;
-    case 41: return 1;
+#define TDM_PZ_S(Q, S) case Q: return S;
+        TDM_PZ_CASES(TDM_PZ_S)
+#undef TDM_PZ_S
     default: return 0;
     }
 }
@@ -53,15 +47,9 @@ inline int pz_outputs_per_lane(int q)
 inline int pz_raw_outputs_per_lane(int q)
 {
     switch (q) {
-    case 3: return 16;
-    case 4: return 16;
-    case 6: return 16;
-    case 7: return 16;
-    case 8: return 15;
-    case 10: return 12;
-    case 12: return 10;
-    case 13: return 8;
-    case 41: return 2;
+#define TDM_PZR_S(Q, S) case Q: return S;
+        TDM_PZR_CASES(TDM_PZR_S)
+#undef TDM_PZR_S
     default: return 0;
     }
 }
@@ -124,7 +112,10 @@ inline ZpFilterDesc desc_from_sos(const Sos4 &s) { return desc_from_rows(s.sos, 
 // the order-4 channel filter runs as its two-biquad factorisation (see Tf4 in design.hpp)
 inline ZpFilterDesc desc_from_tf(const Tf4 &t) { return desc_from_rows(t.sos, 2); }
 
-inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidth = 25000.0, bool allow_pz = true, int in_fmt = -1)
+// base: a plan of the same sample rate, bandwidth and wire format (another length): its designs and the
+// length-independent tables of the parallel-form stages are reused, only the length-dependent part is built
+inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidth = 25000.0, bool allow_pz = true, int in_fmt = -1,
+                                  const RefPlanHost *base = nullptr)
 {
     RefPlanHost h;
     h.sample_rate = sample_rate;
@@ -138,23 +129,29 @@ inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidt
     h.phase_step = h.sps / 8 > 1 ? h.sps / 8 : 1;
     h.max_soft = h.sps > 1 ? h.n_dec / h.sps + 1 : h.n_dec;
     if (h.max_soft < 1) h.max_soft = 1;
-    if (h.q > 1) h.sos = design_cheby1_8(0.05, 0.8 / h.q);
-    h.tf = design_butter4(butter_cutoff(bandwidth, h.rate_dec));
+    if (base && base->sample_rate != sample_rate) base = nullptr;
+    if (h.q > 1) h.sos = base ? base->sos : design_cheby1_8(0.05, 0.8 / h.q);
+    h.tf = (base && base->rate_dec == h.rate_dec) ? base->tf : design_butter4(butter_cutoff(bandwidth, h.rate_dec));
     if (h.decimated) {
         h.pz_S = (allow_pz && rows_are_lp121(h.sos.sos, 4)) ? pz_outputs_per_lane(h.q) : 0;
-        if (h.pz_S)
-            h.dec = build_pz_tables(h.sos.sos, 4, n, kEdgeSos, h.q * h.pz_S, h.pz_S, h.n_dec, h.q);
-        else
+        if (h.pz_S) {
+            auto sh = (base && base->pz_S == h.pz_S && base->dec.shared) ? std::static_pointer_cast<const PzShared>(base->dec.shared)
+                                                                         : build_pz_shared(h.sos.sos, 4, kEdgeSos, h.q * h.pz_S, h.pz_S, h.q);
+            h.dec = build_pz_tables(sh, n, h.n_dec);
+        } else {
             h.dec = build_zp_tables(desc_from_sos(h.sos), n, kEdgeSos, kLDec, h.n_dec, h.q);
+        }
     }
-    if (h.lpf)
-        h.lpf_t = build_zp_tables(desc_from_tf(h.tf), h.n_dec, kEdgeTf, kLLpf, h.n_dec, 1);
     if (allow_pz && h.lpf && h.sps > 1 && h.sps <= 32 && (!h.decimated || h.pz_S) && rows_are_lp121(h.tf.sos, 2))
         h.lp2 = build_lp2(h.tf.sos, h.n_dec, kEdgeTf, h.sps, h.decimated ? &h.dec : nullptr, h.sos.sos);
+    if (h.lpf && !h.lp2.ok)   // (the cascade engine's tables: only where the one-kernel low-rate stage does not apply)
+        h.lpf_t = build_zp_tables(desc_from_tf(h.tf), h.n_dec, kEdgeTf, kLLpf, h.n_dec, 1);
     if (h.lp2.ok && h.decimated && in_fmt == 0 /* FMT_CU8 */ && pz_raw_outputs_per_lane(h.q)) {
         const int S = pz_raw_outputs_per_lane(h.q);
         // x = fl(1/127.5) * u - 1 (pyrtlsdr's conversion without its two roundings, see pz_raw_body)
-        h.dec_raw = build_pz_tables(h.sos.sos, 4, n, kEdgeSos, h.q * S, S, h.n_dec, h.q, 1.0 / 127.5, 1.0);
+        auto sh = (base && base->raw_S == S && base->dec_raw.shared) ? std::static_pointer_cast<const PzShared>(base->dec_raw.shared)
+                                                                     : build_pz_shared(h.sos.sos, 4, kEdgeSos, h.q * S, S, h.q, 1.0 / 127.5, 1.0);
+        h.dec_raw = build_pz_tables(sh, n, h.n_dec);
         h.lp2_raw = build_lp2(h.tf.sos, h.n_dec, kEdgeTf, h.sps, &h.dec_raw, h.sos.sos);
         if (h.lp2_raw.ok) h.raw_S = S;
     }

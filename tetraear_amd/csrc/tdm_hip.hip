@@ -17,15 +17,11 @@
 
 #include "../../include/tetrahip.h"
 #include "ref_pipeline.hpp"
+#include "dev_comm.hpp"
+#include "launch.hpp"
 #include "resample_plan.hpp"
 #include "sync_kernels.hpp"
 #include "tetra_params.hpp"
-#ifdef TDM_ZP_TIMING
-__device__ unsigned long long g_zp_dbg[16];
-#endif
-#ifdef TDM_LP2_TIMING
-__device__ unsigned long long g_lp2_dbg[16];
-#endif
 #include "pfb_kernels.hpp"
 #include "gate_kernels.hpp"
 #include "detect_kernels.hpp"
@@ -68,160 +64,8 @@ static int use_device(int device)
 }
 
 // ------------------------------------------------------------------------------------------
-// device-side communication objects
-// ------------------------------------------------------------------------------------------
-struct WaveComm {
-    double *stg;
-    __device__ __forceinline__ double *stage() { return stg; }
-    __device__ __forceinline__ double *edge_slots() { return stg; }
-    // ---- lane-row shuffles of the parallel-form scan (DPP: VALU moves, no LDS traffic)
-    template <int CTRL, int ROW_MASK, bool BOUND>
-    static __device__ __forceinline__ double dpp(double v)
-    {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BOUND);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BOUND);
-        return __hiloint2double(hi, lo);
-    }
-    template <int K, int CTRL, int ROW_MASK, bool BOUND>
-    static __device__ __forceinline__ void dpp2(const double *a, const double *b, double *oa, double *ob)
-    {
-#pragma unroll
-        for (int k = 0; k < K; ++k) { oa[k] = dpp<CTRL, ROW_MASK, BOUND>(a[k]); ob[k] = dpp<CTRL, ROW_MASK, BOUND>(b[k]); }
-    }
-    // out[lane] = in[lane - d] inside the lane's row of 16, 0 where the row has no such lane (d = 1, 2, 4, 8)
-    template <int K>
-    __device__ __forceinline__ void row_shr2(const double *a, const double *b, double *oa, double *ob, int d)
-    {
-        switch (d) {
-        case 1: dpp2<K, 0x111, 0xf, true>(a, b, oa, ob); break;
-        case 2: dpp2<K, 0x112, 0xf, true>(a, b, oa, ob); break;
-        case 4: dpp2<K, 0x114, 0xf, true>(a, b, oa, ob); break;
-        default: dpp2<K, 0x118, 0xf, true>(a, b, oa, ob); break;
-        }
-    }
-    template <int K>
-    __device__ __forceinline__ void row_shl2(const double *a, const double *b, double *oa, double *ob, int d)
-    {
-        switch (d) {
-        case 1: dpp2<K, 0x101, 0xf, true>(a, b, oa, ob); break;
-        case 2: dpp2<K, 0x102, 0xf, true>(a, b, oa, ob); break;
-        case 4: dpp2<K, 0x104, 0xf, true>(a, b, oa, ob); break;
-        default: dpp2<K, 0x108, 0xf, true>(a, b, oa, ob); break;
-        }
-    }
-    // step 0: rows 1,3 <- lane 15 of rows 0,2 (row_bcast:15); step 1: rows 2,3 <- lane 31 (row_bcast:31); 0 elsewhere
-    template <int K>
-    __device__ __forceinline__ void row_total_prev2(const double *a, const double *b, double *oa, double *ob, int step)
-    {
-        if (step == 0) dpp2<K, 0x142, 0xa, false>(a, b, oa, ob);
-        else dpp2<K, 0x143, 0xc, false>(a, b, oa, ob);
-    }
-    // mirror image (no DPP form exists): step 0: rows 0,2 <- lane 0 of rows 1,3; step 1: rows 0,1 <- lane 32; 0 elsewhere
-    template <int K>
-    __device__ __forceinline__ void row_total_next2(const double *a, const double *b, double *oa, double *ob, int step)
-    {
-        const int lane = threadIdx.x & 63;
-        const int src = step == 0 ? (lane & ~15) + 16 : 32;
-        const bool ok = step == 0 ? ((lane & 16) == 0) : (lane < 32);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const double x = __shfl(a[k], src, 64), y = __shfl(b[k], src, 64);
-            oa[k] = ok ? x : 0.0;
-            ob[k] = ok ? y : 0.0;
-        }
-    }
-    // whole-wave shift by one lane, 0 shifted in
-    template <int K>
-    __device__ __forceinline__ void wave_shr1(const double *a, const double *b, double *oa, double *ob) { dpp2<K, 0x138, 0xf, true>(a, b, oa, ob); }
-    template <int K>
-    __device__ __forceinline__ void wave_shl1(const double *a, const double *b, double *oa, double *ob) { dpp2<K, 0x130, 0xf, true>(a, b, oa, ob); }
-    __device__ __forceinline__ void wave_sync() { __syncthreads(); }  // one wavefront per workgroup
-    template <int K>
-    __device__ __forceinline__ void shfl_up2(const double *a, const double *b, double *oa, double *ob, int d)
-    {
-#pragma unroll
-        for (int k = 0; k < K; ++k) { oa[k] = __shfl_up(a[k], d, 64); ob[k] = __shfl_up(b[k], d, 64); }
-    }
-    template <int K>
-    __device__ __forceinline__ void shfl_down2(const double *a, const double *b, double *oa, double *ob, int d)
-    {
-#pragma unroll
-        for (int k = 0; k < K; ++k) { oa[k] = __shfl_down(a[k], d, 64); ob[k] = __shfl_down(b[k], d, 64); }
-    }
-};
-
-// workgroup of kLp2Waves wavefronts (lp2_kernels.hpp): the wavefront shuffles of WaveComm + barrier and two LDS areas
-struct WgComm : WaveComm {
-    double *sml;
-    __device__ __forceinline__ double *small() { return sml; }
-    __device__ __forceinline__ int tid() const { return threadIdx.x; }
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-};
-
-constexpr int kFinishThreads = 256;
-
-struct BlockComm {
-    double *sm;  // [kFinishThreads / 64] LDS (reductions)
-    double *buf; // [kPowThreads] LDS (power_fixup scratch) or null
-    double *big = nullptr;  // large workgroup scratch (gate FFT) or null
-    __device__ __forceinline__ double *smem() { return big; }
-    __device__ __forceinline__ double &lds(int i) { return buf[i]; }
-    __device__ __forceinline__ int tid() const { return threadIdx.x; }
-    __device__ __forceinline__ int nthreads() const { return blockDim.x; }
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-    template <class F>
-    __device__ __forceinline__ double reduce(double v, F f)
-    {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v = f(v, __shfl_xor(v, d, 64));
-        const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        if ((threadIdx.x & 63) == 0) sm[w] = v;
-        __syncthreads();
-        double r = sm[0];
-        for (int i = 1; i < nw; ++i) r = f(r, sm[i]);
-        __syncthreads();
-        return r;
-    }
-    __device__ __forceinline__ double reduce_sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
-    __device__ __forceinline__ double reduce_max(double v) { return reduce(v, [](double a, double b) { return fmax(a, b); }); }
-    __device__ __forceinline__ double reduce_min(double v) { return reduce(v, [](double a, double b) { return fmin(a, b); }); }
-};
-
-// ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-#ifndef TDM_BLOCK_WAVES
-#define TDM_BLOCK_WAVES 2  // waves per SIMD the block kernel is register-budgeted for
-#endif
-template <int K, int NSEC, int L, int EDGE, class Loader>
-__global__ __launch_bounds__(64, (L <= 16 ? 4 : (L <= 24 ? 3 : TDM_BLOCK_WAVES))) void k_zp_block(const ZpParams P, const Loader ld)
-{
-    __shared__ __attribute__((aligned(16))) double stg[Loader::kStaged ? StageGeom<L>::kDoubles : 2];
-    WaveComm cm{stg};
-    zp_block_body<K, NSEC, L, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
-}
-
-// parallel-form decimator (pz_kernels.hpp): one wavefront per block of 64 lanes x Q*S samples
-template <int Q, int S, int EDGE, bool SHIFT>
-__global__ __launch_bounds__(64, (Q * S <= 32 ? 2 : 1)) void k_pz_block(const ZpParams P, const RawLoaderRT<SHIFT> ld)
-{
-    __shared__ __attribute__((aligned(16))) double stg[PzEdgeGeom<Q * S, EDGE>::kDoubles];
-    WaveComm cm{stg};
-    pz_block_body<Q, S, EDGE>(P, ld, cm, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y);
-}
-
-// low-rate stage in one kernel (lp2_kernels.hpp): grid = (chunks, rows), one workgroup of 8 wavefronts per chunk
-template <class Src>
-__global__ __launch_bounds__(kLp2Lanes, 2) void k_lp2(const Lp2Params P, const Src src)
-{
-    __shared__ __attribute__((aligned(16))) double stg[Lp2Lds::kStage];
-    __shared__ __attribute__((aligned(16))) double sml[Lp2Lds::kSmall];
-    WgComm cm;
-    cm.stg = stg;
-    cm.sml = sml;
-    lp2_body(P, src, cm, (int)blockIdx.x, (int)blockIdx.y);
-}
-
 template <int K, int NSEC, bool FWD>
 __global__ __launch_bounds__(256) void k_zp_carry(const ZpParams P, int nb, int rows)
 {
@@ -235,20 +79,6 @@ __global__ __launch_bounds__(256) void k_zp_carry(const ZpParams P, int nb, int 
         zp_carry_fwd_body<K, NSEC>(P, row, b, ch);
     else
         zp_carry_bwd_body<K, NSEC>(P, row, b, ch);
-}
-
-// raw-integer decimator (pz_raw_body), one launch for all blocks of all rows: blocks without extension samples run the
-// narrow body (bytes as they come), the first block and the block(s) with the tail extension the wide one (int16 pairs)
-template <int Q, int S, int EDGE, int FMT8>
-__global__ __launch_bounds__(64, 2) void k_pz_raw(const ZpParams P, const void *iq, int64_t stride, int b_tail)
-{
-    __shared__ __attribute__((aligned(16))) double stg[PzEdgeGeom<Q * S, EDGE>::kDoubles];
-    WaveComm cm{stg};
-    const int blk = (int)blockIdx.x;
-    if (blk == 0 || blk >= b_tail)
-        pz_raw_body<Q, S, EDGE, FMT8, true>(P, iq, stride, cm, (int)threadIdx.x, blk, (int)blockIdx.y);
-    else
-        pz_raw_body<Q, S, EDGE, FMT8, false>(P, iq, stride, cm, (int)threadIdx.x, blk, (int)blockIdx.y);
 }
 
 template <int NSEC>
@@ -418,25 +248,25 @@ struct HipBackend {
     void zp_block(const ZpParams &P, Loader ld, int nb, int rows)
     {
         Scope s(*this, NSEC == 4 ? ST_DEC_BLOCK : ST_LPF_BLOCK);
-        hipLaunchKernelGGL((k_zp_block<K, NSEC, L, EDGE, Loader>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
+        launch_zp_block<K, NSEC, L, EDGE, Loader>(P, ld, nb, rows, stream);
     }
     template <int Q, int S, int EDGE, bool SHIFT>
     void pz_block(const ZpParams &P, const RawLoaderRT<SHIFT> &ld, int nb, int rows)
     {
         Scope s(*this, ST_DEC_BLOCK);
-        hipLaunchKernelGGL((k_pz_block<Q, S, EDGE, SHIFT>), dim3(nb, rows), dim3(64), 0, stream, P, ld);
+        launch_pz_block<Q, S, EDGE, SHIFT>(P, ld, nb, rows, stream);
     }
     template <int Q, int S, int EDGE, int FMT8>
     void pz_raw(const ZpParams &P, const void *iq, int64_t stride, int b_tail, int rows)
     {
         Scope s(*this, ST_DEC_BLOCK);
-        hipLaunchKernelGGL((k_pz_raw<Q, S, EDGE, FMT8>), dim3(P.nb, rows), dim3(64), 0, stream, P, iq, stride, b_tail);
+        launch_pz_raw<Q, S, EDGE, FMT8>(P, iq, stride, b_tail, rows, stream);
     }
     template <class Src>
     void lp2(const Lp2Params &P, const Src &src, int rows)
     {
         Scope s(*this, ST_LPF_BLOCK);
-        hipLaunchKernelGGL((k_lp2<Src>), dim3(P.n_chunks, rows), dim3(kLp2Lanes), 0, stream, P, src);
+        launch_lp2<Src>(P, src, rows, stream);
     }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
@@ -507,58 +337,41 @@ static std::vector<double> tetra_rrc_taps(double sps)
 }
 
 // ------------------------------------------------------------------------------------------
-// device copies of a zero-phase stage
+// plan.  A plan is made for (sample rate, wire format, carriers) and a chunk length; it serves any other chunk length
+// through tdm_plan_resize: per length a VARIANT (the host plan + one small device allocation with the tables that depend
+// on the length), while the large length-independent tables are uploaded once and the work buffers are shared and only
+// ever grow.  Ragged reads (scanner.py:347, rtl_auto_capture.py:182) therefore cost a fraction of a millisecond the
+// first time a length is seen and nothing afterwards.
 // ------------------------------------------------------------------------------------------
-struct DevZp {
-    ZpParams params{};  // host copy whose pointers are device addresses (passed by value to kernels)
-    double *d_blob = nullptr;
-    double *d_work = nullptr;
-    int init(const ZpHostTables &t, int rows)
-    {
-        ZpParams p = t.p;
-        const int D = p.nsec * p.K;
-        HIP_TRY(hipMalloc(&d_blob, t.blob.size() * sizeof(double)));
-        HIP_TRY(hipMemcpy(d_blob, t.blob.data(), t.blob.size() * sizeof(double), hipMemcpyHostToDevice));
-        t.bind(p, d_blob);
-        const size_t n_y0 = (size_t)rows * p.n_out * 2;
-        const size_t n_e = (size_t)rows * p.nb * D * 2;
-        const size_t total = n_y0 + 4 * n_e + (size_t)rows * 2 + (size_t)rows * D * 2;
-        HIP_TRY(hipMalloc(&d_work, total * sizeof(double)));
-        p.y0 = d_work;
-        p.Ef = p.y0 + n_y0;
-        p.Eb = p.Ef + n_e;
-        p.Gf = p.Eb + n_e;
-        p.Hb = p.Gf + n_e;
-        p.flast = p.Hb + n_e;
-        p.Elast = p.flast + (size_t)rows * 2;
-        params = p;
-        return TDM_OK;
-    }
-    void destroy()
-    {
-        if (d_blob) (void)hipFree(d_blob);
-        if (d_work) (void)hipFree(d_work);
-        d_blob = nullptr; d_work = nullptr;
-    }
+struct Variant {
+    RefPlanHost h;
+    double *d_tab = nullptr;     // the length-dependent tables of every stage, one allocation
+    ZpParams dec{}, lpf{}, dec_raw{};
+    Lp2Params lp2{}, lp2_raw{};
+    double *d_y = nullptr, *d_z = nullptr, *d_partials = nullptr;
+    uint64_t stamp = 0;          // last use (eviction order)
+    ~Variant() { if (d_tab) (void)hipFree(d_tab); }
 };
 
-// ------------------------------------------------------------------------------------------
-// plan
-// ------------------------------------------------------------------------------------------
+constexpr size_t kMaxVariants = 32;
+
 struct tdm_plan {
-    RefPlanHost h;
     int rows = 0, fmt = 0, mode = 0, device = 0;
-    DevZp dec, lpf, dec_raw;
-    double *d_y = nullptr, *d_z = nullptr, *d_partials = nullptr;
-    double *d_zt = nullptr, *d_lp2p = nullptr, *d_lp2m = nullptr, *d_lp2s = nullptr, *d_lp2c = nullptr;   // lp2: phase-major filter output, chunk partials, lane matrices, seed rows
-    Lp2Params lp2{}, lp2_raw{};
-    double *d_lp2s_raw = nullptr, *d_lp2c_raw = nullptr;
+    bool allow_raw = true;
+    std::map<int64_t, std::unique_ptr<Variant>> variants;
+    Variant *cur = nullptr;
+    uint64_t clock = 0;
+    std::map<const ZpSharedTables *, std::pair<std::shared_ptr<const ZpSharedTables>, double *>> d_shared;   // uploaded once per plan
+    double *d_work = nullptr;    // work buffers of the stages, carved per variant, sized for the longest chunk so far
+    size_t work_doubles = 0;
+    const RefPlanHost &h() const { return cur->h; }
     // TETRA mode
     TetraParams tp{};
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
     bool staging_ready = false;
+    size_t staging_soft = 0;     // rows * max_soft the staging buffers were sized for
     double *d_pre = nullptr, *d_foff = nullptr, *d_soft = nullptr, *d_margin = nullptr;
     uint8_t *d_hard = nullptr;
     int32_t *d_nsoft = nullptr, *d_bp = nullptr;
@@ -567,16 +380,163 @@ struct tdm_plan {
     StageTimer timer;
 };
 
+static inline size_t even(size_t x) { return (x + 1) & ~(size_t)1; }   // 16-byte granules
+
+// work doubles of one zero-phase stage: y0, Ef, Eb, Gf, Hb, flast, Elast
+static size_t zp_work_doubles(const ZpParams &p, int rows)
+{
+    const int D = p.nsec * p.K;
+    const size_t n_y0 = even((size_t)rows * p.n_out * 2), n_e = (size_t)rows * p.nb * D * 2;
+    return n_y0 + 4 * n_e + (size_t)rows * 2 + (size_t)rows * D * 2;
+}
+static double *zp_bind_work(ZpParams &p, int rows, double *w)
+{
+    const int D = p.nsec * p.K;
+    const size_t n_y0 = even((size_t)rows * p.n_out * 2), n_e = (size_t)rows * p.nb * D * 2;
+    p.y0 = w;
+    p.Ef = p.y0 + n_y0;
+    p.Eb = p.Ef + n_e;
+    p.Gf = p.Eb + n_e;
+    p.Hb = p.Gf + n_e;
+    p.flast = p.Hb + n_e;
+    p.Elast = p.flast + (size_t)rows * 2;
+    return w + zp_work_doubles(p, rows);
+}
+
+// the shared (length-independent) tables of a stage on the device, uploaded the first time the plan sees them
+static int shared_on_device(tdm_plan *plan, const std::shared_ptr<const ZpSharedTables> &sh, const double **out)
+{
+    *out = nullptr;
+    if (!sh) return TDM_OK;
+    auto it = plan->d_shared.find(sh.get());
+    if (it == plan->d_shared.end()) {
+        double *d = nullptr;
+        HIP_TRY(hipMalloc(&d, sh->blob.size() * sizeof(double)));
+        hipError_t e = hipMemcpy(d, sh->blob.data(), sh->blob.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return fail(TDM_ERR_HIP, std::string("hipMemcpy(shared tables): ") + hipGetErrorString(e)); }
+        it = plan->d_shared.emplace(sh.get(), std::make_pair(sh, d)).first;
+    }
+    *out = it->second.second;
+    return TDM_OK;
+}
+
+// Make the variant for chunk length n current (reference mode).
+static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
+{
+    auto hit = plan->variants.find(n);
+    if (hit != plan->variants.end()) {
+        plan->cur = hit->second.get();
+        plan->cur->stamp = ++plan->clock;
+        return TDM_OK;
+    }
+    const int rows = plan->rows;
+    std::unique_ptr<Variant> v(new Variant);
+    v->h = build_ref_plan(sample_rate, n, 25000.0, true, plan->allow_raw ? plan->fmt : -1, plan->cur ? &plan->cur->h : nullptr);
+    const RefPlanHost &h = v->h;
+    // ---- tables: the length-dependent ones of all stages in one allocation and one copy
+    const bool use_lpf = h.lpf && !h.lp2.ok;
+    std::vector<double> tab;
+    auto put = [&](const std::vector<double> &src) { const size_t o = tab.size(); tab.insert(tab.end(), src.begin(), src.end()); if (tab.size() & 1) tab.push_back(0.0); return o; };
+    const size_t o_dec = h.decimated ? put(h.dec.blob) : 0;
+    const size_t o_lpf = use_lpf ? put(h.lpf_t.blob) : 0;
+    const size_t o_raw = h.raw_S ? put(h.dec_raw.blob) : 0;
+    const size_t o_lm = h.lp2.ok ? put(h.lp2.lane_m) : 0, o_lc = h.lp2.ok ? put(h.lp2.cst) : 0, o_ls = h.lp2.ok ? put(h.lp2.seeds) : 0;
+    const size_t o_rc = h.raw_S ? put(h.lp2_raw.cst) : 0, o_rs = h.raw_S ? put(h.lp2_raw.seeds) : 0;
+    if (!tab.empty()) {
+        HIP_TRY(hipMalloc(&v->d_tab, tab.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(v->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int rc;
+    const double *sb = nullptr;
+    if (h.decimated) {
+        if ((rc = shared_on_device(plan, h.dec.shared, &sb))) return rc;
+        v->dec = h.dec.p;
+        h.dec.bind(v->dec, v->d_tab + o_dec, sb);
+    }
+    if (use_lpf) {
+        v->lpf = h.lpf_t.p;
+        h.lpf_t.bind(v->lpf, v->d_tab + o_lpf);
+    }
+    if (h.raw_S) {
+        if ((rc = shared_on_device(plan, h.dec_raw.shared, &sb))) return rc;
+        v->dec_raw = h.dec_raw.p;
+        h.dec_raw.bind(v->dec_raw, v->d_tab + o_raw, sb);
+    }
+    // ---- work: carved out of one buffer that only grows
+    // y: the low-rate signal when nothing downstream forms it on the fly (no decimation, or no channel filter);
+    // z / partials: only the cascade-engine fallback of the low-rate stage materialises them
+    const size_t nd = even((size_t)rows * h.n_dec * 2);
+    const bool need_y = !h.decimated || !h.lpf;
+    const bool need_z = !h.lp2.ok && h.lpf && !(h.sps > 1 && h.sps <= kMaxSps);
+    const size_t n_part = !h.lp2.ok ? even((size_t)rows * (h.n_dec / kPowThreads + 16) * kMaxSps) : 0;
+    const size_t n_zt = h.lp2.ok ? even((size_t)rows * h.sps * h.lp2.p.zt_k * 2) : 0;
+    const int max_chunks = h.raw_S && h.lp2_raw.p.n_chunks > h.lp2.p.n_chunks ? h.lp2_raw.p.n_chunks : h.lp2.p.n_chunks;
+    const size_t n_lp2p = h.lp2.ok ? even((size_t)rows * max_chunks * kMaxSps) : 0;
+    const size_t need = (h.decimated ? zp_work_doubles(v->dec, rows) : 0) + (use_lpf ? zp_work_doubles(v->lpf, rows) : 0) +
+                        (h.raw_S ? zp_work_doubles(v->dec_raw, rows) : 0) + n_zt + n_lp2p + (need_y ? nd : 0) + (need_z ? nd : 0) + n_part;
+    if (need > plan->work_doubles) {
+        // kernels of earlier calls may still be using the buffer; the other variants' pointers into it go stale
+        HIP_TRY(hipStreamSynchronize(plan->stream));
+        plan->cur = nullptr;
+        plan->variants.clear();
+        if (plan->d_work) (void)hipFree(plan->d_work);
+        plan->d_work = nullptr;
+        plan->work_doubles = 0;
+        HIP_TRY(hipMalloc(&plan->d_work, need * sizeof(double)));
+        plan->work_doubles = need;
+    }
+    double *w = plan->d_work;
+    if (h.decimated) w = zp_bind_work(v->dec, rows, w);
+    if (use_lpf) w = zp_bind_work(v->lpf, rows, w);
+    if (h.raw_S) w = zp_bind_work(v->dec_raw, rows, w);
+    if (h.lp2.ok) {
+        v->lp2 = h.lp2.p;
+        v->lp2.zt = w; w += n_zt;
+        v->lp2.partials = w; w += n_lp2p;
+        v->lp2.lane_m = v->d_tab + o_lm;
+        v->lp2.cst = v->d_tab + o_lc;
+        if (!h.lp2.seeds.empty()) v->lp2.seeds = v->d_tab + o_ls;
+        if (h.raw_S) {
+            // the raw-integer decimator's geometry: own tables and work buffers, same low-rate outputs
+            // (the edge constants depend on the lane grid's offset, which follows the decimator's block geometry)
+            v->lp2_raw = h.lp2_raw.p;
+            v->lp2_raw.zt = v->lp2.zt;
+            v->lp2_raw.partials = v->lp2.partials;
+            v->lp2_raw.lane_m = v->lp2.lane_m;
+            v->lp2_raw.cst = v->d_tab + o_rc;
+            v->lp2_raw.seeds = v->d_tab + o_rs;
+        }
+    }
+    if (need_y) { v->d_y = w; w += nd; }
+    if (need_z) { v->d_z = w; w += nd; }
+    if (n_part) { v->d_partials = w; w += n_part; }
+    // ---- keep it
+    if (plan->variants.size() >= kMaxVariants) {
+        auto old = plan->variants.begin();
+        for (auto it = plan->variants.begin(); it != plan->variants.end(); ++it)
+            if (it->second->stamp < old->second->stamp) old = it;
+        // (its tables may still be read by kernels in flight)
+        HIP_TRY(hipStreamSynchronize(plan->stream));
+        plan->variants.erase(old);
+    }
+    v->stamp = ++plan->clock;
+    plan->cur = v.get();
+    plan->variants[n] = std::move(v);
+    return TDM_OK;
+}
+
 static size_t fmt_bytes(int fmt) { return fmt == TDM_CU8 || fmt == TDM_CS8 ? 2 : (fmt == TDM_CF32 ? 8 : 16); }
 
 static void plan_free(tdm_plan *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    p->dec.destroy();
-    p->lpf.destroy();
-    p->dec_raw.destroy();
-    void *ptrs[] = {p->d_zt, p->d_lp2p, p->d_lp2m, p->d_lp2s, p->d_lp2c, p->d_lp2s_raw, p->d_lp2c_raw, p->d_y, p->d_z, p->d_partials, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    p->cur = nullptr;
+    p->variants.clear();
+    for (auto &kv : p->d_shared)
+        if (kv.second.second) (void)hipFree(kv.second.second);
+    void *ptrs[] = {p->d_work, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -658,13 +618,18 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         clock((double)kRrcTile, tp.tile_c, tp.tile_s);
         tp.max_soft = (int32_t)(n_samples / sps) + 4;
         for (size_t i = 0; i < h.size(); ++i) tp.taps[i] = (float)h[i];
-        p->h.sample_rate = sample_rate;
-        p->h.n = n_samples;
-        p->h.n_dec = n_samples;
-        p->h.rate_dec = sample_rate;
-        p->h.sps = (int)sps;
-        p->h.max_soft = tp.max_soft;
-        p->h.lpf = true;
+        {
+            std::unique_ptr<Variant> v(new Variant);
+            v->h.sample_rate = sample_rate;
+            v->h.n = n_samples;
+            v->h.n_dec = n_samples;
+            v->h.rate_dec = sample_rate;
+            v->h.sps = (int)sps;
+            v->h.max_soft = tp.max_soft;
+            v->h.lpf = true;
+            p->cur = v.get();
+            p->variants[n_samples] = std::move(v);
+        }
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&p->ev0));
         HIP_TRY(hipEventCreate(&p->ev1));
@@ -673,71 +638,35 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     }
     // (TDM_NO_RAW=1: experiments / tests keep cu8 plans on the kernel that holds its samples as doubles)
     const char *no_raw = std::getenv("TDM_NO_RAW");
-    p->h = build_ref_plan(sample_rate, n_samples, 25000.0, true, (no_raw && no_raw[0] == '1') ? -1 : in_fmt);
-    const RefPlanHost &h = p->h;
+    p->allow_raw = !(no_raw && no_raw[0] == '1');
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p->ev0));
     HIP_TRY(hipEventCreate(&p->ev1));
-    if (h.decimated && (rc = p->dec.init(h.dec, n_carriers))) return rc;
-    if (h.lpf && !h.lp2.ok && (rc = p->lpf.init(h.lpf_t, n_carriers))) return rc;
-    if (h.lp2.ok) {
-        p->lp2 = h.lp2.p;
-        HIP_TRY(hipMalloc(&p->d_zt, (size_t)n_carriers * h.sps * p->lp2.zt_k * 2 * sizeof(double)));
-        const int max_chunks = h.raw_S && h.lp2_raw.p.n_chunks > p->lp2.n_chunks ? h.lp2_raw.p.n_chunks : p->lp2.n_chunks;
-        HIP_TRY(hipMalloc(&p->d_lp2p, (size_t)n_carriers * max_chunks * kMaxSps * sizeof(double)));
-        HIP_TRY(hipMalloc(&p->d_lp2m, h.lp2.lane_m.size() * sizeof(double)));
-        HIP_TRY(hipMemcpy(p->d_lp2m, h.lp2.lane_m.data(), h.lp2.lane_m.size() * sizeof(double), hipMemcpyHostToDevice));
-        p->lp2.zt = p->d_zt;
-        p->lp2.partials = p->d_lp2p;
-        p->lp2.lane_m = p->d_lp2m;
-        HIP_TRY(hipMalloc(&p->d_lp2c, h.lp2.cst.size() * sizeof(double)));
-        HIP_TRY(hipMemcpy(p->d_lp2c, h.lp2.cst.data(), h.lp2.cst.size() * sizeof(double), hipMemcpyHostToDevice));
-        p->lp2.cst = p->d_lp2c;
-        if (!h.lp2.seeds.empty()) {
-            HIP_TRY(hipMalloc(&p->d_lp2s, h.lp2.seeds.size() * sizeof(double)));
-            HIP_TRY(hipMemcpy(p->d_lp2s, h.lp2.seeds.data(), h.lp2.seeds.size() * sizeof(double), hipMemcpyHostToDevice));
-            p->lp2.seeds = p->d_lp2s;
-        }
-        if (h.raw_S) {
-            // the raw-integer decimator's geometry: own tables and work buffers, same low-rate outputs
-            if ((rc = p->dec_raw.init(h.dec_raw, n_carriers))) return rc;
-            p->lp2_raw = h.lp2_raw.p;
-            p->lp2_raw.zt = p->d_zt;
-            p->lp2_raw.partials = p->d_lp2p;
-            p->lp2_raw.lane_m = p->d_lp2m;
-            // (the edge constants depend on the lane grid's offset, which follows the decimator's block geometry)
-            HIP_TRY(hipMalloc(&p->d_lp2c_raw, h.lp2_raw.cst.size() * sizeof(double)));
-            HIP_TRY(hipMemcpy(p->d_lp2c_raw, h.lp2_raw.cst.data(), h.lp2_raw.cst.size() * sizeof(double), hipMemcpyHostToDevice));
-            p->lp2_raw.cst = p->d_lp2c_raw;
-            HIP_TRY(hipMalloc(&p->d_lp2s_raw, h.lp2_raw.seeds.size() * sizeof(double)));
-            HIP_TRY(hipMemcpy(p->d_lp2s_raw, h.lp2_raw.seeds.data(), h.lp2_raw.seeds.size() * sizeof(double), hipMemcpyHostToDevice));
-            p->lp2_raw.seeds = p->d_lp2s_raw;
-        }
-    }
-    // y: the low-rate signal when nothing downstream forms it on the fly (no decimation, or no channel filter);
-    // z / partials: only the cascade-engine fallback of the low-rate stage materialises them
-    const size_t nd = (size_t)n_carriers * h.n_dec * 2 * sizeof(double);
-    if (!h.decimated || !h.lpf) HIP_TRY(hipMalloc(&p->d_y, nd));
-    if (!h.lp2.ok) {
-        if (h.lpf && !(h.sps > 1 && h.sps <= kMaxSps)) HIP_TRY(hipMalloc(&p->d_z, nd));
-        HIP_TRY(hipMalloc(&p->d_partials, (size_t)n_carriers * (h.n_dec / kPowThreads + 16) * kMaxSps * sizeof(double)));
-    }
+    if ((rc = plan_select(p.get(), sample_rate, n_samples))) return rc;
     *out = p.release();
     return TDM_OK;
 }
 
-#ifdef TDM_ZP_TIMING
-static void zp_timing_dump();
-#endif
+// Serve another chunk length with the same plan (reference mode).  The first call for a length builds its small tables
+// (a fraction of a millisecond, one allocation, one copy); a length seen before costs a map look-up.  Work buffers are
+// shared between lengths and grow when a longer chunk arrives.  Not to be called while another thread is inside a
+// process call of the same plan; kernels already enqueued on the plan's stream are unaffected.
+int tdm_plan_resize(tdm_plan *plan, int64_t n_samples)
+{
+    if (!plan) return fail(TDM_ERR_INVALID, "null plan");
+    if (plan->mode != TDM_MODE_REFERENCE) return fail(TDM_ERR_UNSUPPORTED, "TETRA-mode plans have one chunk length");
+    if (n_samples < 1 || n_samples > (int64_t(1) << 31)) return fail(TDM_ERR_INVALID, "bad n_samples");
+    if (plan->cur && plan->cur->h.n == n_samples) return TDM_OK;
+    HIP_TRY(hipSetDevice(plan->device));
+    const double fs = plan->cur ? plan->cur->h.sample_rate : 0.0;
+    if (!(fs > 0)) return fail(TDM_ERR_INVALID, "plan has no current length (an earlier resize failed)");
+    return plan_select(plan, fs, n_samples);
+}
+
 int tdm_plan_destroy(tdm_plan *plan)
 {
 #ifdef TDM_LP2_TIMING
-    {
-        unsigned long long h[16];
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lp2_dbg), sizeof(h)) == hipSuccess)
-            fprintf(stderr, "lp2 phases (memtime ticks): stage-in %llu fixup+nco %llu ext+pass1 %llu scans %llu pass2 %llu stage-out %llu store+power %llu\n",
-                    h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
-    }
+    lp2_timing_dump();
 #endif
 #ifdef TDM_ZP_TIMING
     zp_timing_dump();
@@ -749,7 +678,8 @@ int tdm_plan_destroy(tdm_plan *plan)
 int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info)
 {
     if (!plan || !info) return fail(TDM_ERR_INVALID, "null argument");
-    const RefPlanHost &h = plan->h;
+    if (!plan->cur) return fail(TDM_ERR_INVALID, "plan has no current length");
+    const RefPlanHost &h = plan->h();
     std::memset(info, 0, sizeof(*info));
     info->sample_rate = h.sample_rate;
     info->rate_dec = h.rate_dec;
@@ -793,30 +723,22 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
         if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
         return TDM_OK;
     }
+    if (!plan->cur) return fail(TDM_ERR_INVALID, "plan has no current length");
+    const Variant &v = *plan->cur;
     RefBuffers B;
-    B.dec_params = plan->dec.params;
-    B.lpf_params = plan->lpf.params;
-    B.y = plan->d_y;
-    B.z = plan->d_z;
-    B.partials = plan->d_partials;
-    B.lp2 = plan->lp2;
-    B.dec_raw_params = plan->dec_raw.params;
-    B.lp2_raw = plan->lp2_raw;
+    B.dec_params = v.dec;
+    B.lpf_params = v.lpf;
+    B.y = v.d_y;
+    B.z = v.d_z;
+    B.partials = v.d_partials;
+    B.lp2 = v.lp2;
+    B.dec_raw_params = v.dec_raw;
+    B.lp2_raw = v.lp2_raw;
     RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin};
-    run_ref(be, plan->h, plan->rows, plan->fmt, B, io);
+    run_ref(be, v.h, plan->rows, plan->fmt, B, io);
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
     return TDM_OK;
 }
-
-#ifdef TDM_ZP_TIMING
-static void zp_timing_dump()
-{
-    unsigned long long h[16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_zp_dbg), sizeof(h)) != hipSuccess) return;
-    fprintf(stderr, "zp phases (memtime ticks, summed over waves): dec load %llu fwd %llu bwd %llu out %llu | lpf load %llu fwd %llu bwd %llu out %llu \n",
-            h[0], h[1], h[2], h[3], h[8], h[9], h[10], h[11]);
-}
-#endif
 
 int tdm_set_stream(void *stream)
 {
@@ -846,7 +768,8 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
     if (!plan || !iq || !hard || !soft || !n_soft) return fail(TDM_ERR_INVALID, "null argument");
     if (carrier_stride_samples < 0) return fail(TDM_ERR_INVALID, "negative carrier stride");
     HIP_TRY(hipSetDevice(plan->device));
-    const RefPlanHost &h = plan->h;
+    if (!plan->cur) return fail(TDM_ERR_INVALID, "plan has no current length");
+    const RefPlanHost &h = plan->h();
     const int rows = plan->rows;
     const size_t span = carrier_stride_samples == 0 ? (size_t)h.n
                                                     : (size_t)(rows - 1) * carrier_stride_samples + h.n;
@@ -858,6 +781,7 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
         HIP_TRY(hipMalloc(&plan->d_iq, bytes));
         plan->d_iq_bytes = bytes;
     }
+    if (plan->staging_ready && plan->staging_soft < (size_t)rows * h.max_soft) plan->staging_ready = false;   // a longer chunk than the buffers were made for
     if (!plan->staging_ready) {
         // all or nothing: a failed allocation leaves the flag clear, the next call starts over (plan_free releases
         // whatever a failed attempt left behind)
@@ -871,6 +795,7 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
             HIP_TRY(hipMalloc(slots[i], sizes[i]));
         }
         plan->staging_ready = true;
+        plan->staging_soft = (size_t)rows * h.max_soft;
     }
     hipStream_t st = plan->stream;
     HIP_TRY(hipMemcpyAsync(plan->d_iq, iq, bytes, hipMemcpyHostToDevice, st));
@@ -897,7 +822,8 @@ int tdm_process_pipelined(tdm_plan *plan, const void *iq, int64_t n_batches, con
 {
     if (!plan || !iq || !hard || !soft || !n_soft || n_batches < 1) return fail(TDM_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(plan->device));
-    const RefPlanHost &h = plan->h;
+    if (!plan->cur) return fail(TDM_ERR_INVALID, "plan has no current length");
+    const RefPlanHost &h = plan->h();
     const int rows = plan->rows;
     const size_t in_bytes = (size_t)rows * h.n * fmt_bytes(plan->fmt);
     const size_t soft_elem = plan->mode == TDM_MODE_TETRA ? 2 * sizeof(float) : 2 * sizeof(double);
@@ -1078,11 +1004,89 @@ int tdm_dev_sync(int32_t device)
 
 // ---- single-method entry points (host pointers, blocking) ---------------------------------------
 namespace {
+// Device scratch of the stand-alone entry points (filter_signal, decimate, extract_symbols, ... each a host array in, a
+// host array out): buffers go back to a pool instead of hipFree, so a caller that uses these per read (scanner.py:42-147
+// style loops) pays for hipMalloc once per size class, not per call.  Every entry point synchronises the device before
+// it returns, so a pooled buffer is idle when it is handed out again.
+struct ScratchPool {
+    struct Ent { void *p; size_t bytes; int dev; };
+    std::vector<Ent> idle;
+    size_t held = 0;
+    std::mutex mu;
+    static constexpr size_t kMaxIdle = 24, kMaxHeld = size_t(1) << 30;
+    void *take(size_t bytes, int dev, size_t *got)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (int i = 0; i < (int)idle.size(); ++i)
+            if (idle[i].dev == dev && idle[i].bytes >= bytes && idle[i].bytes <= 4 * bytes + 65536 &&
+                (best < 0 || idle[i].bytes < idle[best].bytes))
+                best = i;
+        if (best < 0) return nullptr;
+        void *q = idle[best].p;
+        *got = idle[best].bytes;
+        held -= idle[best].bytes;
+        idle.erase(idle.begin() + best);
+        return q;
+    }
+    void give(void *q, size_t bytes, int dev)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        idle.push_back({q, bytes, dev});
+        held += bytes;
+        while (idle.size() > kMaxIdle || held > kMaxHeld) {   // drop the largest
+            int big = 0;
+            for (int i = 1; i < (int)idle.size(); ++i)
+                if (idle[i].bytes > idle[big].bytes) big = i;
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            (void)hipSetDevice(idle[big].dev);
+            (void)hipFree(idle[big].p);
+            (void)hipSetDevice(cur);
+            held -= idle[big].bytes;
+            idle.erase(idle.begin() + big);
+        }
+    }
+};
+static ScratchPool g_scratch;
+
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); return TDM_OK; }
+    size_t cap = 0;
+    int dev = 0;
+    ~DevBuf() { if (p) g_scratch.give(p, cap, dev); }
+    int alloc(size_t bytes)
+    {
+        if (!bytes) bytes = 16;
+        HIP_TRY(hipGetDevice(&dev));
+        if ((p = g_scratch.take(bytes, dev, &cap))) return TDM_OK;
+        bytes = (bytes + 4095) & ~size_t(4095);
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+        return TDM_OK;
+    }
     template <class T> T *as() { return (T *)p; }
+};
+
+// device copy of one zero-phase stage (tables + work for one row) out of the scratch pool
+struct DevZp {
+    ZpParams params{};
+    DevBuf blob, sblob, work;
+    int init(const ZpHostTables &t)
+    {
+        int rc;
+        params = t.p;
+        if ((rc = blob.alloc(t.blob.size() * sizeof(double)))) return rc;
+        HIP_TRY(hipMemcpy(blob.p, t.blob.data(), t.blob.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (t.shared) {
+            if ((rc = sblob.alloc(t.shared->blob.size() * sizeof(double)))) return rc;
+            HIP_TRY(hipMemcpy(sblob.p, t.shared->blob.data(), t.shared->blob.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        t.bind(params, blob.as<double>(), sblob.as<double>());
+        if ((rc = work.alloc(zp_work_doubles(params, 1) * sizeof(double)))) return rc;
+        zp_bind_work(params, 1, work.as<double>());
+        return TDM_OK;
+    }
 };
 
 // one zero-phase stage on a c128 host array
@@ -1091,8 +1095,7 @@ int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, do
     DevZp dz;
     DevBuf dx, dy;
     int rc;
-    if ((rc = dz.init(t, 1))) { dz.destroy(); return rc; }
-    struct Guard { DevZp &d; ~Guard() { d.destroy(); } } g{dz};
+    if ((rc = dz.init(t))) return rc;
     if ((rc = dx.alloc((size_t)n * 16))) return rc;
     if ((rc = dy.alloc((size_t)n_out * 16))) return rc;
     HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 16, hipMemcpyHostToDevice));

@@ -1,0 +1,41 @@
+// libtetrahip.so, low-rate stage translation unit: k_lp2 for both sample sources (gfx950 only).
+#include <cstdio>
+
+#include "dev_comm.hpp"
+#include "launch.hpp"
+
+namespace tdm {
+
+#ifdef TDM_LP2_TIMING
+__device__ unsigned long long g_lp2_dbg[16];
+void lp2_timing_dump()
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lp2_dbg), sizeof(h)) == hipSuccess)
+        fprintf(stderr, "lp2 phases (memtime ticks): stage-in %llu fixup+nco %llu ext+pass1 %llu scans %llu pass2 %llu stage-out %llu store+power %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+}
+#endif
+
+// low-rate stage in one kernel (lp2_kernels.hpp): grid = (chunks, rows), one workgroup of 8 wavefronts per chunk
+template <class Src>
+__global__ __launch_bounds__(kLp2Lanes, 2) void k_lp2(const Lp2Params P, const Src src)
+{
+    __shared__ __attribute__((aligned(16))) double stg[Lp2Lds::kStage];
+    __shared__ __attribute__((aligned(16))) double sml[Lp2Lds::kSmall];
+    WgComm cm;
+    cm.stg = stg;
+    cm.sml = sml;
+    lp2_body(P, src, cm, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+template <class Src>
+void launch_lp2(const Lp2Params &P, const Src &src, int rows, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_lp2<Src>), dim3(P.n_chunks, rows), dim3(kLp2Lanes), 0, st, P, src);
+}
+
+template void launch_lp2<Lp2SrcDec>(const Lp2Params &, const Lp2SrcDec &, int, hipStream_t);
+template void launch_lp2<Lp2SrcPlain>(const Lp2Params &, const Lp2SrcPlain &, int, hipStream_t);
+
+}  // namespace tdm

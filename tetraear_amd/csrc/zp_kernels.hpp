@@ -74,7 +74,7 @@ struct alignas(16) f64x2 {
 struct phasor {
     double c, s;
 };
-TDM_NOINLINE phasor nco_phasor(int64_t k, double f, double fs)
+inline TDM_NOINLINE phasor nco_phasor(int64_t k, double f, double fs)
 {
     const double ci = -(2.0 * M_PI) * f;
     const double t = (double)k / fs;

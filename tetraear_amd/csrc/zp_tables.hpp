@@ -4,6 +4,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "zp_common.hpp"
@@ -23,19 +24,29 @@ struct ZpFilterDesc {
     double in_gain;
 };
 
+// Tables of a stage that do not depend on the row length (parallel-form stages: scan matrices, block transitions, the
+// full blocks' carry-response tables): built once per plan and shared by every length the plan serves.
+struct ZpSharedTables {
+    std::vector<double> blob;
+    virtual ~ZpSharedTables() = default;
+};
+
 struct ZpHostTables {
     ZpParams p;                // table/work pointers are null until patched by the owner
-    std::vector<double> blob;  // all tables, concatenated
+    std::vector<double> blob;  // all tables, concatenated (with `shared`: only those that depend on the row length)
+    std::shared_ptr<const ZpSharedTables> shared;   // (parallel form) Mpow, T1/T2reg, Mf, Ureg live here
     size_t off_Mpow, off_zirh, off_cflast, off_T1reg, off_T2reg, off_T1last, off_T2last, off_Mf, off_Mblast, off_Ureg, off_Ulast, off_pz = 0;
-    // point p's table pointers into a copy of blob that lives at `base`
-    void bind(ZpParams &q, const double *base) const
+    // point p's table pointers into a copy of blob that lives at `base` (and a copy of shared->blob at `sbase`)
+    void bind(ZpParams &q, const double *base, const double *sbase = nullptr) const
     {
-        q.Mpow = base + off_Mpow; q.zirh = base + off_zirh; q.cf_last = base + off_cflast;
-        q.T1_reg = base + off_T1reg; q.T2_reg = base + off_T2reg;
-        q.T1_last = base + off_T1last; q.T2_last = base + off_T2last; q.Mf = base + off_Mf;
-        q.Mb_last = base + off_Mblast; q.U_reg = base + off_Ureg; q.U_last = base + off_Ulast;
+        const double *rb = shared ? sbase : base;
+        q.Mpow = rb + off_Mpow; q.zirh = base + off_zirh; q.cf_last = base + off_cflast;
+        q.T1_reg = rb + off_T1reg; q.T2_reg = rb + off_T2reg;
+        q.T1_last = base + off_T1last; q.T2_last = base + off_T2last; q.Mf = rb + off_Mf;
+        q.Mb_last = base + off_Mblast; q.U_reg = rb + off_Ureg; q.U_last = base + off_Ulast;
         q.pz = q.pform ? base + off_pz : nullptr;
     }
+    const double *reg_tables() const { return shared ? shared->blob.data() : blob.data(); }   // host base of the *_reg offsets
 };
 
 namespace detail {

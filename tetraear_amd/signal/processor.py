@@ -8,6 +8,7 @@ computed in numpy here beyond dtype plumbing, and a missing library / GPU raises
 """
 import ctypes as C
 import logging
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -18,7 +19,39 @@ from tetraear_amd.batch import BatchDemodulator
 
 logger = logging.getLogger(__name__)
 
+# One plan per (device, sample rate, wire format), shared by every SignalProcessor of the process: the reference's
+# callers make a new SignalProcessor per call (signal/scanner.py:164) and read whatever length they like
+# (scanner.py:347, rtl_auto_capture.py:182), so neither the instance nor the length may key the expensive state.
+# A plan serves any chunk length (tdm_plan_resize keeps the per-length tables of the lengths it has seen).
 _PLAN_CACHE_SIZE = 8
+_PLANS = OrderedDict()
+_PLANS_LOCK = threading.Lock()
+
+
+def _shared_plan(device, sample_rate, n, fmt):
+    key = (int(device), float(sample_rate), fmt)
+    with _PLANS_LOCK:
+        p = _PLANS.get(key)
+        if p is None:
+            p = BatchDemodulator(sample_rate, n, 1, fmt, device)
+            p.lock = threading.Lock()
+            _PLANS[key] = p
+            while len(_PLANS) > _PLAN_CACHE_SIZE:
+                _, old = _PLANS.popitem(last=False)
+                with old.lock:
+                    old.close()
+        else:
+            _PLANS.move_to_end(key)
+    return p
+
+
+def close_plans():
+    """Release every cached plan (device memory, streams)."""
+    with _PLANS_LOCK:
+        while _PLANS:
+            _, old = _PLANS.popitem()
+            with old.lock:
+                old.close()
 
 
 def _as_c128(samples):
@@ -39,21 +72,6 @@ class SignalProcessor:
         self.best_phase = None
         self.min_margin = None
         self.device = device
-        self._plans = OrderedDict()
-
-    # ------------------------------------------------------------------ helpers
-    def _plan(self, n, fmt):
-        key = (float(self.sample_rate), int(n), fmt)
-        p = self._plans.get(key)
-        if p is None:
-            p = BatchDemodulator(self.sample_rate, n, 1, fmt, self.device)
-            self._plans[key] = p
-            while len(self._plans) > _PLAN_CACHE_SIZE:
-                _, old = self._plans.popitem(last=False)
-                old.close()
-        else:
-            self._plans.move_to_end(key)
-        return p
 
     # ------------------------------------------------------------------ processor.py:35-49
     def resample(self, samples, target_rate):
@@ -140,7 +158,13 @@ class SignalProcessor:
         return self._run(u8, FMT_CU8, n, freq_offset)
 
     def _run(self, x, fmt, n, freq_offset):
-        plan = self._plan(n, fmt)
+        plan = _shared_plan(self.device, self.sample_rate, n, fmt)
+        with plan.lock:
+            if plan.handle is None:   # (evicted between the look-up and the lock)
+                return self._run(x, fmt, n, freq_offset)
+            return self._run_locked(plan.resize(n), x, freq_offset)
+
+    def _run_locked(self, plan, x, freq_offset):
         info = plan.info
         if info.q == 1 and self.sample_rate > 480000 and int(self.sample_rate / 240000) > 1:
             logger.warning("Decimation failed: The length of the input vector x must be greater than "
@@ -155,6 +179,4 @@ class SignalProcessor:
         return hards[0]
 
     def close(self):
-        for p in self._plans.values():
-            p.close()
-        self._plans.clear()
+        """Kept for callers of earlier versions: plans are shared by all instances now (see close_plans)."""
