@@ -344,17 +344,36 @@ def leg_single(carriers, steps, warmup):
     for _ in range(warmup):
         bd.enqueue()
     bd.sync()
+    # per-stage pass (events around every launch), then the calls as a capture loop makes them: back to back, HIP events
+    # around the whole loop only
     bd.time_begin()
     for _ in range(steps):
         bd.enqueue()
-    ms = bd.time_end() / steps
+    ms_staged = bd.time_end() / steps
     st = bd.stage_times()
+    for _ in range(3):
+        bd.enqueue()
+    bd.sync()
+    bd.time_begin(per_stage=False)
+    for _ in range(steps):
+        bd.enqueue()
+    ms = bd.time_end() / steps
+    # a length the plan has not seen, then one it has (tdm_plan_resize: ragged read sizes on one plan)
+    t0 = time.perf_counter()
+    bd.resize(131072)
+    resize_new_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    bd.resize(262144)
+    resize_seen_ms = (time.perf_counter() - t0) * 1e3
     hard, soft, n_soft, bp, mm = bd.download()
     bd.close()
     nsym = int(np.maximum(n_soft - 1, 0).sum())
     return {"workload": f"{carriers} carrier x 262144 cu8 samples @2.4 MS/s", "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6,
             "unit": "Msym/s", "x_realtime": (262144 / SAMPLE_RATE) / (ms * 1e-3), "plan_create_ms": create_ms,
-            "stage_ms_per_launch": st}
+            "plan_resize_ms": {"new_length": resize_new_ms, "seen_length": resize_seen_ms},
+            "ms_per_step_staged": ms_staged, "stage_ms_per_launch": st,
+            "timing": "HIP events on the plan's stream; ms_per_step = calls back to back, events around the loop; "
+                      "ms_per_step_staged = the per-stage pass (events around each of the launches)"}
 
 
 def main_stream(args):

@@ -219,6 +219,9 @@ TDM_API int tdm_dev_download(int32_t device, void *dst_host, const void *src_dev
 TDM_API int tdm_dev_sync(int32_t device);
 /* event timing on the library's own stream for a plan: elapsed milliseconds between two marks */
 TDM_API int tdm_plan_time_begin(tdm_plan *plan);
+/* the same mark without per-stage events: the launches of the timed region go out back to back exactly as they do
+ * untimed (the events around every launch cost a one-carrier call a third of its time) */
+TDM_API int tdm_plan_time_begin_total(tdm_plan *plan);
 TDM_API int tdm_plan_time_end(tdm_plan *plan, float *elapsed_ms);
 /* per-stage kernel time (ms) accumulated between time_begin/time_end; names[i] static strings */
 TDM_API int tdm_plan_stage_times(tdm_plan *plan, int32_t max_stages, const char **names, float *ms,

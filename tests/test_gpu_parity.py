@@ -48,13 +48,29 @@ def test_process_c128_matches_reference(name, gold_process, SP):
     p.close()
 
 
+@pytest.fixture(params=["auto", "raw"])
+def cu8_engine(request, monkeypatch):
+    """A few carriers run the decimator that holds its samples as doubles (shorter blocks fill the chip sooner), big
+    batches the raw-integer one; "raw" puts single carriers on the raw-integer kernel too (TDM_RAW_MIN_BLOCKS=0)."""
+    from tetraear_amd.signal import processor as P
+    P.close_plans()
+    if request.param == "raw":
+        monkeypatch.setenv("TDM_RAW_MIN_BLOCKS", "0")
+    yield request.param
+    P.close_plans()
+
+
 @pytest.mark.parametrize("name", sorted(n for n, c in CASES.items() if c["kind"] in ("noise", "dqpsk", "const")))
-def test_process_cu8_matches_reference(name, gold_process, SP):
-    """Raw RTL-SDR bytes in (in-kernel u8 -> float conversion must equal pyrtlsdr's)."""
+def test_process_cu8_matches_reference(name, gold_process, SP, cu8_engine):
+    """Raw RTL-SDR bytes in (in-kernel u8 -> float conversion must equal pyrtlsdr's), both cu8 decimator kernels."""
     c = CASES[name]
     p = SP(c["fs"])
     hard = p.process_cu8(case_cu8(c), c["foff"])
     _check(name, hard, p.symbols, gold_process)
+    # the same call again on the same plan and buffers
+    for _ in range(2):
+        again = p.process_cu8(case_cu8(c), c["foff"])
+        np.testing.assert_array_equal(again, hard)
     p.close()
 
 
@@ -296,7 +312,7 @@ def test_recorded_file_ingest_pipelined(tmp_path):
 
 
 @pytest.mark.gpu
-def test_random_lengths_and_rates_vs_oracle():
+def test_random_lengths_and_rates_vs_oracle(cu8_engine):
     """seeded random chunk lengths (1 .. 300 000, plus lengths around block multiples and the fall-back
     thresholds), sample rates incl. 10 MS/s (q = 41) and AFC offsets: process_cu8 against the C oracle"""
     from oracle.oracle import OracleSignalProcessor

@@ -63,6 +63,7 @@ SIGNATURES = {
     "tdm_dev_download": (C.c_int, [_i32, _vp, _vp, _sz]),
     "tdm_dev_sync": (C.c_int, [_i32]),
     "tdm_plan_time_begin": (C.c_int, [_vp]),
+    "tdm_plan_time_begin_total": (C.c_int, [_vp]),
     "tdm_plan_time_end": (C.c_int, [_vp, _P(C.c_float)]),
     "tdm_plan_stage_times": (C.c_int, [_vp, _i32, _P(C.c_char_p), _P(C.c_float), _P(_i32)]),
     "tdm_design_dump": (C.c_int, [_f64, _i64, _vp, _vp, _vp, _vp, _vp, _P(_i32), _P(_f64)]),

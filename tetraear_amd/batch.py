@@ -177,8 +177,9 @@ class BatchDemodulator:
         mm = d["mm"].download(np.float64, rows)
         return hard, soft, n_soft, bp, mm
 
-    def time_begin(self):
-        check(self.lib.tdm_plan_time_begin(self.handle))
+    def time_begin(self, per_stage=True):
+        """HIP-event mark on the plan's stream; per_stage=False leaves the launches back to back as they are untimed."""
+        check((self.lib.tdm_plan_time_begin if per_stage else self.lib.tdm_plan_time_begin_total)(self.handle))
 
     def time_end(self):
         ms = C.c_float()

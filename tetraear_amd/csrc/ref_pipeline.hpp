@@ -77,7 +77,7 @@ template <class BE, int FMT, bool SHIFT>
 void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, const RefIO &io)
 {
     RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
-    const bool use_raw = h.raw_S > 0 && FMT == FMT_CU8 && !SHIFT;
+    const bool use_raw = h.raw_S > 0 && FMT == FMT_CU8 && !SHIFT && (int64_t)rows * h.dec.p.nb >= h.raw_min_blocks;
     if (use_raw) {
         run_pz_raw(be, h, B.dec_raw_params, io.iq, io.carrier_stride, rows);
         be.template zp_carry<2, 4>(B.dec_raw_params, h.dec_raw.p.nb, rows);

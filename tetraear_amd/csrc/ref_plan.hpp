@@ -74,6 +74,9 @@ struct RefPlanHost {
     // cu8 plans: the same two stages with the decimator on the raw bytes (longer lanes, other block geometry); used
     // whenever no input-rate pre-shift is requested
     int raw_S = 0;
+    // the raw-integer kernel's blocks are four times as long: with fewer than raw_min_blocks blocks in the whole batch
+    // (a few carriers) they cannot fill the chip and the double-based kernel finishes sooner.  0 = always raw.
+    int64_t raw_min_blocks = 0;
     ZpHostTables dec_raw;
     Lp2Host lp2_raw;
 };

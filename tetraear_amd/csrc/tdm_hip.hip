@@ -350,6 +350,7 @@ struct Variant {
     Lp2Params lp2{}, lp2_raw{};
     double *d_y = nullptr, *d_z = nullptr, *d_partials = nullptr;
     uint64_t stamp = 0;          // last use (eviction order)
+    uint64_t id = 0;             // unique within the plan
     ~Variant() { if (d_tab) (void)hipFree(d_tab); }
 };
 
@@ -358,6 +359,7 @@ constexpr size_t kMaxVariants = 32;
 struct tdm_plan {
     int rows = 0, fmt = 0, mode = 0, device = 0;
     bool allow_raw = true;
+    int64_t raw_min_blocks = 0;
     std::map<int64_t, std::unique_ptr<Variant>> variants;
     Variant *cur = nullptr;
     uint64_t clock = 0;
@@ -520,6 +522,8 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
         plan->variants.erase(old);
     }
     v->stamp = ++plan->clock;
+    v->id = plan->clock;
+    v->h.raw_min_blocks = plan->raw_min_blocks;
     plan->cur = v.get();
     plan->variants[n] = std::move(v);
     return TDM_OK;
@@ -639,6 +643,14 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     // (TDM_NO_RAW=1: experiments / tests keep cu8 plans on the kernel that holds its samples as doubles)
     const char *no_raw = std::getenv("TDM_NO_RAW");
     p->allow_raw = !(no_raw && no_raw[0] == '1');
+    {
+        // blocks of the double-based decimator below which a batch stays on it: two wavefronts per SIMD of the device
+        // (TDM_RAW_MIN_BLOCKS overrides; tests use 0 to put single carriers on the raw-integer kernel)
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        p->raw_min_blocks = (int64_t)prop.multiProcessorCount * 8;
+        if (const char *e = std::getenv("TDM_RAW_MIN_BLOCKS")) p->raw_min_blocks = std::atoll(e);
+    }
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p->ev0));
     HIP_TRY(hipEventCreate(&p->ev1));
@@ -921,6 +933,16 @@ int tdm_plan_time_begin(tdm_plan *plan)
     HIP_TRY(hipSetDevice(plan->device));
     plan->timer.release_all();
     plan->timer.on = true;
+    HIP_TRY(hipEventRecord(plan->ev0, plan->stream));
+    return TDM_OK;
+}
+
+int tdm_plan_time_begin_total(tdm_plan *plan)
+{
+    if (!plan) return fail(TDM_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(plan->device));
+    plan->timer.release_all();
+    plan->timer.on = false;
     HIP_TRY(hipEventRecord(plan->ev0, plan->stream));
     return TDM_OK;
 }
