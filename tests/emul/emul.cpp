@@ -247,6 +247,12 @@ struct EmuBackend {
                                            partials + (int64_t)row * n_pblk * kMaxSps, n_pblk);
                 });
     }
+    template <class Src>
+    void lp2_finish(const Lp2Params &P, const Src &src, const FinishArgs &fa, int rows)
+    {
+        lp2(P, src, rows);
+        finish(fa, rows);
+    }
     void finish(const FinishArgs &fa, int rows)
     {
         for (int row = 0; row < rows; ++row)

@@ -7,7 +7,7 @@
 //   pass 1  recurrences from zero state -> lane end states
 //   scan    lanes of a wavefront (DPP rows), wavefronts of the workgroup (LDS) -> every lane's true start states
 //   pass 2  recurrences from the true start states, two-tap outputs accumulated -> the filter output, final.
-// Because the halo lets the filter's memory decay below 1e-30, no carry crosses a workgroup and no later kernel
+// Because the halo lets the filter's memory decay below 1e-21, no carry crosses a workgroup and no later kernel
 // has to touch the output again: it is written once, phase-major (sample p + sps*k at [p][k]), so that the symbol
 // gather of the finish stage reads one contiguous row.
 //

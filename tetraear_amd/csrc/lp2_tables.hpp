@@ -2,7 +2,7 @@
 // filter_signal(samples, 25000, current_rate) (processor.py:51-83, scipy butter(4) + filtfilt, pad 15) as the
 // partial-fraction expansion of H(z)H(1/z) (see pz_tables.hpp), evaluated by workgroups that own a chunk of a
 // carrier's low-rate samples plus a halo on either side.  The halo is long enough for the filter's memory to decay
-// below 1e-30, so chunks need no carries from their neighbours and the filter output is final when it is written.
+// below 1e-21 (five decades under the rounding of the samples themselves), so chunks need no carries from their neighbours and the filter output is final when it is written.
 #pragma once
 #include <cstring>
 #include <vector>
@@ -17,6 +17,9 @@ constexpr int kLp2Lanes = kLp2Waves * kWave;
 constexpr int kLp2Span = kLp2Lanes * kLp2La;   // positions a workgroup covers (chunk + both halos)
 constexpr int kLp2Pairs = 2;
 constexpr int kLp2D = 2 * kLp2Pairs;
+// what a chunk may ignore of its neighbours: the states are O(10) per unit input, so the neglected part is below 1e-20 of
+// the signal -- four decades under one rounding of a sample (1.1e-16); 1e-30 cost a ninth chunk per 26 215-sample row
+constexpr long double kLp2HaloTol = 1e-21L;
 
 struct Lp2Params {
     // ---- geometry: lane t of chunk c covers positions j = c*U - H - off + La*t ... + La - 1 of the low-rate row
@@ -73,10 +76,10 @@ inline Lp2Host build_lp2(const double (*sos)[6], int64_t n, int edge, int sps, c
     Lp2Params &p = h.p;
     constexpr int La = kLp2La, NP = kLp2Pairs, D = kLp2D;
     const PzDesign dz = design_pz(sos, NP);
-    // halo: |largest pole|^H < 1e-30
+    // halo: |largest pole|^H < kLp2HaloTol
     ldbl rmax = 0;
     for (int s = 0; s < NP; ++s) rmax = std::fmax(rmax, std::sqrt(dz.a2[s]));
-    int H = (int)std::ceil(std::log(1e-30L) / std::log(rmax));
+    int H = (int)std::ceil(std::log(kLp2HaloTol) / std::log(rmax));
     H = ((H + La - 1) / La) * La;
     if (H < 3 * La) H = 3 * La;
     if (2 * H > kLp2Span / 2) return h;   // (a filter this narrow runs on the cascade engine with its block carries)

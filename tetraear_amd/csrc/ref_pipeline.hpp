@@ -13,6 +13,7 @@
 //   template<int D,int L> void power_fixup(const ZpParams&, int rows, int64_t n, double* z, int sps,
 //                                           double* partials, int n_pblk);
 //   void finish(const FinishArgs&, int rows);
+//   template<class Src> void lp2_finish(const Lp2Params&, const Src&, const FinishArgs&, int rows);   (low-rate kernel, then finish)
 #pragma once
 #include "ref_plan.hpp"
 #include "zp_kernels.hpp"
@@ -95,25 +96,41 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     } else {
         be.convert(ld, rows, h.n, B.y, io.freq_offset, h.sample_rate);
     }
-    const double *zin = B.y;
-    const double *partials = nullptr;
-    int n_pblk = 0;
-    bool fix_in_finish = false;
+    // extract_symbols + demodulate_dqpsk  (processor.py:267-271)
+    FinishArgs fa{};
+    fa.z = B.y;
+    fa.n = h.n_dec;
+    fa.row_stride = h.n_dec;
+    fa.sps = h.sps;
+    fa.do_extract = 1;
+    fa.do_demod = 1;
+    fa.max_soft = (int32_t)h.max_soft;
+    fa.soft = io.soft;
+    fa.hard = io.hard;
+    fa.n_soft = io.n_soft;
+    fa.best_phase = io.best_phase;
+    fa.min_margin = io.min_margin;
     if (h.lp2.ok) {
-        // fix-up + frequency_shift + filter_signal + phase powers in one kernel, output final and phase-major
+        // fix-up + frequency_shift + filter_signal + phase powers in one kernel, output final and phase-major; then the
+        // finish stage
+        const Lp2Params &L = use_raw ? B.lp2_raw : B.lp2;
+        fa.partials = L.partials;
+        fa.n_pblk = L.n_chunks;
+        fa.zt = B.lp2.zt;
+        fa.zt_k = B.lp2.zt_k;
         if (use_raw) {
             Lp2SrcDec src{B.dec_raw_params, io.freq_offset, h.rate_dec};
-            be.lp2(B.lp2_raw, src, rows);
+            be.lp2_finish(L, src, fa, rows);
         } else if (h.decimated) {
             Lp2SrcDec src{B.dec_params, io.freq_offset, h.rate_dec};
-            be.lp2(B.lp2, src, rows);
+            be.lp2_finish(L, src, fa, rows);
         } else {
             Lp2SrcPlain src{B.y, h.n_dec};
-            be.lp2(B.lp2, src, rows);
+            be.lp2_finish(L, src, fa, rows);
         }
-        partials = use_raw ? B.lp2_raw.partials : B.lp2.partials;
-        n_pblk = use_raw ? B.lp2_raw.n_chunks : B.lp2.n_chunks;
-    } else if (h.lpf) {
+        return;
+    }
+    if (h.lpf) {
         // filter_signal(samples, 25000, current_rate)  (processor.py:264).  When decimated, the
         // loader finishes the decimator output (carry responses) and applies
         // frequency_shift(samples, freq_offset, current_rate) (processor.py:260-261) on the fly.
@@ -126,37 +143,16 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         }
         be.template zp_carry<2, 2>(B.lpf_params, h.lpf_t.p.nb, rows);
         if (h.sps > 1 && h.sps <= kMaxSps) {
-            n_pblk = h.lpf_t.p.nb * (kWave * kLLpf / kPowThreads);
+            fa.n_pblk = h.lpf_t.p.nb * (kWave * kLLpf / kPowThreads);
             // z itself is not written: the finish stage evaluates it at the symbols it gathers
-            be.template power_fixup<4, kLLpf>(B.lpf_params, rows, h.n_dec, nullptr, h.sps, B.partials, n_pblk);
-            partials = B.partials;
-            fix_in_finish = true;
+            be.template power_fixup<4, kLLpf>(B.lpf_params, rows, h.n_dec, nullptr, h.sps, B.partials, fa.n_pblk);
+            fa.partials = B.partials;
+            fa.use_fix = 1;
+            fa.fix = B.lpf_params;
         } else {
             be.template zp_fixup<4, kLLpf>(B.lpf_params, h.lpf_t.p.nb, rows, B.z, h.n_dec, nullptr, h.rate_dec);
         }
-        zin = B.z;
-    }
-    // extract_symbols + demodulate_dqpsk  (processor.py:267-271)
-    FinishArgs fa{};
-    fa.z = zin;
-    fa.n = h.n_dec;
-    fa.row_stride = h.n_dec;
-    fa.sps = h.sps;
-    fa.do_extract = 1;
-    fa.do_demod = 1;
-    fa.max_soft = (int32_t)h.max_soft;
-    fa.soft = io.soft;
-    fa.hard = io.hard;
-    fa.n_soft = io.n_soft;
-    fa.best_phase = io.best_phase;
-    fa.min_margin = io.min_margin;
-    fa.partials = partials;
-    fa.n_pblk = n_pblk;
-    fa.use_fix = fix_in_finish;
-    if (fix_in_finish) fa.fix = B.lpf_params;
-    if (h.lp2.ok) {
-        fa.zt = B.lp2.zt;
-        fa.zt_k = B.lp2.zt_k;
+        fa.z = B.z;
     }
     static_assert(kFixBn == kWave * kLLpf, "finish evaluates the channel filter's fix-up with its block length");
     be.finish(fa, rows);

@@ -34,7 +34,6 @@ void launch_lp2(const Lp2Params &P, const Src &src, int rows, hipStream_t st)
 {
     hipLaunchKernelGGL((k_lp2<Src>), dim3(P.n_chunks, rows), dim3(kLp2Lanes), 0, st, P, src);
 }
-
 template void launch_lp2<Lp2SrcDec>(const Lp2Params &, const Lp2SrcDec &, int, hipStream_t);
 template void launch_lp2<Lp2SrcPlain>(const Lp2Params &, const Lp2SrcPlain &, int, hipStream_t);
 

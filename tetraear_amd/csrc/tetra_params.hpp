@@ -39,6 +39,9 @@ struct TetraParams {
 };
 
 // one launch of the fused receiver on `rows` carriers; returns false when no kernel is instantiated for tp.ntaps
+#ifdef TDM_TETRA_TIMING
+void tetra_timing_dump();
+#endif
 bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, uint8_t *hard,
                   int32_t *n_soft, int32_t *timing_milli, double *min_margin, hipStream_t stream);
 
