@@ -38,8 +38,16 @@ extern __device__ unsigned long long g_lp2_dbg[16];
 
 namespace tdm {
 
+// Staging area: one 16-byte slot per position of the workgroup's span, swizzled so that both access patterns are free of
+// bank conflicts without padding: a lane's own run (slot = 16 lane + i: the low four bits become i ^ lane, sixteen
+// neighbouring lanes hit sixteen different 16-byte bank groups) and the coalesced one (slot = base + lane with base a
+// multiple of 16: XOR with a constant).  (One pad slot per 32 -- the cascade engine's layout, made for 8-sample lanes --
+// left this kernel's 16-sample lanes with two-way conflicts: 37 % of its LDS cycles.)
+TDM_HD int lp2_slot(int s) { return s ^ ((s >> 4) & 15); }
+static_assert(kLp2La == 16, "lp2_slot swizzles inside runs of 16 slots = one lane's samples");
+
 struct Lp2Lds {
-    static constexpr int kSlots = kLp2Span + kLp2Span / 32 + 1;   // 16-byte slots, one pad per 32 (conflict-free both ways)
+    static constexpr int kSlots = kLp2Span;
     static constexpr int kStage = 2 * kSlots;
     // small area (doubles): [0,256) wave totals and the causal state at the end of the row, [256, 256 + 40*32) power partials of the groups
     static constexpr int oTot = 0, oPow = 256, kPowGroups = 39;
@@ -148,13 +156,17 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         for (int i = 0; i < La; ++i) {
             const int j = jw32 + i * kWave;
             const int jj = j < 0 ? 0 : (j >= n32 ? n32 - 1 : j);
+#ifdef TDM_LP2_FAKE_LOADS   // experiment: every load hits the same cache-resident kilobytes (results are wrong, timing only)
+            v[i] = src.raw_row(0)[jj & 1023];
+#else
             v[i] = rowp[jj];
+#endif
         }
 #pragma unroll
         for (int i = 0; i < La; ++i) {
             const int j = jw32 + i * kWave;
             const bool ok = (j >= 0 && j < n32);
-            stage[stage_slot(wave * (kWave * La) + i * kWave + lane)] = f64x2{ok ? v[i].x : 0.0, ok ? v[i].y : 0.0};
+            stage[lp2_slot(wave * (kWave * La) + i * kWave + lane)] = f64x2{ok ? v[i].x : 0.0, ok ? v[i].y : 0.0};
         }
     }
     cm.sync();
@@ -162,7 +174,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     double yr[La], yi[La];
 #pragma unroll
     for (int i = 0; i < La; ++i) {
-        const f64x2 v = stage[stage_slot(tid * La + i)];
+        const f64x2 v = stage[lp2_slot(tid * La + i)];
         yr[i] = v.x;
         yi[i] = v.y;
     }
@@ -193,10 +205,10 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     // publish the finished samples; the odd extension (scipy odd_ext: 2 x[0] - x[-j], 2 x[n-1] - x[2n-2-j]) of the lanes
     // around the ends of the row reads them from there
 #pragma unroll
-    for (int i = 0; i < La; ++i) stage[stage_slot(tid * La + i)] = f64x2{yr[i], yi[i]};
+    for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{yr[i], yi[i]};
     cm.sync();
     LP2_T(1);
-    auto Y = [&](int64_t j) { return stage[stage_slot((int)(j - jc))]; };
+    auto Y = [&](int64_t j) { return stage[lp2_slot((int)(j - jc))]; };
     if (!inside) {
 #pragma unroll
         for (int i = 0; i < La; ++i) {
@@ -434,7 +446,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     // ---------------- output: through LDS; one thread per (timing phase, group) stores its phase's samples and sums their powers ----------------
     cm.sync();   // (all lanes have taken their input out of the staging area)
 #pragma unroll
-    for (int i = 0; i < La; ++i) stage[stage_slot(tid * La + i)] = f64x2{or_[i], oi[i]};
+    for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{or_[i], oi[i]};
     cm.sync();
     LP2_T(5);
     const int64_t j_lo = (int64_t)chunk * P.U - P.off > 0 ? (int64_t)chunk * P.U - P.off : 0;
@@ -456,7 +468,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
             int64_t k0 = j_lo <= p2 ? 0 : (j_lo - p2 + sps - 1) / sps;
             for (int64_t k = k0 + g2; p2 + k * sps < j_hi; k += ngrp) {
                 const int64_t j = p2 + k * sps;
-                const f64x2 v = stage[stage_slot((int)(j - jc))];
+                const f64x2 v = stage[lp2_slot((int)(j - jc))];
                 zt[(int64_t)p2 * P.zt_k + k] = v;
                 if (j < lim) acc += fma(v.x, v.x, v.y * v.y);
             }
@@ -471,7 +483,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         }
     } else {
         f64x2 *z = (f64x2 *)P.zt + (int64_t)row * P.zt_k;
-        for (int64_t j = j_lo + tid; j < j_hi; j += kLp2Lanes) z[j] = stage[stage_slot((int)(j - jc))];
+        for (int64_t j = j_lo + tid; j < j_hi; j += kLp2Lanes) z[j] = stage[lp2_slot((int)(j - jc))];
     }
     LP2_T(6);
 }
