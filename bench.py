@@ -287,7 +287,10 @@ def main():
             "event_ms_per_step_rank0": ev_ms / args.steps,
             "stage_ms_per_launch": stage_ms,
             "roofline": {
-                "kernel": "k_pz_raw<10,12,27> (zero-phase Chebyshev-8 decimator in parallel form: causal + anticausal all-pole banks on the raw samples)",
+                "kernel": ("k_pz_raw<10,12,27> (zero-phase Chebyshev-8 decimator in parallel form: causal + anticausal all-pole banks on the raw samples)"
+                           if bd.info.dec_engine == 3 else
+                           "k_pz_block (the same decimator with the samples held as doubles: few carriers, or a wire format other than cu8)"
+                           if bd.info.dec_engine == 2 else "k_zp_block (cascade engine)"),
                 "bound": "valu_fp64",
                 "achieved": achieved_tf,
                 "peak": PEAK_FP64_TFLOPS,

@@ -76,7 +76,8 @@ typedef struct tdm_plan_info {
     int32_t in_fmt;
     int32_t mode;
     int32_t device;
-    int32_t reserved;
+    int32_t dec_engine;   /* decimator kernel the next call runs: 0 none, 1 cascade engine, 2 parallel form on doubles,
+                             3 parallel form on the raw bytes (cu8 batches of at least 8 blocks per CU) */
 } tdm_plan_info;
 
 /* ---- library ---------------------------------------------------------------------------- */

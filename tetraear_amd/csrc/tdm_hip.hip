@@ -718,6 +718,11 @@ int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info)
     info->in_fmt = plan->fmt;
     info->mode = plan->mode;
     info->device = plan->device;
+    if (plan->mode == TDM_MODE_REFERENCE && h.decimated) {
+        // (the rule of run_ref_fmt; a call with an input-rate pre-shift stays on the double-based kernel)
+        const bool raw = h.raw_S > 0 && plan->fmt == TDM_CU8 && (int64_t)plan->rows * h.dec.p.nb >= h.raw_min_blocks;
+        info->dec_engine = raw ? 3 : (h.pz_S ? 2 : 1);
+    }
     return TDM_OK;
 }
 

@@ -480,15 +480,29 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // carrier's soft symbols come back from L2: every load is unconditional (clamped index) so that a thread's
     // 2 U loads are in flight together.
     constexpr int U = kSymUnroll;
-    float a4r = 0.f, a4i = 0.f;
-    for (int i0 = 1 + tid; i0 < ns; i0 += kRrcThreads * U) {
-        float2 c[U], p[U];
+    // symbols i0 + u*256 and their predecessors: a lane's predecessor is its left neighbour's symbol (one wavefront shift,
+    // DPP) except in lane 0 of a wavefront, which reads it; every load unconditional (clamped index)
+    auto load_pairs = [&](int i0, float2 (&c)[U], float2 (&p)[U]) {
+        float2 q[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = min(i0 + u * kRrcThreads, ns - 1);
             c[u] = sr[i];
-            p[u] = sr[i - 1];
+            q[u] = sr[(tid & 63) == 0 ? i - 1 : i];   // (lanes 1..63: the same address again, no extra traffic)
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float px = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[u].x), 0x138, 0xf, 0xf, false));   // wave_shr:1
+            const float py = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[u].y), 0x138, 0xf, 0xf, false));
+            const bool first = (tid & 63) == 0;
+            // a clamped lane (i0 + u*256 >= ns) holds symbol ns-1, its left neighbour may too: the pair is unused then
+            p[u] = first ? q[u] : make_float2(px, py);
+        }
+    };
+    float a4r = 0.f, a4i = 0.f;
+    for (int i0 = 1 + tid; i0 < ns; i0 += kRrcThreads * U) {
+        float2 c[U], p[U];
+        load_pairs(i0, c, p);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (i0 + u * kRrcThreads < ns) {
@@ -518,12 +532,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     };
     for (int i0 = 1 + tid; i0 < ns; i0 += kRrcThreads * U) {
         float2 c[U], p[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u * kRrcThreads, ns - 1);
-            c[u] = sr[i];
-            p[u] = sr[i - 1];
-        }
+        load_pairs(i0, c, p);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * kRrcThreads;
