@@ -621,13 +621,14 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         tp.ntaps = (int32_t)h.size();
         tp.sps = sps;
         tp.inv_sps = 1.0 / sps;
-        // symbol-clock phasors exp(-2 pi i g / sps) at g = 0..7 and g = one tile (argument reduced before the call)
+        // symbol-clock phasors exp(-2 pi i g / sps) at a lane's eight outputs of a tile (g = 256 (v >> 2) + 16 (v & 3)) and
+        // at g = one tile (argument reduced before the call)
         auto clock = [&](double g, float &c, float &s_) {
             const double ph = g / sps, fr = ph - std::floor(ph);
             c = (float)std::cos(-2.0 * M_PI * fr);
             s_ = (float)std::sin(-2.0 * M_PI * fr);
         };
-        for (int v = 0; v < kRrcPerThread; ++v) clock((double)v, tp.ev_c[v], tp.ev_s[v]);
+        for (int v = 0; v < kRrcPerThread; ++v) clock((double)(256 * (v >> 2) + kRrcRun * (v & 3)), tp.ev_c[v], tp.ev_s[v]);
         clock((double)kRrcTile, tp.tile_c, tp.tile_s);
         tp.max_soft = (int32_t)(n_samples / sps) + 4;
         for (size_t i = 0; i < h.size(); ++i) tp.taps[i] = (float)h[i];

@@ -135,22 +135,26 @@ __device__ unsigned long long g_tetra_dbg[16];
 
 constexpr int kSymUnroll = 8;   // symbols per thread whose loads are in flight together (final passes)
 
+// staged input: two planes (re, im) of floats, two pad dwords per run of 16 samples.  The matrix-core operand loads
+// (lane = run J + 16 * (k mod 4): dword 18 J + k) then touch 32 different banks in each half of the wavefront.
+__device__ __forceinline__ constexpr int xp_slot(int q) { return q + 2 * (q >> 4); }
+
 template <int NT>
 __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fused(const float2 *__restrict__ x, int64_t in_stride,
                                                               const TetraParams P, float2 *__restrict__ soft,
                                                               uint8_t *__restrict__ hard, int32_t *n_soft,
                                                               int32_t *timing_milli, double *min_margin)
 {
-    static_assert(kRrcPerThread == 4 || kRrcPerThread == 8, "a timing sub-block = one wavefront (4 outputs per thread) or half of one (8)");
-    static_assert(kRing % kRrcPerThread == 0 && kRing - kRrcTile - kTimingBlock * (2 * kTimingHalfWin + 1) / 2 >= kTimingBlock, "ring too short");
+    static_assert(kRrcPerThread == 8 && kRrcThreads == 256 && kTimingBlock == 256, "a wavefront owns two timing sub-blocks of a tile");
+    static_assert(kRing % 512 == 0 && kRing - kRrcTile - kTimingBlock * (2 * kTimingHalfWin + 1) / 2 >= kTimingBlock, "ring too short");
     constexpr int PER = kRrcPerThread;
     constexpr int HALO = NT - 1, H2 = HALO / 2;
-    constexpr int OFF = ((H2 + 1) & ~1) + 1;              // the staged window starts at tile base - OFF (odd: see fetch)
-    constexpr int D0 = OFF - H2;                          // staged index of the first tap of output 0
-    constexpr int NS = (kRrcTile + OFF + H2 + 2) & ~1;    // samples staged per tile
-    constexpr int NP = (NS / 2 + kRrcThreads - 1) / kRrcThreads;   // 16-byte sample pairs per thread
-    constexpr int NW = kRrcPerThread + HALO;
-    __shared__ float2 xs[NS + (NS >> kRrcPadShift) + 2];
+    constexpr int KS = (kRrcRun + HALO + 3) / 4;          // matrix-core steps (4 window positions each) per run of 16 outputs
+    constexpr int NS = kRrcTile - kRrcRun + 4 * KS;       // samples staged per tile: base - H2 .. base - H2 + NS
+    constexpr int NP = ((NS + 2) / 2 + kRrcThreads - 1) / kRrcThreads;   // 16-byte sample pairs per thread (+1 sample: alignment)
+    constexpr int PLANE = (xp_slot(NS) + 63) / 64 * 64;   // dwords per plane (multiple of 64: re and im go out as one ds_write2st64)
+    static_assert(2 * kRrcThreads * (NP - 1) + 1 < NS, "only the last pair of a thread can fall outside the staged window");
+    __shared__ float xsp[2 * PLANE];
     __shared__ float2 yring[kRing + (kRing >> kRrcPadShift)];
     __shared__ float2 Cst[2 * kTileBlocks];   // the statistic of two tiles' sub-blocks
     __shared__ float tau[kTauRing];
@@ -165,53 +169,78 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     float2 *sr = soft + (int64_t)row * P.max_soft;
     const int nb = (n + kTimingBlock - 1) / kTimingBlock;
     const int ntiles = (n + kRrcTile - 1) / kRrcTile;
-    // ---- input: a tile's samples base - OFF .. base - OFF + NS (zero outside the chunk) travel HBM -> registers one
+    // ---- input: a tile's samples base - H2 .. base - H2 + NS (zero outside the chunk) travel HBM -> registers one
     // tile ahead of their use, as 16-byte pairs.  A row starts on an 8-byte boundary (pitched channeliser rows, odd
-    // offsets): pairs begin at the samples whose address is a multiple of 16 (index parity `par`), the one sample a
-    // clamped pair can miss at either end of the chunk is read once up front.  fetch() only issues loads (clamped
-    // addresses, no branch, nothing that consumes a loaded value: a use would wait for the load on the spot);
-    // stage() masks what lies outside the chunk and writes LDS.
+    // offsets): pairs begin at the samples whose address is a multiple of 16 (index parity `par`), so a thread's first
+    // pair starts `e` samples before the window; the one sample a clamped pair can miss at either end of the chunk is
+    // read once up front.  fetch() only issues loads (clamped addresses, no branch, nothing that consumes a loaded
+    // value: a use would wait for the load on the spot); stage() masks what lies outside the chunk and writes LDS.
     const int par = (int)(((uintptr_t)xr >> 3) & 1);
+    const int e = (H2 + par) & 1;
     const int gmaxp = ((n - 2 - par) & ~1) + par;         // last pair start inside the chunk
     const float2 x_first = xr[0], x_last = xr[n - 1];
     f32x4 pf[NP];
     auto fetch = [&](int tile) {
-        const int g0 = tile * kRrcTile - OFF + 1 - par;   // = par (mod 2)
+        const int g0 = tile * kRrcTile - H2 - e;          // = par (mod 2)
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int g = g0 + 2 * (tid + j * kRrcThreads);
             pf[j] = __builtin_nontemporal_load((const f32x4 *)(xr + min(max(g, par), gmaxp)));
         }
     };
+    auto put = [&](int q, float re, float im) {
+        const int a = xp_slot(q);
+        xsp[a] = re;
+        xsp[PLANE + a] = im;
+    };
     auto stage = [&](int tile) {
-        const int g0 = tile * kRrcTile - OFF;
-        if (g0 >= 2 * par && g0 + NS + 1 <= gmaxp) {   // every pair of the tile lies inside the chunk: no masks
+        const int g0 = tile * kRrcTile - H2;
+        if (g0 - e >= par && g0 + NS <= gmaxp) {   // every pair of the tile lies inside the chunk: no masks
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const int q = 2 * (tid + j * kRrcThreads) + 1 - par;
+                const int q = 2 * (tid + j * kRrcThreads) - e;
                 const f32x4 v = pf[j];
-                if (j < NP - 1 || q < NS) xs[rrc_slot(q)] = make_float2(v.x, v.y);
-                if (j < NP - 1 || q + 1 < NS) xs[rrc_slot(q + 1)] = make_float2(v.z, v.w);
+                if ((j > 0 || q >= 0) && (j < NP - 1 || q < NS)) put(q, v.x, v.y);
+                if (j < NP - 1 || q + 1 < NS) put(q + 1, v.z, v.w);
             }
             return;
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int q = 2 * (tid + j * kRrcThreads) + 1 - par;   // staged index of the pair's first sample
+            const int q = 2 * (tid + j * kRrcThreads) - e;   // staged index of the pair's first sample
             const int g = g0 + q;
             const bool in = g >= par && g <= gmaxp;
             const f32x4 v = pf[j];
             const float2 e0 = in ? make_float2(v.x, v.y) : (g == n - 1 ? x_last : make_float2(0.f, 0.f));
             const float2 e1 = in ? make_float2(v.z, v.w) : (g == -1 ? x_first : make_float2(0.f, 0.f));
-            if (j < NP - 1 || q < NS) xs[rrc_slot(q)] = e0;
-            if (j < NP - 1 || q + 1 < NS) xs[rrc_slot(q + 1)] = e1;
+            if ((j > 0 || q >= 0) && (j < NP - 1 || q < NS)) put(q, e0.x, e0.y);
+            if (j < NP - 1 || q + 1 < NS) put(q + 1, e1.x, e1.y);
         }
     };
 
-    // symbol-clock phasor exp(-2 pi i g / sps) at the thread's first output of the current tile
+    // ---- matched filter on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 multiply-adds, executed beside the
+    // vector ALU that everything else in this kernel keeps busy).  A wavefront owns 512 consecutive outputs of a tile =
+    // two timing sub-blocks of 16 runs of 16:  Y[J][i] = y[16 J + i] = sum_m X[J][m] T[m][i],  X[J][m] = staged sample
+    // 16 J + m (m < 16 + NT - 1),  T[m][i] = h[m - i] (Toeplitz, zero outside the taps): 33 of 48 multiply-adds are
+    // useful at 33 taps.  Lane l supplies X[l & 15][4 s + (l >> 4)] (one dword from LDS per step and component) and the
+    // constant T[4 s + (l >> 4)][l & 15]; it receives Y[4 (l >> 4) + r][l & 15], r < 4.
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float hB[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = 4 * s + (lane >> 4) - (lane & 15);
+        const float h = P.taps[min(max(t, 0), NT - 1)];
+        hB[s] = (t >= 0 && t < NT) ? h : 0.f;
+    }
+    const float *ab = xsp + xp_slot(512 * wv + 16 * (lane & 15)) + (lane >> 4);
+    const int out_off = 64 * (lane >> 4) + (lane & 15);   // the lane's outputs inside a sub-block: out_off + 16 r
+    const int ring_lane = rrc_slot(out_off);
+
+    // symbol-clock phasor exp(-2 pi i g / sps) at the lane's first output of the current tile
     float pc, ps;
     {
-        const double ph = (double)(kRrcPerThread * tid) * P.inv_sps;
+        const double ph = (double)(512 * wv + out_off) * P.inv_sps;
         sincospif(-2.f * (float)(ph - floor(ph)), &ps, &pc);
     }
     float tau_prev = 0.f;   // (wave 0) last unwrapped estimate
@@ -230,83 +259,74 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         TT_MARK(0)
         __syncthreads();   // tile i staged; the previous round's ring reads are done
         TT_MARK(1)
-        // ---- matched filter: outputs base + 8 tid + v need staged samples 8 tid + v + D0 .. + NT - 1
-        // Taps as 64-bit scalar pairs, one half broadcast per instruction (the compiler's own form spends two scalar
-        // registers per tap and spills them); window addresses are one base + compile-time offsets.  The window slides
-        // through the registers in chunks of 8 taps: a chunk needs PER + 7 samples, the 8 new ones of the next chunk are
-        // loaded while this chunk's 64 multiply-adds run (scheduling fences keep that order), so PER + 15 window samples
-        // are live at a time instead of all NT + PER - 1.
-        f32x2 acc[kRrcPerThread];
-        {
-            f32x2 w[NW];
-            const float2 *wb = xs + (PER + 1) * tid;
-            auto wload = [&](int j) {
-                const float2 q = wb[j + D0 + ((j + D0) >> kRrcPadShift)];
-                w[j] = f32x2{q.x, q.y};
-            };
+        f32x4 cre[2], cim[2];
 #pragma unroll
-            for (int j = 0; j < (NW < PER + 7 ? NW : PER + 7); ++j) wload(j);
+        for (int bb = 0; bb < 2; ++bb) {
+            cre[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            cim[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int c = 0; 8 * c < NT; ++c) {
+        for (int s = 0; s < KS; ++s) {
 #pragma unroll
-                for (int j = 8 * c + PER + 7; j < 8 * c + PER + 15; ++j)
-                    if (j < NW) wload(j);
-#pragma unroll
-                for (int k = 8 * c; k < 8 * c + 8 && k < NT; k += 2) {
-                    uint64_t tp;
-                    __builtin_memcpy(&tp, &P.taps[k], 8);
-#pragma unroll
-                    for (int v = 0; v < kRrcPerThread; ++v) {
-                        if (k == 0)
-                            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc[v]) : "s"(tp), "v"(w[v]));
-                        else
-                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[v]) : "s"(tp), "v"(w[v + k]));
-                    }
-                    if (k + 1 < NT) {
-#pragma unroll
-                        for (int v = 0; v < kRrcPerThread; ++v)
-                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[v]) : "s"(tp), "v"(w[v + k + 1]));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int bb = 0; bb < 2; ++bb) {
+                const int o = 288 * bb + 4 * s + 2 * (s >> 2);
+                cre[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[o], hB[s], cre[bb], 0, 0, 0);
+                cim[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[PLANE + o], hB[s], cim[bb], 0, 0, 0);
             }
         }
         TT_MARK(2)
-        // ---- square-law timing statistic of the tile's sub-blocks, C_b = sum |y[g]|^2 exp(-2 pi i g / sps):
-        // 32 threads x 8 samples per sub-block, the phasor inside a thread's run is a constant table
+        // ---- square-law timing statistic of the wavefront's two sub-blocks, C_b = sum |y[g]|^2 exp(-2 pi i g / sps): the
+        // phasor of a lane's four outputs of a sub-block is a constant table times the lane's own
         {
-            const int g0 = base + kRrcPerThread * tid;
-            float qr = 0.f, qi = 0.f;
+            float pw[8], acc4[4];
 #pragma unroll
-            for (int v = 0; v < kRrcPerThread; ++v) {
-                float p = acc[v].x * acc[v].x + acc[v].y * acc[v].y;
-                if (last && g0 + v >= n) p = 0.f;
-                qr = fmaf(p, P.ev_c[v], qr);
-                qi = fmaf(p, P.ev_s[v], qi);
+            for (int v = 0; v < 8; ++v) pw[v] = cre[v >> 2][v & 3] * cre[v >> 2][v & 3] + cim[v >> 2][v & 3] * cim[v >> 2][v & 3];
+            if (last) {
+                asm volatile("" : "+v"(pw[0]));   // (a real branch: only the last tile pays for the masks)
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+                    if (base + 512 * wv + 256 * (v >> 2) + out_off + 16 * (v & 3) >= n) pw[v] = 0.f;
             }
-            float ar = qr * pc - qi * ps, ai = qr * ps + qi * pc;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                float qr = 0.f, qi = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    qr = fmaf(pw[4 * bb + r], P.ev_c[4 * bb + r], qr);
+                    qi = fmaf(pw[4 * bb + r], P.ev_s[4 * bb + r], qi);
+                }
+                acc4[2 * bb] = qr * pc - qi * ps;
+                acc4[2 * bb + 1] = qr * ps + qi * pc;
+            }
             const float nc = pc * P.tile_c - ps * P.tile_s, nsn = pc * P.tile_s + ps * P.tile_c;
             pc = nc;
             ps = nsn;
-            // sum over each 16-lane row with DPP (no LDS round trips), then across the rows of the sub-block's lanes
+            // sum over the wavefront with DPP (no LDS round trips): inside each row of 16 lanes, then across the rows
 #define TDM_DPP_ADD(X, CTRL, ROWS, BC) X += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X), CTRL, ROWS, 0xf, BC));
-            TDM_DPP_ADD(ar, 0xB1, 0xf, true) TDM_DPP_ADD(ai, 0xB1, 0xf, true)     // quad_perm [1,0,3,2]
-            TDM_DPP_ADD(ar, 0x4E, 0xf, true) TDM_DPP_ADD(ai, 0x4E, 0xf, true)     // quad_perm [2,3,0,1]
-            TDM_DPP_ADD(ar, 0x141, 0xf, true) TDM_DPP_ADD(ai, 0x141, 0xf, true)   // row_half_mirror
-            TDM_DPP_ADD(ar, 0x140, 0xf, true) TDM_DPP_ADD(ai, 0x140, 0xf, true)   // row_mirror
-            TDM_DPP_ADD(ar, 0x142, 0xa, false) TDM_DPP_ADD(ai, 0x142, 0xa, false) // row_bcast:15 into rows 1, 3
-            if (PER == 4) { TDM_DPP_ADD(ar, 0x143, 0xc, false) TDM_DPP_ADD(ai, 0x143, 0xc, false) }   // row_bcast:31 into rows 2, 3
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                TDM_DPP_ADD(acc4[c], 0xB1, 0xf, true)     // quad_perm [1,0,3,2]
+                TDM_DPP_ADD(acc4[c], 0x4E, 0xf, true)     // quad_perm [2,3,0,1]
+                TDM_DPP_ADD(acc4[c], 0x141, 0xf, true)    // row_half_mirror
+                TDM_DPP_ADD(acc4[c], 0x140, 0xf, true)    // row_mirror
+                TDM_DPP_ADD(acc4[c], 0x142, 0xa, false)   // row_bcast:15 into rows 1, 3
+                TDM_DPP_ADD(acc4[c], 0x143, 0xc, false)   // row_bcast:31 into rows 2, 3
+            }
 #undef TDM_DPP_ADD
-            constexpr int LPB = kTimingBlock / PER;   // lanes per sub-block: 64 or 32
-            const int b = i * kTileBlocks + tid / LPB;
-            if ((tid & (LPB - 1)) == (PER == 4 ? 63 : 16) && b < nb) Cst[b & (2 * kTileBlocks - 1)] = make_float2(ar, ai);
+            const int b = i * kTileBlocks + 2 * wv;
+            if (lane == 63) {
+                if (b < nb) Cst[b & (2 * kTileBlocks - 1)] = make_float2(acc4[0], acc4[1]);
+                if (b + 1 < nb) Cst[(b + 1) & (2 * kTileBlocks - 1)] = make_float2(acc4[2], acc4[3]);
+            }
         }
         TT_MARK(3)
-        // ---- matched-filter output into the ring
+        // ---- matched-filter output into the ring (a wavefront's 512 outputs never straddle its end)
         {
-            const int p0 = (base + kRrcPerThread * tid) % kRing;   // a thread's outputs never straddle the end
+            float2 *yw = yring + rrc_slot((base + 512 * wv) % kRing) + ring_lane;
 #pragma unroll
-            for (int v = 0; v < kRrcPerThread; ++v) yring[rrc_slot(p0) + v] = make_float2(acc[v].x, acc[v].y);
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yw[288 * bb + 18 * r] = make_float2(cre[bb][r], cim[bb][r]);
         }
         TT_MARK(4)
         __syncthreads();   // ring, statistic visible; staging buffer free

@@ -11,7 +11,8 @@ constexpr int kRrcThreads = 256;
 #ifndef TDM_TETRA_PER
 #define TDM_TETRA_PER 8
 #endif
-constexpr int kRrcPerThread = TDM_TETRA_PER;              // consecutive outputs per thread (4 or 8)
+constexpr int kRrcPerThread = TDM_TETRA_PER;              // outputs per thread and tile (8: a wavefront owns 512 consecutive outputs)
+constexpr int kRrcRun = 16;                               // outputs per row of the matched filter's matrix-core tiles
 constexpr int kRrcPadShift = kRrcPerThread == 4 ? 2 : 3;  // LDS: one pad slot per kRrcPerThread samples
 constexpr int kRrcTile = kRrcThreads * kRrcPerThread;     // samples per round of a workgroup
 constexpr int kTimingBlock = 256;                         // samples per timing sub-block (TB)
@@ -33,7 +34,7 @@ struct TetraParams {
     int32_t pad_;
     double sps;         // samples per symbol (sample_rate / 18000)
     double inv_sps;
-    float ev_c[kRrcPerThread], ev_s[kRrcPerThread];   // exp(-2 pi i v / sps), v < kRrcPerThread: symbol-clock phasor inside a thread's run
+    float ev_c[kRrcPerThread], ev_s[kRrcPerThread];   // exp(-2 pi i g / sps) at g = 256 (v >> 2) + 16 (v & 3): symbol-clock phasor of a lane's outputs inside a wavefront's two sub-blocks
     float tile_c, tile_s;                             // exp(-2 pi i kRrcTile / sps): advance per tile
     float taps[kRrcMaxTaps];
 };
