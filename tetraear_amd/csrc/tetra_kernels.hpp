@@ -3,16 +3,18 @@
 // There is no reference implementation of this mode: the algorithm is defined by
 // oracle/tetra_np.py (fp64 numpy) and restated here in fp32 for gfx950 as ONE kernel, k_tetra_fused:
 // a workgroup owns a carrier and walks its chunk tile by tile,
-//   HBM -> registers (next tile in flight) -> LDS -> sliding-window RRC matched filter in registers
-//       -> square-law (Oerder-Meyr) timing statistic of the tile's sub-blocks from the registers
+//   HBM -> registers (next tile in flight) -> LDS (re / im planes) -> RRC matched filter on the matrix cores
+//          (v_mfma_f32_16x16x4_f32, exact fp32: a Toeplitz tile of the taps times 16 runs of the staged input)
+//       -> square-law (Oerder-Meyr) timing statistic of the tile's sub-blocks from the accumulators
 //       -> matched-filter output into an LDS ring (never to HBM)
-//       -> timing estimates of the sub-blocks whose averaging window is complete (one wavefront)
+//       -> timing estimates of the sub-blocks whose averaging window is complete
 //       -> cubic Farrow interpolation at the symbol instants out of the ring -> soft symbols to HBM,
 // then the 4th-power carrier-offset estimate over the carrier's symbols and the differential quadrant
 // decision.  HBM traffic = the input once + 9 bytes per symbol (SURVEY 8(d) "fused": R*8 + 8 + 1 B/symbol).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "tetra_params.hpp"
 
 namespace tdm {
@@ -132,8 +134,6 @@ __device__ unsigned long long g_tetra_dbg[16];
 #else
 #define TT_MARK(i)
 #endif
-
-constexpr int kSymUnroll = 8;   // symbols per thread whose loads are in flight together (final passes)
 
 // staged input: two planes (re, im) of floats, two pad dwords per run of 16 samples.  The matrix-core operand loads
 // (lane = run J + 16 * (k mod 4): dword 18 J + k) then touch 32 different banks in each half of the wavefront.
@@ -496,43 +496,65 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         TT_MARK(10)
     }
     __syncthreads();   // the carrier's soft symbols are visible to the whole workgroup
-    // ---- differential products and the 4th-power carrier-offset estimate (per-thread sums in index order).  The
-    // carrier's soft symbols come back from L2: every load is unconditional (clamped index) so that a thread's
-    // 2 U loads are in flight together.
-    constexpr int U = kSymUnroll;
-    // symbols i0 + u*256 and their predecessors: a lane's predecessor is its left neighbour's symbol (one wavefront shift,
-    // DPP) except in lane 0 of a wavefront, which reads it; every load unconditional (clamped index)
-    auto load_pairs = [&](int i0, float2 (&c)[U], float2 (&p)[U]) {
-        float2 q[U];
+    // ---- differential products d_i = s_i conj(s_{i-1}), the 4th-power carrier-offset estimate over them, then the quadrant
+    // decisions.  A thread owns CH consecutive symbols of a chunk of CH * 256: four 16-byte loads (the carrier's soft
+    // symbols come back from L2), the predecessor of its first symbol from the lane to its left (one wavefront shift), one
+    // 8-byte store of its decisions.  The products of the first KEEP chunks (8192 symbols) stay in registers between the
+    // two passes; longer chunks form theirs again.
+    typedef f32x4 __attribute__((aligned(8))) f32x4_a8;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32x2 __attribute__((aligned(1))) u32x2_a1;
+    constexpr int CH = 8, CSYM = CH * kRrcThreads, KEEP = 4;
+    const int ms2 = P.max_soft - 2;   // (ns <= max_soft - 2: a pair that holds a symbol below ns is never clamped)
+    auto products = [&](int c0, float2 (&d)[CH]) {
+        const int i0 = c0 + CH * tid;
+        f32x4 v[CH / 2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u * kRrcThreads, ns - 1);
-            c[u] = sr[i];
-            q[u] = sr[(tid & 63) == 0 ? i - 1 : i];   // (lanes 1..63: the same address again, no extra traffic)
+        for (int j = 0; j < CH / 2; ++j) v[j] = *(const f32x4_a8 *)(sr + min(i0 + 2 * j, ms2));
+        const float2 pm = sr[max(min(i0, ms2) - 1, 0)];   // (used by lane 0 of a wavefront)
+        // (copies first: __builtin_bit_cast of a vector-element lvalue reads element 0 with this compiler)
+        const float lx = v[CH / 2 - 1].z, ly = v[CH / 2 - 1].w;
+        float px = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lx), 0x138, 0xf, 0xf, false));   // wave_shr:1
+        float py = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ly), 0x138, 0xf, 0xf, false));
+        if (lane == 0) {   // symbol 0 has no predecessor: its product is zero
+            px = i0 == 0 ? 0.f : pm.x;
+            py = i0 == 0 ? 0.f : pm.y;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float px = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[u].x), 0x138, 0xf, 0xf, false));   // wave_shr:1
-            const float py = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[u].y), 0x138, 0xf, 0xf, false));
-            const bool first = (tid & 63) == 0;
-            // a clamped lane (i0 + u*256 >= ns) holds symbol ns-1, its left neighbour may too: the pair is unused then
-            p[u] = first ? q[u] : make_float2(px, py);
+        for (int u = 0; u < CH; ++u) {
+            const float cx = (u & 1) ? v[u >> 1].z : v[u >> 1].x, cy = (u & 1) ? v[u >> 1].w : v[u >> 1].y;
+            d[u] = make_float2(cx * px + cy * py, cy * px - cx * py);
+            px = cx;
+            py = cy;
+        }
+        if (c0 + CSYM > ns) {   // the carrier's last chunk: nothing beyond symbol ns - 1
+            asm volatile("" : "+v"(d[0].x));
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (i0 + u >= ns) d[u] = make_float2(0.f, 0.f);
         }
     };
     float a4r = 0.f, a4i = 0.f;
-    for (int i0 = 1 + tid; i0 < ns; i0 += kRrcThreads * U) {
-        float2 c[U], p[U];
-        load_pairs(i0, c, p);
+    auto power4 = [&](const float2 (&d)[CH]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (i0 + u * kRrcThreads < ns) {
-                const float2 d = make_float2(c[u].x * p[u].x + c[u].y * p[u].y, c[u].y * p[u].x - c[u].x * p[u].y);
-                const float2 d2 = cmulf(d, d);
-                const float2 d4 = cmulf(d2, d2);
-                a4r += d4.x;
-                a4i += d4.y;
-            }
+        for (int u = 0; u < CH; ++u) {
+            const float2 d2 = cmulf(d[u], d[u]);
+            const float2 d4 = cmulf(d2, d2);
+            a4r += d4.x;
+            a4i += d4.y;
         }
+    };
+    float2 dk[KEEP][CH];
+#pragma unroll
+    for (int c = 0; c < KEEP; ++c)
+        if (c * CSYM < ns) {
+            products(c * CSYM, dk[c]);
+            power4(dk[c]);
+        }
+    for (int c0 = KEEP * CSYM; c0 < ns; c0 += CSYM) {
+        float2 d[CH];
+        products(c0, d);
+        power4(d);
     }
     a4r = block_sum(a4r, sm);
     a4i = block_sum(a4i, sm);
@@ -543,21 +565,41 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // ---- quadrant decision of d_k exp(-i delta): +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3
     float mratio = 3.4e38f;   // smallest min(|re|,|im|) / max(|re|,|im|): the angular distance to the nearest boundary is its atan
     uint8_t *hr = hard + (int64_t)row * P.max_soft;
-    auto decide = [&](float2 d, int i) {
-        const float2 dd = make_float2(d.x * rc - d.y * rs, d.x * rs + d.y * rc);
-        hr[i - 1] = dd.y >= 0.f ? (dd.x >= 0.f ? 0 : 1) : (dd.x >= 0.f ? 2 : 3);
-        const float ax = fabsf(dd.x), ay = fabsf(dd.y);
-        const float lo = fminf(ax, ay), hi = fmaxf(ax, ay);
-        mratio = fminf(mratio, hi > 0.f ? __fdividef(lo, hi) : 0.f);
-    };
-    for (int i0 = 1 + tid; i0 < ns; i0 += kRrcThreads * U) {
-        float2 c[U], p[U];
-        load_pairs(i0, c, p);
+    auto decide = [&](int c0, float2 (&d)[CH], auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        const int i0 = c0 + CH * tid;
+        // (symbol 0: its slot repeats symbol 1, which leaves the minimum margin alone; its decision is not stored)
+        if (c0 == 0 && i0 == 0) d[0] = d[1];
+        uint32_t w[2] = {0u, 0u};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * kRrcThreads;
-            if (i < ns) decide(make_float2(c[u].x * p[u].x + c[u].y * p[u].y, c[u].y * p[u].x - c[u].x * p[u].y), i);
+        for (int u = 0; u < CH; ++u) {
+            const float2 dd = make_float2(d[u].x * rc - d[u].y * rs, d[u].x * rs + d[u].y * rc);
+            const uint32_t h = dd.y >= 0.f ? (dd.x >= 0.f ? 0u : 1u) : (dd.x >= 0.f ? 2u : 3u);
+            w[u >> 2] |= h << (8 * (u & 3));
+            const float ax = fabsf(dd.x), ay = fabsf(dd.y);
+            const float lo = fminf(ax, ay), hi = fmaxf(ax, ay);
+            const float ratio = hi > 0.f ? __fdividef(lo, hi) : 0.f;
+            if (!TAIL || (i0 + u < ns && i0 + u >= 1)) mratio = fminf(mratio, ratio);
         }
+        if (!TAIL && i0 > 0) {
+            *(u32x2_a1 *)(hr + i0 - 1) = u32x2{w[0], w[1]};
+        } else {
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (i0 + u >= 1 && i0 + u < ns) hr[i0 + u - 1] = (uint8_t)(w[u >> 2] >> (8 * (u & 3)));
+        }
+    };
+    auto decide_chunk = [&](int c0, float2 (&d)[CH]) {
+        if (c0 + CSYM > ns) decide(c0, d, std::true_type{});
+        else decide(c0, d, std::false_type{});
+    };
+#pragma unroll
+    for (int c = 0; c < KEEP; ++c)
+        if (c * CSYM < ns) decide_chunk(c * CSYM, dk[c]);
+    for (int c0 = KEEP * CSYM; c0 < ns; c0 += CSYM) {
+        float2 d[CH];
+        products(c0, d);
+        decide_chunk(c0, d);
     }
     float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;   // (a NaN ratio never replaces the running minimum)
     margin = block_min(margin, sm);
