@@ -534,7 +534,7 @@ def leg_tetra(carriers, steps, warmup):
            "config": {"workload": f"{rows} channelised 25 kHz carriers, cf32 @72 kS/s, {n}-sample chunks", "mode": "tetra"},
            "realtime_carriers": nsym * steps / dt / 18000.0, "event_ms_per_step": ev_ms / steps,
            "stage_ms_per_launch": st,
-           "roofline": {"kernel": "k_tetra_fused<33> (RRC matched filter LDS-tiled -> timing -> Farrow -> slicer, one pass over the input)", "bound": "hbm",
+           "roofline": {"kernel": "k_tetra_fused<33> (RRC matched filter on the matrix cores (fp32 MFMA) -> timing -> Farrow -> slicer, one pass over the input)", "bound": "hbm",
                         "achieved": bytes_alg / (rrc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": bytes_alg / (rrc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                         "traffic_source": traffic_src,
