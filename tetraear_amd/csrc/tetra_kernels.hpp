@@ -113,16 +113,6 @@ __device__ __forceinline__ float atan2_turns(float y, float x)
     return y < 0.f ? -r : r;
 }
 
-// ring position of sample g (g >= 0)
-__device__ __forceinline__ int ring_slot(int p)   // p in [0, 2 kRing)
-{
-    if ((kRing & (kRing - 1)) == 0)
-        p &= kRing - 1;
-    else
-        p = (int)min((unsigned)p, (unsigned)(p - kRing));   // p >= kRing ? p - kRing : p
-    return rrc_slot(p);
-}
-
 // waves per SIMD the register allocation aims for (three workgroups per CU fit in LDS)
 #ifndef TDM_TETRA_WAVES
 #define TDM_TETRA_WAVES(NT) 3
@@ -155,7 +145,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     constexpr int PLANE = (xp_slot(NS) + 63) / 64 * 64;   // dwords per plane (multiple of 64: re and im go out as one ds_write2st64)
     static_assert(2 * kRrcThreads * (NP - 1) + 1 < NS, "only the last pair of a thread can fall outside the staged window");
     __shared__ float xsp[2 * PLANE];
-    __shared__ float2 yring[kRing + (kRing >> kRrcPadShift)];
+    __shared__ float2 yring[kRing + (kRing >> kRrcPadShift) + 4];   // + the first three samples again past the end: a symbol's four never wrap
     __shared__ float2 Cst[2 * kTileBlocks];   // the statistic of two tiles' sub-blocks
     __shared__ float tau[kTauRing];
     __shared__ float tau_mid_s;
@@ -182,6 +172,13 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     f32x4 pf[NP];
     auto fetch = [&](int tile) {
         const int g0 = tile * kRrcTile - H2 - e;          // = par (mod 2)
+        if (g0 >= par && g0 + 2 * (NP * kRrcThreads - 1) <= gmaxp) {
+            // an inner tile: nothing to clamp, one scalar base and the thread's own offset (no vector address arithmetic)
+            const f32x4 *pb = (const f32x4 *)(xr + g0);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) pf[j] = __builtin_nontemporal_load(pb + tid + j * kRrcThreads);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int g = g0 + 2 * (tid + j * kRrcThreads);
@@ -301,32 +298,43 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             const float nc = pc * P.tile_c - ps * P.tile_s, nsn = pc * P.tile_s + ps * P.tile_c;
             pc = nc;
             ps = nsn;
-            // sum over the wavefront with DPP (no LDS round trips): inside each row of 16 lanes, then across the rows
-#define TDM_DPP_ADD(X, CTRL, ROWS, BC) X += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X), CTRL, ROWS, 0xf, BC));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                TDM_DPP_ADD(acc4[c], 0xB1, 0xf, true)     // quad_perm [1,0,3,2]
-                TDM_DPP_ADD(acc4[c], 0x4E, 0xf, true)     // quad_perm [2,3,0,1]
-                TDM_DPP_ADD(acc4[c], 0x141, 0xf, true)    // row_half_mirror
-                TDM_DPP_ADD(acc4[c], 0x140, 0xf, true)    // row_mirror
-                TDM_DPP_ADD(acc4[c], 0x142, 0xa, false)   // row_bcast:15 into rows 1, 3
-                TDM_DPP_ADD(acc4[c], 0x143, 0xc, false)   // row_bcast:31 into rows 2, 3
+            // sum of the four values over the wavefront without LDS round trips, halving the number of live values in the
+            // first two steps: after them a lane holds the quad's sum of value (lane & 3) (0: re of the first sub-block, 1: re
+            // of the second, 2 / 3: the imaginary parts); then the quads of a row (row rotations keep lane & 3) and the four
+            // rows (permlane swaps).  17 vector instructions instead of the 44 of four separate butterflies.
+#define TDM_DPP(X, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X), CTRL, 0xf, 0xf, true))
+            const bool odd = lane & 1, hi = lane & 2;
+            const float s0 = odd ? acc4[2] : acc4[0], t0 = odd ? acc4[0] : acc4[2];
+            const float s1 = odd ? acc4[3] : acc4[1], t1 = odd ? acc4[1] : acc4[3];
+            const float y0 = s0 + TDM_DPP(t0, 0xB1), y1 = s1 + TDM_DPP(t1, 0xB1);   // quad_perm [1,0,3,2]
+            const float sz = hi ? y1 : y0, tz = hi ? y0 : y1;
+            float z = sz + TDM_DPP(tz, 0x4E);                                      // quad_perm [2,3,0,1]
+            z += TDM_DPP(z, 0x124);                                                // row_ror:4
+            z += TDM_DPP(z, 0x128);                                                // row_ror:8
+#undef TDM_DPP
+            {
+                auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, z), __builtin_bit_cast(unsigned, z), false, false);
+                const unsigned r0 = r[0], r1 = r[1];   // (scalar copies: see the note at the final passes)
+                z = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
             }
-#undef TDM_DPP_ADD
-            const int b = i * kTileBlocks + 2 * wv;
-            if (lane == 63) {
-                if (b < nb) Cst[b & (2 * kTileBlocks - 1)] = make_float2(acc4[0], acc4[1]);
-                if (b + 1 < nb) Cst[(b + 1) & (2 * kTileBlocks - 1)] = make_float2(acc4[2], acc4[3]);
+            {
+                auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, z), __builtin_bit_cast(unsigned, z), false, false);
+                const unsigned r0 = r[0], r1 = r[1];
+                z = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
             }
+            const int b = i * kTileBlocks + 2 * wv + (lane & 1);
+            if (lane < 4 && b < nb) ((float *)Cst)[2 * (b & (2 * kTileBlocks - 1)) + (lane >> 1)] = z;
         }
         TT_MARK(3)
         // ---- matched-filter output into the ring (a wavefront's 512 outputs never straddle its end)
         {
-            float2 *yw = yring + rrc_slot((base + 512 * wv) % kRing) + ring_lane;
+            const int pw = (base + 512 * wv) % kRing;
+            float2 *yw = yring + rrc_slot(pw) + ring_lane;
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) yw[288 * bb + 18 * r] = make_float2(cre[bb][r], cim[bb][r]);
+            if (pw == 0 && lane < 3) yring[rrc_slot(kRing) + lane] = make_float2(cre[0][0], cim[0][0]);   // (kRing is a multiple of 8)
         }
         TT_MARK(4)
         __syncthreads();   // ring, statistic visible; staging buffer free
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         TT_MARK(9)
         const int ring_lo = max(0, base + kRrcTile - kRing), ring_hi = base + kRrcTile;
         const int ring_off = ring_lo % kRing;
+        const int span4 = ring_hi - ring_lo - 4;
         const int b0_max = min(nb - 2, b_known - 1);
         const float sps_f = (float)sps;
         constexpr int SU = PER / 4;   // symbols per thread in flight together
@@ -437,14 +446,18 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             instants(k0, mm, mu);
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
-                const int m = mm[u];
                 f[u].mu = mu[u];
-                any_direct |= !(m - 1 >= ring_lo && m + 2 < ring_hi) && k0 + u * kRrcThreads < k_end;
-                const int p = min(max(m - 1, ring_lo), ring_hi - 4) - ring_lo + ring_off;   // < 2 kRing
-                f[u].ym1 = yring[ring_slot(p)];
-                f[u].y0 = yring[ring_slot(p + 1)];
-                f[u].y1 = yring[ring_slot(p + 2)];
-                f[u].y2 = yring[ring_slot(p + 3)];
+                // position of the symbol's first filter output in the ring's window; outside it -> direct path below
+                const int q = mm[u] - 1 - ring_lo;
+                any_direct |= (unsigned)q > (unsigned)span4 && k0 + u * kRrcThreads < k_end;
+                const int p = min(max(q, 0), span4) + ring_off;                    // < 2 kRing
+                const int p0 = (int)min((unsigned)p, (unsigned)(p - kRing));       // p >= kRing ? p - kRing : p
+                const int c = p0 & 7;                                              // four consecutive slots: one pad may lie between
+                const float2 *yp = yring + rrc_slot(p0);
+                f[u].ym1 = yp[0];
+                f[u].y0 = yp[1 + ((c + 1) >> 3)];
+                f[u].y1 = yp[2 + ((c + 2) >> 3)];
+                f[u].y2 = yp[3 + ((c + 3) >> 3)];
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
