@@ -22,9 +22,10 @@ namespace tdm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// LDS index of sample s: one pad slot per kRrcPerThread samples so that a thread's strided accesses (ds_read_b64 /
-// ds_write_b64, lane stride 5 or 9 slots = 10 or 18 dwords) hit 32 distinct bank pairs.
-__device__ __forceinline__ int rrc_slot(int s) { return s + (s >> kRrcPadShift); }
+// The ring of matched-filter outputs is plain: its writers store 16 consecutive samples per 16 lanes, and the four-way
+// bank conflicts of the symbol stage's strided reads (eight 8-byte reads per wavefront and tile) cost less than the
+// LDS a padded ring takes from the second workgroup of a compute unit.
+__device__ __forceinline__ constexpr int rrc_slot(int s) { return s; }
 
 // ---- workgroup helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)
@@ -113,9 +114,9 @@ __device__ __forceinline__ float atan2_turns(float y, float x)
     return y < 0.f ? -r : r;
 }
 
-// waves per SIMD the register allocation aims for (three workgroups per CU fit in LDS)
+// waves per SIMD the register allocation aims for (LDS holds two workgroups of 512 threads = 4 wavefronts per SIMD)
 #ifndef TDM_TETRA_WAVES
-#define TDM_TETRA_WAVES(NT) 3
+#define TDM_TETRA_WAVES(NT) (kRrcThreads == 512 ? 4 : 3)
 #endif
 
 #ifdef TDM_TETRA_TIMING
@@ -125,9 +126,23 @@ __device__ unsigned long long g_tetra_dbg[16];
 #define TT_MARK(i)
 #endif
 
-// staged input: two planes (re, im) of floats, two pad dwords per run of 16 samples.  The matrix-core operand loads
-// (lane = run J + 16 * (k mod 4): dword 18 J + k) then touch 32 different banks in each half of the wavefront.
-__device__ __forceinline__ constexpr int xp_slot(int q) { return q + 2 * (q >> 4); }
+// Split-bf16 arithmetic of the matched filter: a float is the sum of two bf16 (16 significant bits), a product of two
+// such sums keeps its three leading terms; the matrix cores multiply bf16 exactly and accumulate in fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b)   // (bf16(a), bf16(b)) in one dword, round to nearest even
+{
+    const bf16x2 v = __builtin_convertvector((f32x2{a, b}), bf16x2);
+    return __builtin_bit_cast(uint32_t, v);
+}
+// leading and trailing bf16 halves of two floats: hi = (bf16(a), bf16(b)), lo = (bf16(a - hi_a), bf16(b - hi_b))
+__device__ __forceinline__ void split_bf16(float a, float b, uint32_t &hi, uint32_t &lo)
+{
+    hi = pk_bf16(a, b);
+    const float a1 = __builtin_bit_cast(float, hi << 16), b1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pk_bf16(a - a1, b - b1);
+}
 
 template <int NT>
 __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fused(const float2 *__restrict__ x, int64_t in_stride,
@@ -135,17 +150,20 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                                                               uint8_t *__restrict__ hard, int32_t *n_soft,
                                                               int32_t *timing_milli, double *min_margin)
 {
-    static_assert(kRrcPerThread == 8 && kRrcThreads == 256 && kTimingBlock == 256, "a wavefront owns two timing sub-blocks of a tile");
+    static_assert(kRrcPerThread == 8 && kRrcThreads % 64 == 0 && kTimingBlock == 256, "a wavefront owns two timing sub-blocks of a tile");
     static_assert(kRing % 512 == 0 && kRing - kRrcTile - kTimingBlock * (2 * kTimingHalfWin + 1) / 2 >= kTimingBlock, "ring too short");
     constexpr int PER = kRrcPerThread;
     constexpr int HALO = NT - 1, H2 = HALO / 2;
-    constexpr int KS = (kRrcRun + HALO + 3) / 4;          // matrix-core steps (4 window positions each) per run of 16 outputs
-    constexpr int NS = kRrcTile - kRrcRun + 4 * KS;       // samples staged per tile: base - H2 .. base - H2 + NS
-    constexpr int NP = ((NS + 2) / 2 + kRrcThreads - 1) / kRrcThreads;   // 16-byte sample pairs per thread (+1 sample: alignment)
-    constexpr int PLANE = (xp_slot(NS) + 63) / 64 * 64;   // dwords per plane (multiple of 64: re and im go out as one ds_write2st64)
-    static_assert(2 * kRrcThreads * (NP - 1) + 1 < NS, "only the last pair of a thread can fall outside the staged window");
-    __shared__ float xsp[2 * PLANE];
-    __shared__ float2 yring[kRing + (kRing >> kRrcPadShift) + 4];   // + the first three samples again past the end: a symbol's four never wrap
+    constexpr int KS = (kRrcRun + HALO + 31) / 32;        // matrix-core steps (32 window positions each) per run of 16 outputs
+    constexpr int NS = kRrcTile - kRrcRun + 32 * KS;      // samples staged per tile: base - H2 .. base - H2 + NS
+    constexpr int NP = (NS / 2 + 1 + kRrcThreads - 1) / kRrcThreads;   // 16-byte sample pairs per thread (+1: a window that starts inside a pair)
+    constexpr int PLANE = (NS / 2 + 63) / 64 * 64;        // dwords per plane of bf16 pairs
+    static_assert(NS % 2 == 0 && kRrcThreads * (NP - 1) + 1 < NS / 2, "only the last pair of a thread can fall outside the staged window");
+    // staged input, four planes of bf16: leading / trailing halves of the real parts, then of the imaginary parts; sample
+    // q of a plane is half q of the plane's dwords.  (No padding: a 16-byte operand load of lane l starts at sample
+    // 16 (l & 15) + 8 (l >> 4) of its block, and the lane groups the LDS serves together cover 256 distinct bytes.)
+    __shared__ __attribute__((aligned(16))) uint32_t xsb[4 * PLANE];
+    __shared__ float2 yring[kRing + 4];   // + the first three samples again past the end: a symbol's four never wrap
     __shared__ float2 Cst[2 * kTileBlocks];   // the statistic of two tiles' sub-blocks
     __shared__ float tau[kTauRing];
     __shared__ float tau_mid_s;
@@ -185,52 +203,89 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             pf[j] = __builtin_nontemporal_load((const f32x4 *)(xr + min(max(g, par), gmaxp)));
         }
     };
-    auto put = [&](int q, float re, float im) {
-        const int a = xp_slot(q);
-        xsp[a] = re;
-        xsp[PLANE + a] = im;
+    // a loaded pair of consecutive samples into the four planes.  The staged window starts at chunk position base - H2
+    // whatever the row's alignment, so that the matrix-core operands -- and with them every rounding -- do not depend on
+    // where the caller's buffer lies: pair idx holds staged samples 2 idx - e and 2 idx - e + 1, one dword per plane
+    // when e = 0, two 16-bit stores per plane when the pair straddles two dwords (rows at odd multiples of 8 bytes).
+    auto put = [&](auto odd_c, int idx, bool last_pair, float re0, float im0, float re1, float im1) __attribute__((always_inline)) {
+        uint32_t w[4];
+        split_bf16(re0, re1, w[0], w[1]);
+        split_bf16(im0, im1, w[2], w[3]);
+        if (!decltype(odd_c)::value) {
+            if (!last_pair || idx < NS / 2) {
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) xsb[pl * PLANE + idx] = w[pl];
+            }
+        } else {
+            uint16_t *hp = (uint16_t *)xsb;
+            const int q = 2 * idx - 1;
+            if (q >= 0 && (!last_pair || q < NS)) {
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) hp[2 * pl * PLANE + q] = (uint16_t)w[pl];
+            }
+            if (!last_pair || q + 1 < NS) {
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) hp[2 * pl * PLANE + q + 1] = (uint16_t)(w[pl] >> 16);
+            }
+        }
     };
-    auto stage = [&](int tile) {
-        const int g0 = tile * kRrcTile - H2;
-        if (g0 - e >= par && g0 + NS <= gmaxp) {   // every pair of the tile lies inside the chunk: no masks
+    auto stage_as = [&](auto odd_c, int tile) __attribute__((always_inline)) {
+        const int g0 = tile * kRrcTile - H2 - e;   // chunk position of the first pair (= par mod 2)
+        if (g0 >= par && g0 + NS + 2 <= gmaxp) {   // every pair of the tile lies inside the chunk: no masks
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const int q = 2 * (tid + j * kRrcThreads) - e;
                 const f32x4 v = pf[j];
-                if ((j > 0 || q >= 0) && (j < NP - 1 || q < NS)) put(q, v.x, v.y);
-                if (j < NP - 1 || q + 1 < NS) put(q + 1, v.z, v.w);
+                put(odd_c, tid + j * kRrcThreads, j == NP - 1, v.x, v.y, v.z, v.w);
             }
             return;
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int q = 2 * (tid + j * kRrcThreads) - e;   // staged index of the pair's first sample
-            const int g = g0 + q;
+            const int idx = tid + j * kRrcThreads;
+            const int g = g0 + 2 * idx;               // chunk position of the pair's first sample
             const bool in = g >= par && g <= gmaxp;
             const f32x4 v = pf[j];
             const float2 e0 = in ? make_float2(v.x, v.y) : (g == n - 1 ? x_last : make_float2(0.f, 0.f));
             const float2 e1 = in ? make_float2(v.z, v.w) : (g == -1 ? x_first : make_float2(0.f, 0.f));
-            if ((j > 0 || q >= 0) && (j < NP - 1 || q < NS)) put(q, e0.x, e0.y);
-            if (j < NP - 1 || q + 1 < NS) put(q + 1, e1.x, e1.y);
+            put(odd_c, idx, j == NP - 1, e0.x, e0.y, e1.x, e1.y);
         }
     };
+    auto stage = [&](int tile) __attribute__((always_inline)) {
+        if (e == 0) stage_as(std::false_type{}, tile);
+        else stage_as(std::true_type{}, tile);
+    };
 
-    // ---- matched filter on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 multiply-adds, executed beside the
-    // vector ALU that everything else in this kernel keeps busy).  A wavefront owns 512 consecutive outputs of a tile =
-    // two timing sub-blocks of 16 runs of 16:  Y[J][i] = y[16 J + i] = sum_m X[J][m] T[m][i],  X[J][m] = staged sample
-    // 16 J + m (m < 16 + NT - 1),  T[m][i] = h[m - i] (Toeplitz, zero outside the taps): 33 of 48 multiply-adds are
-    // useful at 33 taps.  Lane l supplies X[l & 15][4 s + (l >> 4)] (one dword from LDS per step and component) and the
-    // constant T[4 s + (l >> 4)][l & 15]; it receives Y[4 (l >> 4) + r][l & 15], r < 4.
+    // ---- matched filter on the matrix cores.  A wavefront owns 512 consecutive outputs of a tile = two timing sub-blocks
+    // of 16 runs of 16:  Y[J][i] = y[16 J + i] = sum_m X[J][m] T[m][i],  X[J][m] = staged sample 16 J + m,
+    // T[m][i] = h[m - i] (Toeplitz, zero outside the taps).
+    // Data and taps are split into two bf16 each, x = x1 + x2, h = h1 + h2, and the product keeps x1 h1 + x1 h2 + x2 h1
+    // (what is dropped is below 2^-16 of |x||h|: 1e-5 of a symbol, two decades under the 8-bit samples' own noise) on
+    // v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 3 x KS instructions per 16 x 16 outputs at 16x the fp32 rate.
+    // (The fp32-input MFMA computes the same sums exactly but runs on the vector ALUs' own multipliers: measured, its
+    // 48 instructions per wavefront and tile add their full 0.20 ms to the 0.37 ms of the rest of this kernel.)
+    // Lane l supplies X[l & 15][32 s + 8 (l >> 4) .. + 7] (16 bytes per plane and step from LDS) and the constants
+    // T[32 s + 8 (l >> 4) .. + 7][l & 15]; it receives Y[4 (l >> 4) + r][l & 15], r < 4.
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float hB[KS];
+    u32x4 hB1[KS], hB2[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const int t = 4 * s + (lane >> 4) - (lane & 15);
-        const float h = P.taps[min(max(t, 0), NT - 1)];
-        hB[s] = (t >= 0 && t < NT) ? h : 0.f;
+        uint32_t w1[4], w2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float hv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int t = 32 * s + 8 * (lane >> 4) + 2 * j + c - (lane & 15);
+                const float h = P.taps[min(max(t, 0), NT - 1)];
+                hv[c] = (t >= 0 && t < NT) ? h : 0.f;
+            }
+            split_bf16(hv[0], hv[1], w1[j], w2[j]);
+        }
+        hB1[s] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+        hB2[s] = u32x4{w2[0], w2[1], w2[2], w2[3]};
     }
-    const float *ab = xsp + xp_slot(512 * wv + 16 * (lane & 15)) + (lane >> 4);
+    const u32x4 *ab = (const u32x4 *)(xsb + 256 * wv + 8 * (lane & 15) + 4 * (lane >> 4));
     const int out_off = 64 * (lane >> 4) + (lane & 15);   // the lane's outputs inside a sub-block: out_off + 16 r
     const int ring_lane = rrc_slot(out_off);
 
@@ -266,9 +321,16 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
-                const int o = 288 * bb + 4 * s + 2 * (s >> 2);
-                cre[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[o], hB[s], cre[bb], 0, 0, 0);
-                cim[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[PLANE + o], hB[s], cim[bb], 0, 0, 0);
+                const int o = 32 * bb + 4 * s;   // (16-byte units: a sub-block is 128 dwords of a plane, a step 16)
+                const bf16x8 r1 = __builtin_bit_cast(bf16x8, ab[o]), r2 = __builtin_bit_cast(bf16x8, ab[PLANE / 4 + o]);
+                const bf16x8 i1 = __builtin_bit_cast(bf16x8, ab[2 * (PLANE / 4) + o]), i2 = __builtin_bit_cast(bf16x8, ab[3 * (PLANE / 4) + o]);
+                const bf16x8 h1 = __builtin_bit_cast(bf16x8, hB1[s]), h2 = __builtin_bit_cast(bf16x8, hB2[s]);
+                cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2, h1, cre[bb], 0, 0, 0);
+                cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i2, h1, cim[bb], 0, 0, 0);
+                cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r1, h2, cre[bb], 0, 0, 0);
+                cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i1, h2, cim[bb], 0, 0, 0);
+                cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r1, h1, cre[bb], 0, 0, 0);
+                cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i1, h1, cim[bb], 0, 0, 0);
             }
         }
         TT_MARK(2)
@@ -333,7 +395,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yw[288 * bb + 18 * r] = make_float2(cre[bb][r], cim[bb][r]);
+                for (int r = 0; r < 4; ++r) yw[rrc_slot(256 * bb + 16 * r)] = make_float2(cre[bb][r], cim[bb][r]);
             if (pw == 0 && lane < 3) yring[rrc_slot(kRing) + lane] = make_float2(cre[0][0], cim[0][0]);   // (kRing is a multiple of 8)
         }
         TT_MARK(4)
@@ -349,7 +411,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         // (every wavefront computes them, identically, in its first lanes: cheaper than a barrier around one that does)
         {
             const int lane = tid & 63;
-            const int cnt = b_known - b_done + 1;   // <= 10
+            const int cnt = b_known - b_done + 1;   // <= kTileBlocks + kTimingHalfWin
             const int b = b_done + lane;
             float cr = 0.f, ci = 0.f;
             const int lo = max(0, b - kTimingHalfWin), hi = min(nb - 1, b + kTimingHalfWin);
@@ -367,11 +429,13 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             if (!(fabsf(tb) <= 1.0f) || lane >= cnt) tb = 0.f;
             // unwrap: tau_b = raw_b + N_b, N_b = N_{b-1} + rint(raw_{b-1} - raw_b) (whole symbols), as an inclusive scan
             // over the (<= 10) new sub-blocks in the first row of the wavefront (DPP row shifts)
-            const float rawp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tb), 0x111, 0xf, 0xf, true));   // row_shr:1
+            const float rawp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tb), 0x138, 0xf, 0xf, false));   // wave_shr:1 (the new sub-blocks may reach into the second row of lanes)
             float stp = lane == 0 ? (b_done > 0 ? rintf(tau_prev - tb) : 0.f) : rintf(rawp - tb);
 #define TDM_ROW_SHR_ADD(D) stp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, stp), 0x110 + D, 0xf, 0xf, true));   // row_shr:D, zero shifted in
             TDM_ROW_SHR_ADD(1) TDM_ROW_SHR_ADD(2) TDM_ROW_SHR_ADD(4) TDM_ROW_SHR_ADD(8)
 #undef TDM_ROW_SHR_ADD
+            if (kTileBlocks + kTimingHalfWin > 16)   // more new sub-blocks than a row of 16 lanes: the first row's total enters the second
+                stp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, stp), 0x142, 0x2, 0xf, false));   // row_bcast:15 into row 1
             tb += stp;
             tau_prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb), cnt - 1));
             if (lane < cnt) {
@@ -452,12 +516,11 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 any_direct |= (unsigned)q > (unsigned)span4 && k0 + u * kRrcThreads < k_end;
                 const int p = min(max(q, 0), span4) + ring_off;                    // < 2 kRing
                 const int p0 = (int)min((unsigned)p, (unsigned)(p - kRing));       // p >= kRing ? p - kRing : p
-                const int c = p0 & 7;                                              // four consecutive slots: one pad may lie between
                 const float2 *yp = yring + rrc_slot(p0);
                 f[u].ym1 = yp[0];
-                f[u].y0 = yp[1 + ((c + 1) >> 3)];
-                f[u].y1 = yp[2 + ((c + 2) >> 3)];
-                f[u].y2 = yp[3 + ((c + 3) >> 3)];
+                f[u].y0 = yp[1];
+                f[u].y1 = yp[2];
+                f[u].y2 = yp[3];
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
@@ -517,7 +580,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     typedef f32x4 __attribute__((aligned(8))) f32x4_a8;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef u32x2 __attribute__((aligned(1))) u32x2_a1;
-    constexpr int CH = 8, CSYM = CH * kRrcThreads, KEEP = 4;
+    constexpr int CH = 8, CSYM = CH * kRrcThreads, KEEP = 8192 / CSYM;
     const int ms2 = P.max_soft - 2;   // (ns <= max_soft - 2: a pair that holds a symbol below ns is never clamped)
     auto products = [&](int c0, float2 (&d)[CH]) {
         const int i0 = c0 + CH * tid;

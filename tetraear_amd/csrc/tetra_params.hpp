@@ -7,13 +7,15 @@
 namespace tdm {
 
 constexpr int kRrcMaxTaps = 96;
-constexpr int kRrcThreads = 256;
+#ifndef TDM_TETRA_THREADS
+#define TDM_TETRA_THREADS 256
+#endif
+constexpr int kRrcThreads = TDM_TETRA_THREADS;            // 256: three workgroups per CU fit in LDS (0.465 ms per 4096 x 32768); 512: two (0.48 ms)
 #ifndef TDM_TETRA_PER
 #define TDM_TETRA_PER 8
 #endif
 constexpr int kRrcPerThread = TDM_TETRA_PER;              // outputs per thread and tile (8: a wavefront owns 512 consecutive outputs)
 constexpr int kRrcRun = 16;                               // outputs per row of the matched filter's matrix-core tiles
-constexpr int kRrcPadShift = kRrcPerThread == 4 ? 2 : 3;  // LDS: one pad slot per kRrcPerThread samples
 constexpr int kRrcTile = kRrcThreads * kRrcPerThread;     // samples per round of a workgroup
 constexpr int kTimingBlock = 256;                         // samples per timing sub-block (TB)
 constexpr int kTimingHalfWin = 2;                         // sub-blocks averaged each side (TW)
@@ -24,7 +26,7 @@ constexpr int kTileBlocks = kRrcTile / kTimingBlock;      // sub-blocks per tile
 // estimates are final then), so the ring covers them with kRing - T - 640 samples to spare below and 640 above: that
 // is how far the unwrapped timing estimate may carry a symbol instant from its nominal position (48 symbols at 8
 // samples/symbol) before the symbol takes the direct path (its four filter outputs recomputed from the input).
-constexpr int kRing = kRrcPerThread == 4 ? 2048 : 3072;
+constexpr int kRing = kRrcTile + 1024;
 constexpr int kTauRing = 32;                              // timing estimates kept (a round reads at most kTileBlocks + 2 of them)
 
 struct TetraParams {
