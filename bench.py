@@ -530,11 +530,11 @@ def leg_tetra(carriers, steps, warmup):
     out = {"metric": "Msymbols/s demodulated (TETRA mode: RRC + feed-forward timing + Farrow + quadrant slicer)",
            "value": nsym * steps / dt / 1e6, "unit": "Msym/s", "n_gpus": 1, "steps": steps,
            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None, "dtype": "f32 (matched filter: split-bf16 products accumulated in fp32, 6e-6 of full scale from the fp64 definition)", "data": "synthetic",
            "config": {"workload": f"{rows} channelised 25 kHz carriers, cf32 @72 kS/s, {n}-sample chunks", "mode": "tetra"},
            "realtime_carriers": nsym * steps / dt / 18000.0, "event_ms_per_step": ev_ms / steps,
            "stage_ms_per_launch": st,
-           "roofline": {"kernel": "k_tetra_fused<33> (RRC matched filter on the matrix cores (fp32 MFMA) -> timing -> Farrow -> slicer, one pass over the input)", "bound": "hbm",
+           "roofline": {"kernel": "k_tetra_fused<33> (RRC matched filter on the matrix cores (split-bf16 products, fp32 accumulate) -> timing -> Farrow -> slicer, one pass over the input)", "bound": "hbm",
                         "achieved": bytes_alg / (rrc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": bytes_alg / (rrc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                         "traffic_source": traffic_src,

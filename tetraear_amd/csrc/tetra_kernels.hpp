@@ -156,9 +156,9 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     constexpr int HALO = NT - 1, H2 = HALO / 2;
     constexpr int KS = (kRrcRun + HALO + 31) / 32;        // matrix-core steps (32 window positions each) per run of 16 outputs
     constexpr int NS = kRrcTile - kRrcRun + 32 * KS;      // samples staged per tile: base - H2 .. base - H2 + NS
-    constexpr int NP = (NS / 2 + 1 + kRrcThreads - 1) / kRrcThreads;   // 16-byte sample pairs per thread (+1: a window that starts inside a pair)
+    constexpr int NP = (NS / 2 + kRrcThreads - 1) / kRrcThreads;   // 16-byte sample pairs per thread
     constexpr int PLANE = (NS / 2 + 63) / 64 * 64;        // dwords per plane of bf16 pairs
-    static_assert(NS % 2 == 0 && kRrcThreads * (NP - 1) + 1 < NS / 2, "only the last pair of a thread can fall outside the staged window");
+    static_assert(NS % 2 == 0 && kRrcThreads * (NP - 1) < NS / 2, "only the last pair of a thread can fall outside the staged window");
     // staged input, four planes of bf16: leading / trailing halves of the real parts, then of the imaginary parts; sample
     // q of a plane is half q of the plane's dwords.  (No padding: a 16-byte operand load of lane l starts at sample
     // 16 (l & 15) + 8 (l >> 4) of its block, and the lane groups the LDS serves together cover 256 distinct bytes.)
@@ -179,20 +179,20 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     const int ntiles = (n + kRrcTile - 1) / kRrcTile;
     // ---- input: a tile's samples base - H2 .. base - H2 + NS (zero outside the chunk) travel HBM -> registers one
     // tile ahead of their use, as 16-byte pairs.  A row starts on an 8-byte boundary (pitched channeliser rows, odd
-    // offsets): pairs begin at the samples whose address is a multiple of 16 (index parity `par`), so a thread's first
-    // pair starts `e` samples before the window; the one sample a clamped pair can miss at either end of the chunk is
-    // read once up front.  fetch() only issues loads (clamped addresses, no branch, nothing that consumes a loaded
-    // value: a use would wait for the load on the spot); stage() masks what lies outside the chunk and writes LDS.
-    const int par = (int)(((uintptr_t)xr >> 3) & 1);
-    const int e = (H2 + par) & 1;
-    const int gmaxp = ((n - 2 - par) & ~1) + par;         // last pair start inside the chunk
+    // offsets, odd tap half-lengths), so a pair may lie across two 16-byte segments: the loads are declared 8-byte
+    // aligned, a wavefront's 1 KB then touches nine cache lines instead of eight, and nothing downstream depends on where
+    // the caller's buffer lies.  The one sample a clamped pair can miss at either end of the chunk is read once up
+    // front.  fetch() only issues loads (clamped addresses, nothing that consumes a loaded value: a use would wait for
+    // the load on the spot); stage() masks what lies outside the chunk, splits into bf16 and writes LDS.
+    typedef f32x4 __attribute__((aligned(8))) f32x4_a8;
+    const int gmaxp = n - 2;                              // last pair start inside the chunk
     const float2 x_first = xr[0], x_last = xr[n - 1];
     f32x4 pf[NP];
     auto fetch = [&](int tile) {
-        const int g0 = tile * kRrcTile - H2 - e;          // = par (mod 2)
-        if (g0 >= par && g0 + 2 * (NP * kRrcThreads - 1) <= gmaxp) {
+        const int g0 = tile * kRrcTile - H2;
+        if (g0 >= 0 && g0 + 2 * (NP * kRrcThreads - 1) <= gmaxp) {
             // an inner tile: nothing to clamp, one scalar base and the thread's own offset (no vector address arithmetic)
-            const f32x4 *pb = (const f32x4 *)(xr + g0);
+            const f32x4_a8 *pb = (const f32x4_a8 *)(xr + g0);
 #pragma unroll
             for (int j = 0; j < NP; ++j) pf[j] = __builtin_nontemporal_load(pb + tid + j * kRrcThreads);
             return;
@@ -200,42 +200,26 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int g = g0 + 2 * (tid + j * kRrcThreads);
-            pf[j] = __builtin_nontemporal_load((const f32x4 *)(xr + min(max(g, par), gmaxp)));
+            pf[j] = __builtin_nontemporal_load((const f32x4_a8 *)(xr + min(max(g, 0), gmaxp)));
         }
     };
-    // a loaded pair of consecutive samples into the four planes.  The staged window starts at chunk position base - H2
-    // whatever the row's alignment, so that the matrix-core operands -- and with them every rounding -- do not depend on
-    // where the caller's buffer lies: pair idx holds staged samples 2 idx - e and 2 idx - e + 1, one dword per plane
-    // when e = 0, two 16-bit stores per plane when the pair straddles two dwords (rows at odd multiples of 8 bytes).
-    auto put = [&](auto odd_c, int idx, bool last_pair, float re0, float im0, float re1, float im1) __attribute__((always_inline)) {
+    // a loaded pair of consecutive samples (pair idx = staged samples 2 idx, 2 idx + 1) into the four planes
+    auto put = [&](int idx, bool last_pair, float re0, float im0, float re1, float im1) __attribute__((always_inline)) {
         uint32_t w[4];
         split_bf16(re0, re1, w[0], w[1]);
         split_bf16(im0, im1, w[2], w[3]);
-        if (!decltype(odd_c)::value) {
-            if (!last_pair || idx < NS / 2) {
+        if (!last_pair || idx < NS / 2) {
 #pragma unroll
-                for (int pl = 0; pl < 4; ++pl) xsb[pl * PLANE + idx] = w[pl];
-            }
-        } else {
-            uint16_t *hp = (uint16_t *)xsb;
-            const int q = 2 * idx - 1;
-            if (q >= 0 && (!last_pair || q < NS)) {
-#pragma unroll
-                for (int pl = 0; pl < 4; ++pl) hp[2 * pl * PLANE + q] = (uint16_t)w[pl];
-            }
-            if (!last_pair || q + 1 < NS) {
-#pragma unroll
-                for (int pl = 0; pl < 4; ++pl) hp[2 * pl * PLANE + q + 1] = (uint16_t)(w[pl] >> 16);
-            }
+            for (int pl = 0; pl < 4; ++pl) xsb[pl * PLANE + idx] = w[pl];
         }
     };
-    auto stage_as = [&](auto odd_c, int tile) __attribute__((always_inline)) {
-        const int g0 = tile * kRrcTile - H2 - e;   // chunk position of the first pair (= par mod 2)
-        if (g0 >= par && g0 + NS + 2 <= gmaxp) {   // every pair of the tile lies inside the chunk: no masks
+    auto stage = [&](int tile) __attribute__((always_inline)) {
+        const int g0 = tile * kRrcTile - H2;       // chunk position of the first pair
+        if (g0 >= 0 && g0 + NS <= gmaxp) {         // every pair of the tile lies inside the chunk: no masks
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const f32x4 v = pf[j];
-                put(odd_c, tid + j * kRrcThreads, j == NP - 1, v.x, v.y, v.z, v.w);
+                put(tid + j * kRrcThreads, j == NP - 1, v.x, v.y, v.z, v.w);
             }
             return;
         }
@@ -243,16 +227,12 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         for (int j = 0; j < NP; ++j) {
             const int idx = tid + j * kRrcThreads;
             const int g = g0 + 2 * idx;               // chunk position of the pair's first sample
-            const bool in = g >= par && g <= gmaxp;
+            const bool in = g >= 0 && g <= gmaxp;
             const f32x4 v = pf[j];
             const float2 e0 = in ? make_float2(v.x, v.y) : (g == n - 1 ? x_last : make_float2(0.f, 0.f));
             const float2 e1 = in ? make_float2(v.z, v.w) : (g == -1 ? x_first : make_float2(0.f, 0.f));
-            put(odd_c, idx, j == NP - 1, e0.x, e0.y, e1.x, e1.y);
+            put(idx, j == NP - 1, e0.x, e0.y, e1.x, e1.y);
         }
-    };
-    auto stage = [&](int tile) __attribute__((always_inline)) {
-        if (e == 0) stage_as(std::false_type{}, tile);
-        else stage_as(std::true_type{}, tile);
     };
 
     // ---- matched filter on the matrix cores.  A wavefront owns 512 consecutive outputs of a tile = two timing sub-blocks
@@ -577,7 +557,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // symbols come back from L2), the predecessor of its first symbol from the lane to its left (one wavefront shift), one
     // 8-byte store of its decisions.  The products of the first KEEP chunks (8192 symbols) stay in registers between the
     // two passes; longer chunks form theirs again.
-    typedef f32x4 __attribute__((aligned(8))) f32x4_a8;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef u32x2 __attribute__((aligned(1))) u32x2_a1;
     constexpr int CH = 8, CSYM = CH * kRrcThreads, KEEP = 8192 / CSYM;
