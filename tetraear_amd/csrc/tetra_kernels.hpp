@@ -297,8 +297,12 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             cre[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
             cim[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#ifndef TDM_TETRA_MFMA_REPS
+#define TDM_TETRA_MFMA_REPS 1   // (experiment hook: 0 / 2 / 3 price the matched filter's share of the kernel)
+#endif
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s_ = 0; s_ < KS * TDM_TETRA_MFMA_REPS; ++s_) {
+            const int s = s_ % KS;
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 const int o = 32 * bb + 4 * s;   // (16-byte units: a sub-block is 128 dwords of a plane, a step 16)
