@@ -117,6 +117,26 @@ def test_gpu_tetra_every_rate_in_the_contract_and_nonfinite_input():
 
 
 @pytest.mark.gpu
+def test_gpu_tetra_input_scale():
+    """Power-of-two scalings of the input (int16-range IQ passed as floats, very small IQ) give the same decisions, the
+    same timing and margin, and soft symbols that are the unscaled ones times the factor: the split-bf16 matched filter
+    and the 4th-power carrier-offset estimate (an 8th power of the amplitude) are both kept scale-free."""
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    fs, n = 72000.0, 16384
+    x, dib = make_signal(n, fs, 31, 0.3, 60.0, 20.0)
+    bd = BatchDemodulator(fs, n, 3, "cf32", mode=MODE_TETRA)
+    scales = (1.0, 2.0 ** 15, 2.0 ** -22)
+    hards, softs, timing, margin = bd.process(np.concatenate([(x * s).astype(np.complex64) for s in scales]))
+    bd.close()
+    assert best_ber(hards[0], dib, edge=8)[0] == 0.0
+    for r, s in enumerate(scales):
+        np.testing.assert_array_equal(hards[r], hards[0])
+        np.testing.assert_allclose(softs[r] / s, softs[0], rtol=0, atol=2e-6 * np.max(np.abs(softs[0])))
+        assert timing[r] == timing[0] and abs(margin[r] - margin[0]) < 1e-6
+
+
+@pytest.mark.gpu
 def test_gpu_tetra_instants_beyond_the_ring():
     """Symbol instants that leave the matched-filter ring in LDS (48 symbols below, 80 above their nominal positions at
     8 samples/symbol) take the kernel's direct path (filter outputs recomputed from the input).

@@ -565,12 +565,28 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     typedef u32x2 __attribute__((aligned(1))) u32x2_a1;
     constexpr int CH = 8, CSYM = CH * kRrcThreads, KEEP = 8192 / CSYM;
     const int ms2 = P.max_soft - 2;   // (ns <= max_soft - 2: a pair that holds a symbol below ns is never clamped)
+    // The 4th power of a differential product is the 8th power of the input's scale: symbols enter the products times a
+    // power of two that brings the carrier's middle symbol to [0.5, 1) -- exact, so estimate, decisions and margin are what
+    // they would be without it, and inputs anywhere in fp32's range (int16-scaled IQ, 1e-6-scaled IQ) neither overflow
+    // nor flush to zero.
+    float sc = 1.f;
+    if (ns > 0) {
+        const float2 smid = sr[ns >> 1];
+        const float a = fmaxf(fabsf(smid.x), fabsf(smid.y));
+        int ex = 0;
+        if (a > 0.f && a < 3.0e38f) (void)frexpf(a, &ex);
+        sc = ldexpf(1.f, -ex);
+    }
     auto products = [&](int c0, float2 (&d)[CH]) {
         const int i0 = c0 + CH * tid;
         f32x4 v[CH / 2];
 #pragma unroll
         for (int j = 0; j < CH / 2; ++j) v[j] = *(const f32x4_a8 *)(sr + min(i0 + 2 * j, ms2));
-        const float2 pm = sr[max(min(i0, ms2) - 1, 0)];   // (used by lane 0 of a wavefront)
+        float2 pm = sr[max(min(i0, ms2) - 1, 0)];   // (used by lane 0 of a wavefront)
+        pm.x *= sc;
+        pm.y *= sc;
+#pragma unroll
+        for (int j = 0; j < CH / 2; ++j) v[j] *= sc;
         // (copies first: __builtin_bit_cast of a vector-element lvalue reads element 0 with this compiler)
         const float lx = v[CH / 2 - 1].z, ly = v[CH / 2 - 1].w;
         float px = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lx), 0x138, 0xf, 0xf, false));   // wave_shr:1
