@@ -67,22 +67,16 @@ struct FarrowTaps {
 };
 __device__ __forceinline__ float2 farrow_eval(const FarrowTaps &f)
 {
-    const float2 ym1 = f.ym1, y0 = f.y0, y1 = f.y1, y2 = f.y2;
-    const float mu = f.mu;
-    float2 r;
-    {
-        const float c1 = y1.x - ym1.x * (1.f / 3.f) - y0.x * 0.5f - y2.x * (1.f / 6.f);
-        const float c2 = (ym1.x + y1.x) * 0.5f - y0.x;
-        const float c3 = (y2.x - ym1.x) * (1.f / 6.f) + (y0.x - y1.x) * 0.5f;
-        r.x = ((c3 * mu + c2) * mu + c1) * mu + y0.x;
-    }
-    {
-        const float c1 = y1.y - ym1.y * (1.f / 3.f) - y0.y * 0.5f - y2.y * (1.f / 6.f);
-        const float c2 = (ym1.y + y1.y) * 0.5f - y0.y;
-        const float c3 = (y2.y - ym1.y) * (1.f / 6.f) + (y0.y - y1.y) * 0.5f;
-        r.y = ((c3 * mu + c2) * mu + c1) * mu + y0.y;
-    }
-    return r;
+    // the cubic through the four samples at -1, 0, 1, 2 as Lagrange weights of mu (11 scalar operations), then four
+    // packed multiply-adds on the (re, im) pairs as they come out of LDS
+    const float mu = f.mu, a = mu + 1.f, b = mu - 1.f, c = mu - 2.f;
+    const float s1 = (mu * b) * (1.f / 6.f), s2 = (a * c) * 0.5f;
+    const float w2 = s1 * a, wm1 = -(s1 * c), w0 = s2 * b, w1 = -(s2 * mu);
+    f32x2 r = f32x2{f.ym1.x, f.ym1.y} * wm1;
+    r += f32x2{f.y0.x, f.y0.y} * w0;
+    r += f32x2{f.y1.x, f.y1.y} * w1;
+    r += f32x2{f.y2.x, f.y2.y} * w2;
+    return make_float2(r.x, r.y);
 }
 // piecewise-linear timing estimate at sample position pos (sub-block centres at (b+0.5)*TB)
 __device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
@@ -275,6 +269,8 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         const double ph = (double)(512 * wv + out_off) * P.inv_sps;
         sincospif(-2.f * (float)(ph - floor(ph)), &ps, &pc);
     }
+    const uint64_t sps40 = (uint64_t)(sps * 1099511627776.0);   // samples per symbol, 40 fraction bits
+    const uint64_t ptid = (uint64_t)(uint32_t)tid * sps40;       // the thread's share of its symbols' nominal positions
     float tau_prev = 0.f;   // (wave 0) last unwrapped estimate
     int b_done = 0;         // sub-blocks whose estimate is final
     int k_lo = 0, k_begin = 0, ns = 0;
@@ -450,36 +446,40 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             k_end = min((int)(((double)b_known + 0.5) * (double)kTimingBlock * P.inv_sps), k_lo + P.max_soft);
         }
         TT_MARK(9)
+        k_end = __builtin_amdgcn_readfirstlane(k_end);       // (uniform by construction: scalar loop control and store bases)
+        k_begin = __builtin_amdgcn_readfirstlane(k_begin);
         const int ring_lo = max(0, base + kRrcTile - kRing), ring_hi = base + kRrcTile;
         const int ring_off = ring_lo % kRing;
         const int span4 = ring_hi - ring_lo - 4;
         const int b0_max = min(nb - 2, b_known - 1);
         const float sps_f = (float)sps;
         constexpr int SU = PER / 4;   // symbols per thread in flight together
-        // whole sample m and fraction mu of the instant t_k = (k + tau(k sps)) sps; SU symbols side by side so that their
-        // LDS round trips (two timing estimates, then four ring samples) overlap
-        auto instants = [&](int k0, int (&mm)[SU], float (&mu)[SU]) {
-            float tk[SU], uf[SU], ta[SU], tb2[SU], ff[SU];
+        // whole sample m and fraction mu of the instant t_k = (k + tau(k sps)) sps for the symbols kb + tid + u * 256; SU
+        // symbols side by side so that their LDS round trips (two timing estimates, then four ring samples) overlap.  The
+        // nominal position k sps is a 64-bit fixed-point number with 40 fraction bits (3e-8 samples at the end of the
+        // longest chunk): the thread's own share is a constant, the rest of the sum is uniform -- one 64-bit add per symbol
+        // where the first version converted to and from fp64.
+        auto instants = [&](int kb, int (&mm)[SU], float (&mu)[SU]) {
+            float tk[SU], ta[SU], tb2[SU], ff[SU];
             int mk[SU];
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
-                const int k = min(k0 + u * kRrcThreads, k_end - 1);
-                const double kd = (double)k * sps;          // nominal position, exact split into whole samples + fraction
-                mk[u] = (int)kd;
-                tk[u] = (float)(kd - (double)mk[u]);
-                uf[u] = ((float)mk[u] + tk[u]) * (1.f / (float)kTimingBlock) - 0.5f;
-            }
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                // piecewise-linear timing estimate between sub-block centres (both estimates final: b0 + 1 <= b_known)
-                const int b0 = max(min((int)floorf(uf[u]), b0_max), 0);
-                ff[u] = fminf(fmaxf(uf[u] - (float)b0, 0.f), 1.f);
+                const uint64_t pos = ptid + (uint64_t)(uint32_t)(kb + u * kRrcThreads) * sps40;
+                const uint32_t hi = (uint32_t)(pos >> 32), lo = (uint32_t)pos;
+                mk[u] = (int)(hi >> 8);
+                tk[u] = (float)__builtin_amdgcn_alignbit(hi, lo, 8) * 2.3283064365386963e-10f;   // top 32 fraction bits * 2^-32
+                // piecewise-linear timing estimate between sub-block centres (both estimates final: b0 + 1 <= b_known):
+                // u = (position - TB/2) / TB, b0 = floor(u) clamped, f = u - b0 clamped
+                const int t = mk[u] - kTimingBlock / 2;
+                const int b0 = max(min(t >> 8, b0_max), 0);
+                static_assert(kTimingBlock == 256, "shift");
+                ff[u] = __builtin_amdgcn_fmed3f(((float)(t - (b0 << 8)) + tk[u]) * (1.f / (float)kTimingBlock), 0.f, 1.f);
                 ta[u] = tau[b0 & (kTauRing - 1)];
                 tb2[u] = tau[min(b0 + 1, nb - 1) & (kTauRing - 1)];
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
-                const float tauk = ta[u] * (1.f - ff[u]) + tb2[u] * ff[u];
+                const float tauk = ta[u] + ff[u] * (tb2[u] - ta[u]);
                 const float ts = tk[u] + tauk * sps_f;      // t_k relative to the whole sample mk
                 const float fl = floorf(ts);
                 mu[u] = ts - fl;
@@ -487,17 +487,17 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             }
         };
         bool any_direct = false;
-        for (int k0 = k_begin + tid; k0 < k_end; k0 += kRrcThreads * SU) {
+        for (int kb = k_begin; kb < k_end; kb += kRrcThreads * SU) {
             FarrowTaps f[SU];
             int mm[SU];
             float mu[SU];
-            instants(k0, mm, mu);
+            instants(kb, mm, mu);
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 f[u].mu = mu[u];
                 // position of the symbol's first filter output in the ring's window; outside it -> direct path below
                 const int q = mm[u] - 1 - ring_lo;
-                any_direct |= (unsigned)q > (unsigned)span4 && k0 + u * kRrcThreads < k_end;
+                any_direct |= (unsigned)q > (unsigned)span4 && kb + tid + u * kRrcThreads < k_end;
                 const int p = min(max(q, 0), span4) + ring_off;                    // < 2 kRing
                 const int p0 = (int)min((unsigned)p, (unsigned)(p - kRing));       // p >= kRing ? p - kRing : p
                 const float2 *yp = yring + rrc_slot(p0);
@@ -506,20 +506,20 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 f[u].y1 = yp[2];
                 f[u].y2 = yp[3];
             }
+            float2 *so = sr + (kb - k_lo);   // (uniform base, the thread's own offset)
 #pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int k = k0 + u * kRrcThreads;
-                if (k < k_end) sr[k - k_lo] = farrow_eval(f[u]);
-            }
+            for (int u = 0; u < SU; ++u)
+                if (kb + tid + u * kRrcThreads < k_end) so[tid + u * kRrcThreads] = farrow_eval(f[u]);
         }
         if (any_direct) {
             // the timing estimate has carried some instants out of the ring (more than 48 symbols from their nominal
             // positions): their four filter outputs again from the input.  Rare, rolled, and kept apart from the loop
             // above so that its loads never order that loop's registers; the explicit wait leaves nothing pending.
-            for (int k0 = k_begin + tid; k0 < k_end; k0 += kRrcThreads * SU) {
+            for (int kb = k_begin; kb < k_end; kb += kRrcThreads * SU) {
+                const int k0 = kb + tid;
                 int mm[SU];
                 float mu[SU];
-                instants(k0, mm, mu);
+                instants(kb, mm, mu);
 #pragma unroll 1
                 for (int u = 0; u < SU; ++u) {
                     const int m = mm[u], k = k0 + u * kRrcThreads;
