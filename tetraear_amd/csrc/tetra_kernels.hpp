@@ -269,8 +269,21 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         const double ph = (double)(512 * wv + out_off) * P.inv_sps;
         sincospif(-2.f * (float)(ph - floor(ph)), &ps, &pc);
     }
-    const uint64_t sps40 = (uint64_t)(sps * 1099511627776.0);   // samples per symbol, 40 fraction bits
-    const uint64_t ptid = (uint64_t)(uint32_t)tid * sps40;       // the thread's share of its symbols' nominal positions
+    uint64_t sps40 = (uint64_t)(sps * 1099511627776.0);          // samples per symbol, 40 fraction bits
+    {
+        // into scalar registers (the builtin is folded away on a value the compiler already knows to be uniform, and the
+        // uniform products of the symbol stage would stay on the vector ALU: 64-bit multiplies at a quarter of its rate)
+        uint32_t vlo = (uint32_t)sps40, vhi = (uint32_t)(sps40 >> 32), slo, shi;
+        asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(slo), "=s"(shi) : "v"(vlo), "v"(vhi));
+        sps40 = ((uint64_t)shi << 32) | slo;
+    }
+    uint64_t ptid = (uint64_t)(uint32_t)tid * sps40;             // the thread's share of its symbols' nominal positions
+    {
+        // (opaque: otherwise the compiler folds it back into (k_uniform + tid) * sps40, a 64-bit vector multiply per symbol)
+        uint32_t plo = (uint32_t)ptid, phi = (uint32_t)(ptid >> 32);
+        asm volatile("" : "+v"(plo), "+v"(phi));
+        ptid = ((uint64_t)phi << 32) | plo;
+    }
     float tau_prev = 0.f;   // (wave 0) last unwrapped estimate
     int b_done = 0;         // sub-blocks whose estimate is final
     int k_lo = 0, k_begin = 0, ns = 0;
@@ -459,12 +472,12 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         // nominal position k sps is a 64-bit fixed-point number with 40 fraction bits (3e-8 samples at the end of the
         // longest chunk): the thread's own share is a constant, the rest of the sum is uniform -- one 64-bit add per symbol
         // where the first version converted to and from fp64.
-        auto instants = [&](int kb, int (&mm)[SU], float (&mu)[SU]) {
+        auto instants = [&](uint64_t ub, int (&mm)[SU], float (&mu)[SU]) {   // ub = kb * sps40 (uniform, scalar registers)
             float tk[SU], ta[SU], tb2[SU], ff[SU];
             int mk[SU];
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
-                const uint64_t pos = ptid + (uint64_t)(uint32_t)(kb + u * kRrcThreads) * sps40;
+                const uint64_t pos = ptid + (ub + (uint64_t)u * (sps40 * kRrcThreads));
                 const uint32_t hi = (uint32_t)(pos >> 32), lo = (uint32_t)pos;
                 mk[u] = (int)(hi >> 8);
                 tk[u] = (float)__builtin_amdgcn_alignbit(hi, lo, 8) * 2.3283064365386963e-10f;   // top 32 fraction bits * 2^-32
@@ -487,11 +500,12 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             }
         };
         bool any_direct = false;
-        for (int kb = k_begin; kb < k_end; kb += kRrcThreads * SU) {
+        uint64_t ub = (uint64_t)(uint32_t)k_begin * sps40;
+        for (int kb = k_begin; kb < k_end; kb += kRrcThreads * SU, ub += sps40 * (kRrcThreads * SU)) {
             FarrowTaps f[SU];
             int mm[SU];
             float mu[SU];
-            instants(kb, mm, mu);
+            instants(ub, mm, mu);
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 f[u].mu = mu[u];
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 const int k0 = kb + tid;
                 int mm[SU];
                 float mu[SU];
-                instants(kb, mm, mu);
+                instants((uint64_t)(uint32_t)kb * sps40, mm, mu);
 #pragma unroll 1
                 for (int u = 0; u < SU; ++u) {
                     const int m = mm[u], k = k0 + u * kRrcThreads;
