@@ -57,7 +57,9 @@ def test_gpu_find_sync_matches_reference():
 
 @pytest.mark.gpu
 def test_gpu_sync_batched_on_demodulator_output():
-    """process() -> find_sync chained: rows of hard symbols straight into the batched entry point."""
+    """process() -> find_sync chained: rows of hard symbols straight into the batched entry point.  (A plumbing test: the
+    checker is the kernel body compiled for the CPU, which test_emul_find_sync_matches_reference pins to the 300 golden
+    cases made by the reference's own find_sync; parity of the device kernel itself is test_gpu_find_sync_matches_reference.)"""
     import ctypes as C
     from tests.emul import emul
     from tetraear_amd import _lib, synth
