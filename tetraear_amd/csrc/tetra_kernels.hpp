@@ -3,8 +3,9 @@
 // There is no reference implementation of this mode: the algorithm is defined by
 // oracle/tetra_np.py (fp64 numpy) and restated here in fp32 for gfx950 as ONE kernel, k_tetra_fused:
 // a workgroup owns a carrier and walks its chunk tile by tile,
-//   HBM -> registers (next tile in flight) -> LDS (re / im planes) -> RRC matched filter on the matrix cores
-//          (v_mfma_f32_16x16x4_f32, exact fp32: a Toeplitz tile of the taps times 16 runs of the staged input)
+//   HBM -> registers (next tile in flight) -> split into bf16 halves -> LDS -> RRC matched filter on the matrix cores
+//          (v_mfma_f32_16x16x32_bf16, fp32 accumulation: a Toeplitz tile of the taps times 16 runs of the staged input;
+//          samples and taps as sums of two bf16, three products)
 //       -> square-law (Oerder-Meyr) timing statistic of the tile's sub-blocks from the accumulators
 //       -> matched-filter output into an LDS ring (never to HBM)
 //       -> timing estimates of the sub-blocks whose averaging window is complete
@@ -108,7 +109,7 @@ __device__ __forceinline__ float atan2_turns(float y, float x)
     return y < 0.f ? -r : r;
 }
 
-// waves per SIMD the register allocation aims for (LDS holds two workgroups of 512 threads = 4 wavefronts per SIMD)
+// waves per SIMD the register allocation aims for (LDS holds three workgroups of 256 threads or two of 512)
 #ifndef TDM_TETRA_WAVES
 #define TDM_TETRA_WAVES(NT) (kRrcThreads == 512 ? 4 : 3)
 #endif
