@@ -3,7 +3,7 @@ timed region of a multi-GPU run (carriers are sharded, SURVEY.md section 8(e): n
 launcher's ranks talk to librccl directly instead of importing a tensor framework.
 
 One process per GPU on ONE node.  The ncclUniqueId travels from rank 0 to the others through a file in /tmp named
-after MASTER_PORT and the launcher's run id (all ranks share the node's /tmp)."""
+after MASTER_PORT, the launcher's run id and the launcher's process id (all ranks share the node's /tmp and their parent)."""
 import contextlib
 import ctypes as C
 import os
@@ -44,7 +44,9 @@ class RcclGroup:
         self.lib.ncclGetErrorString.restype = C.c_char_p
         self.tdm = _lib.load()
         _lib.check(self.tdm.tdm_dev_sync(self.device))          # binds this process to its device (hipSetDevice)
-        tag = tag or f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}"
+        # (the launcher's pid is the same for all ranks of one launch and differs between launches: an id file left behind
+        #  by a crashed earlier run on the same port can never be taken for this run's)
+        tag = tag or f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}_{os.getppid()}"
         path = f"/tmp/tdm_rccl_{tag}_{self.world}.id"
         uid = _UniqueId()
         if self.rank == 0:
