@@ -537,7 +537,9 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 instants((uint64_t)(uint32_t)kb * sps40, mm, mu);
 #pragma unroll 1
                 for (int u = 0; u < SU; ++u) {
-                    const int m = mm[u], k = k0 + u * kRrcThreads;
+                    // (selects, not mm[u] / mu[u]: a dynamically indexed private array is promoted to LDS, 2 KB per workgroup)
+                    static_assert(SU == 2, "select");
+                    const int m = u ? mm[1] : mm[0], k = k0 + u * kRrcThreads;
                     if ((m - 1 >= ring_lo && m + 2 < ring_hi) || k >= k_end) continue;
                     float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f, a3x = 0.f, a3y = 0.f;
                     float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;   // sliding window x[idx - 3 .. idx - 1]
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                         q0 = q1; q1 = q2; q2 = q3;
                     }
                     FarrowTaps f;
-                    f.mu = mu[u];
+                    f.mu = u ? mu[1] : mu[0];
                     f.ym1 = make_float2(a0x, a0y);
                     f.y0 = make_float2(a1x, a1y);
                     f.y1 = make_float2(a2x, a2y);
