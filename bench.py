@@ -140,8 +140,10 @@ def cpu_baseline_allcore(chunk, budget_s=5.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100,
+                    help="untimed steps first: the GPU's clocks need ~40 launches (~40 ms) after idle to settle (per-launch kernel "
+                         "times under rocprofv3: 0.56 -> 0.68 -> 0.495 ms for the decimator), the timed region is the steady state")
     ap.add_argument("--carriers", type=int, default=1024, help="carriers per GPU (SURVEY 8(d) C4: 1024)")
     ap.add_argument("--chunk", type=int, default=262144, help="samples per carrier per step")
     ap.add_argument("--fmt", default="cu8", choices=["cu8", "cf32", "cf64"])
@@ -325,7 +327,7 @@ def main():
             for key, leg, c in (("single_carrier", leg_single, 1), ("tetra", leg_tetra, 4096), ("pfb", leg_pfb, 12800),
                                 ("wideband", leg_wideband, 12800)):
                 try:
-                    out[key] = leg(c, 20, 3)
+                    out[key] = leg(c, 100, 60)   # (steady state: see --warmup)
                 except Exception as e:  # noqa: BLE001
                     out[key] = {"error": str(e)}
     if rank == 0:

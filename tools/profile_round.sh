@@ -9,24 +9,24 @@ export TMPDIR=/tmp
 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
 # per-kernel time (same command, fewer steps)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py "$@" --steps 50 --warmup 5 --no-cpu-baseline --no-extra > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py "$@" --no-cpu-baseline --no-extra > $OUT/trace_bench.json 2> $OUT/trace.err
 # HBM traffic counters, separate passes (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> $OUT/pmc_write.err
 find $OUT -name "*.csv" | head -20
 # tetra-mode legs (no reference oracle): RRC stage HBM roofline, channeliser
-python bench.py --mode tetra --carriers 4096 --steps 20 --warmup 3 > $OUT/bench_tetra.json 2> $OUT/bench_tetra.err
-python bench.py --mode pfb --carriers 12800 --steps 20 --warmup 3 > $OUT/bench_pfb.json 2> $OUT/bench_pfb.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tetra -o tetra -- python bench.py --mode tetra --carriers 4096 --steps 50 --warmup 5 > /dev/null 2> $OUT/trace_tetra.err
+python bench.py --mode tetra --carriers 4096 --steps 100 --warmup 60 > $OUT/bench_tetra.json 2> $OUT/bench_tetra.err
+python bench.py --mode pfb --carriers 12800 --steps 100 --warmup 60 > $OUT/bench_pfb.json 2> $OUT/bench_pfb.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tetra -o tetra -- python bench.py --mode tetra --carriers 4096 --steps 100 --warmup 60 > /dev/null 2> $OUT/trace_tetra.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_fetch -o fetch -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tetra_write -o write -- python bench.py --mode tetra --carriers 4096 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_tetra_write.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pfb -o pfb -- python bench.py --mode pfb --carriers 12800 --steps 50 --warmup 5 > /dev/null 2> $OUT/trace_pfb.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pfb -o pfb -- python bench.py --mode pfb --carriers 12800 --steps 100 --warmup 60 > /dev/null 2> $OUT/trace_pfb.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pfb_fetch -o fetch -- python bench.py --mode pfb --carriers 12800 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_pfb_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pfb_write -o write -- python bench.py --mode pfb --carriers 12800 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_pfb_write.err
-python bench.py --carriers 1 --steps 50 --warmup 5 --no-cpu-baseline --no-extra > $OUT/bench_single.json 2> /dev/null
-python bench.py --shared --carriers 64 --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $OUT/bench_shared64.json 2> /dev/null
-TDM_FORCE_DIST=1 MASTER_PORT=29517 python bench.py --no-cpu-baseline --no-extra --steps 20 > $OUT/bench_forcedist_rccl.json 2> /dev/null
-python bench.py --no-cpu-baseline --no-extra --steps 20 --total-carriers 1024 > $OUT/bench_strong1024.json 2> /dev/null
-python bench.py --mode wideband --carriers 12800 --steps 10 --warmup 2 > $OUT/bench_wideband.json 2> /dev/null
+python bench.py --carriers 1 --no-cpu-baseline --no-extra > $OUT/bench_single.json 2> /dev/null
+python bench.py --shared --carriers 64 --no-cpu-baseline --no-extra > $OUT/bench_shared64.json 2> /dev/null
+TDM_FORCE_DIST=1 MASTER_PORT=29517 python bench.py --no-cpu-baseline --no-extra > $OUT/bench_forcedist_rccl.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-extra --total-carriers 1024 > $OUT/bench_strong1024.json 2> /dev/null
+python bench.py --mode wideband --carriers 12800 --steps 100 --warmup 60 > $OUT/bench_wideband.json 2> /dev/null
 python bench.py --carriers 256 --fmt cf64 --no-cpu-baseline --no-extra > $OUT/bench_cf64_256.json 2> /dev/null
 tail -c 300 $OUT/bench_tetra.json; echo; tail -c 200 $OUT/bench_single.json

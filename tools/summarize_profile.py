@@ -46,6 +46,27 @@ def main():
     for sub, out in (("trace", "reference"), ("trace_tetra", "tetra"), ("trace_pfb", "pfb")):
         for f in glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True):
             shutil.copy(f, os.path.join(dst, f"{tag}_{out}_kernel_stats.csv"))
+    # per-kernel launch durations in launch order (rocprofv3 --stats averages every launch of the process, the untimed
+    # warm-up ones with their clock ramp included): the same trace, split into the warm-up and the timed launches
+    for sub, out, warm in (("trace", "reference", 100), ("trace_tetra", "tetra", 60), ("trace_pfb", "pfb", 60)):
+        for f in glob.glob(os.path.join(src, sub, "**", "*kernel_trace.csv"), recursive=True):
+            per = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            rows = {}
+            for k, v in per.items():
+                d = [x[1] / 1e6 for x in sorted(v)]
+                if len(d) <= warm:
+                    continue
+                timed = d[warm:]
+                rows[k] = {"launches": len(d), "warmup_launches": warm, "warmup_avg_ms": sum(d[:warm]) / warm,
+                           "warmup_max_ms": max(d[:warm]), "timed_avg_ms": sum(timed) / len(timed),
+                           "timed_min_ms": min(timed), "timed_max_ms": max(timed), "first_10_ms": [round(x, 4) for x in d[:10]]}
+            with open(os.path.join(dst, f"{tag}_{out}_kernel_timed.json"), "w") as fo:
+                json.dump({"note": "launch durations from the rocprofv3 kernel trace of the bench command, in launch order: "
+                                   "the first `warmup_launches` are bench.py's untimed warm-up (GPU clocks ramp for ~40 "
+                                   "launches after idle), `timed_*` are the launches of the timed region",
+                           "kernels": rows}, fo, indent=1)
     prof = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py "
                        "[--mode tetra --carriers 4096 | --mode pfb --carriers 12800] --steps 2 --warmup 1",
             "note": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM "
