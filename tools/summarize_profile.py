@@ -48,7 +48,7 @@ def main():
             shutil.copy(f, os.path.join(dst, f"{tag}_{out}_kernel_stats.csv"))
     # per-kernel launch durations in launch order (rocprofv3 --stats averages every launch of the process, the untimed
     # warm-up ones with their clock ramp included): the same trace, split into the warm-up and the timed launches
-    for sub, out, warm in (("trace", "reference", 100), ("trace_tetra", "tetra", 60), ("trace_pfb", "pfb", 60)):
+    for sub, out, warm in (("trace", "reference", 150), ("trace_tetra", "tetra", 150), ("trace_pfb", "pfb", 150)):
         for f in glob.glob(os.path.join(src, sub, "**", "*kernel_trace.csv"), recursive=True):
             per = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
@@ -64,7 +64,7 @@ def main():
                            "timed_min_ms": min(timed), "timed_max_ms": max(timed), "first_10_ms": [round(x, 4) for x in d[:10]]}
             with open(os.path.join(dst, f"{tag}_{out}_kernel_timed.json"), "w") as fo:
                 json.dump({"note": "launch durations from the rocprofv3 kernel trace of the bench command, in launch order: "
-                                   "the first `warmup_launches` are bench.py's untimed warm-up (GPU clocks ramp for ~40 "
+                                   "the first `warmup_launches` are bench.py's untimed settling + warm-up passes (GPU clocks ramp for ~40 "
                                    "launches after idle), `timed_*` are the launches of the timed region",
                            "kernels": rows}, fo, indent=1)
     prof = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py "
