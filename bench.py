@@ -552,7 +552,7 @@ def leg_tetra(carriers, steps, warmup):
     out = {"metric": "Msymbols/s demodulated (TETRA mode: RRC + feed-forward timing + Farrow + quadrant slicer)",
            "value": nsym * steps / dt / 1e6, "unit": "Msym/s", "n_gpus": 1, "steps": steps,
            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32 (matched filter: split-bf16 products accumulated in fp32; soft symbols median 5e-6 / max 1e-5 of full scale from the fp64 definition)", "data": "synthetic",
+           "vs_baseline": None, "dtype": "f32 (matched filter: split-bf16 products accumulated in fp32; soft symbols median 3e-6 / max 6e-6 of full scale from the fp64 definition)", "data": "synthetic",
            "config": {"workload": f"{rows} channelised 25 kHz carriers, cf32 @72 kS/s, {n}-sample chunks", "mode": "tetra"},
            "realtime_carriers": nsym * steps / dt / 18000.0, "event_ms_per_step": ev_ms / steps,
            "stage_ms_per_launch": st,

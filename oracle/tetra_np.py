@@ -43,7 +43,25 @@ def rrc_taps(sps, alpha=ALPHA, span=SPAN):
         else:
             h[i] = (np.sin(np.pi * ti * (1 - alpha)) + 4 * alpha * ti * np.cos(np.pi * ti * (1 + alpha))) \
                 / (np.pi * ti * (1 - (4 * alpha * ti) ** 2))
-    return h / np.sqrt(np.sum(h * h))
+    return coeff16(h / np.sqrt(np.sum(h * h)))
+
+
+def _bf16(x):
+    """float32 -> nearest bfloat16 (round to nearest even), returned as float32"""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def coeff16(h):
+    """The matched filter's coefficients have 16 significant bits: each is the sum of two bfloat16 (leading part +
+    rounded remainder).  The device multiplies on the bf16 matrix cores with samples and coefficients split that way;
+    coefficients that ARE such sums leave no coefficient rounding in its products (the change to the filter is at the
+    -96 dB level)."""
+    f = np.asarray(h, dtype=np.float32)
+    hi = _bf16(f)
+    lo = _bf16(f - hi)
+    return hi.astype(np.float64) + lo.astype(np.float64)
 
 
 def matched_filter(x, h):

@@ -64,8 +64,8 @@ def test_gpu_tetra_matches_definition_and_transmitted():
             assert len(softs[r]) == info["n_sym"], (fs, r)
             np.testing.assert_array_equal(hards[r], ref_hard)
             scale = np.max(np.abs(info["sym"]))
-            # (matched filter in split-bf16 products with fp32 accumulation: measured 4e-6 ... 6e-6 of the largest symbol)
-            assert np.max(np.abs(softs[r] - info["sym"])) < 2e-5 * scale
+            # (matched filter in split-bf16 products with fp32 accumulation: at most 6.2e-6 of the largest symbol over 22 065 random carriers)
+            assert np.max(np.abs(softs[r] - info["sym"])) < 1e-5 * scale
             # differential detection at Es/N0 = 15 dB has a raw symbol error rate of order 1e-3
             assert best_ber(hards[r], dibs[r])[0] <= (0.0 if snr >= 20.0 else 3e-3)
             assert abs(timing[r] / 1000.0 - info["tau"][len(info["tau"]) // 2]) < 2e-3

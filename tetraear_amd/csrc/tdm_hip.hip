@@ -342,6 +342,19 @@ static std::vector<double> tetra_rrc_taps(double sps)
         e += v * v;
     }
     for (auto &v : h) v /= std::sqrt(e);
+    // 16-bit coefficients (oracle/tetra_np.py coeff16): each tap is the sum of two bfloat16, the way the kernel splits it
+    // for the matrix cores, so that the split leaves no coefficient rounding behind
+    auto bf16 = [](float x) {
+        uint32_t u;
+        std::memcpy(&u, &x, 4);
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+        std::memcpy(&x, &u, 4);
+        return x;
+    };
+    for (auto &v : h) {
+        const float f = (float)v, hi = bf16(f), lo = bf16(f - hi);
+        v = (double)hi + (double)lo;
+    }
     return h;
 }
 

@@ -233,9 +233,11 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // ---- matched filter on the matrix cores.  A wavefront owns 512 consecutive outputs of a tile = two timing sub-blocks
     // of 16 runs of 16:  Y[J][i] = y[16 J + i] = sum_m X[J][m] T[m][i],  X[J][m] = staged sample 16 J + m,
     // T[m][i] = h[m - i] (Toeplitz, zero outside the taps).
-    // Data and taps are split into two bf16 each, x = x1 + x2, h = h1 + h2, and the product keeps x1 h1 + x1 h2 + x2 h1
-    // (what is dropped is below 2^-16 of |x||h|: 1e-5 of a symbol, two decades under the 8-bit samples' own noise) on
-    // v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 3 x KS instructions per 16 x 16 outputs at 16x the fp32 rate.
+    // Data and taps are split into two bf16 each, x = x1 + x2, h = h1 + h2 (the taps ARE such sums: 16-bit coefficients,
+    // oracle/tetra_np.py coeff16), and all four products x2 h2 + x2 h1 + x1 h2 + x1 h1 go through
+    // v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 4 x KS instructions per 16 x 16 outputs at 16x the fp32 rate.
+    // What is left is the third chunk of a sample (2^-18 of |x|): soft symbols within 6.2e-6 of the largest symbol of the
+    // fp64 definition over 22 065 random carriers (median 3.3e-6; the fp32 chain around the filter is ~1e-6 of that).
     // (The fp32-input MFMA computes the same sums exactly but runs on the vector ALUs' own multipliers: measured, its
     // 48 instructions per wavefront and tile add their full 0.20 ms to the 0.37 ms of the rest of this kernel.)
     // Lane l supplies X[l & 15][32 s + 8 (l >> 4) .. + 7] (16 bytes per plane and step from LDS) and the constants
@@ -319,6 +321,8 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 const bf16x8 r1 = __builtin_bit_cast(bf16x8, ab[o]), r2 = __builtin_bit_cast(bf16x8, ab[PLANE / 4 + o]);
                 const bf16x8 i1 = __builtin_bit_cast(bf16x8, ab[2 * (PLANE / 4) + o]), i2 = __builtin_bit_cast(bf16x8, ab[3 * (PLANE / 4) + o]);
                 const bf16x8 h1 = __builtin_bit_cast(bf16x8, hB1[s]), h2 = __builtin_bit_cast(bf16x8, hB2[s]);
+                cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2, h2, cre[bb], 0, 0, 0);   // (smallest terms first)
+                cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i2, h2, cim[bb], 0, 0, 0);
                 cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2, h1, cre[bb], 0, 0, 0);
                 cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i2, h1, cim[bb], 0, 0, 0);
                 cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r1, h2, cre[bb], 0, 0, 0);
