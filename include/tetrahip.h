@@ -222,6 +222,11 @@ TDM_API int tdm_dev_free(int32_t device, void *ptr);
 TDM_API int tdm_dev_upload(int32_t device, void *dst_dev, const void *src_host, size_t bytes);
 TDM_API int tdm_dev_download(int32_t device, void *dst_host, const void *src_dev, size_t bytes);
 TDM_API int tdm_dev_sync(int32_t device);
+/* Measured HBM ceilings of the box ("public-spec peaks must be replaced by a measured on-box copy-kernel
+ * ceiling for the denominator"): grid-stride kernels with 16-byte accesses over two buffers of `bytes` each (use more
+ * than the 256 MiB of the last-level cache), `reps` timed launches after 3, HIP events on the current stream.
+ * gbs[0] = copy (bytes read + bytes written per second), gbs[1] = read only, gbs[2] = write only, in GB/s.        */
+TDM_API int tdm_hbm_ceiling(int32_t device, size_t bytes, int32_t reps, double *gbs);
 /* event timing on the library's own stream for a plan: elapsed milliseconds between two marks */
 TDM_API int tdm_plan_time_begin(tdm_plan *plan);
 /* the same mark without per-stage events: the launches of the timed region go out back to back exactly as they do

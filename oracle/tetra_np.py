@@ -28,8 +28,10 @@ TB = 256      # samples per timing sub-block
 TW = 2        # sub-blocks averaged on each side
 
 
-def rrc_taps(sps, alpha=ALPHA, span=SPAN):
-    """Centred RRC taps, odd length, unit energy."""
+def rrc_taps(sps, alpha=ALPHA, span=SPAN, exact=False):
+    """Centred RRC taps, odd length, unit energy.  exact=False: the 16-bit coefficients the device's plan designs
+    (coeff16 below); exact=True: the same taps in full float64, the UNQUANTISED filter the soft-symbol tolerance of
+    BASELINE.json's north_star (1e-5) is also asserted against (tests/test_tetra_precision.py)."""
     half = int(np.floor(span * sps / 2))
     t = np.arange(-half, half + 1, dtype=np.float64) / sps
     h = np.empty_like(t)
@@ -43,7 +45,8 @@ def rrc_taps(sps, alpha=ALPHA, span=SPAN):
         else:
             h[i] = (np.sin(np.pi * ti * (1 - alpha)) + 4 * alpha * ti * np.cos(np.pi * ti * (1 + alpha))) \
                 / (np.pi * ti * (1 - (4 * alpha * ti) ** 2))
-    return coeff16(h / np.sqrt(np.sum(h * h)))
+    h = h / np.sqrt(np.sum(h * h))
+    return h if exact else coeff16(h)
 
 
 def _bf16(x):
@@ -113,11 +116,12 @@ def farrow(y, t):
     return ((c3 * mu + c2) * mu + c1) * mu + c0
 
 
-def demod(x, sample_rate):
-    """Returns (hard uint8[n_sym-1], soft complex[n_sym-1] = derotated d_k, info dict)."""
+def demod(x, sample_rate, exact_taps=False):
+    """Returns (hard uint8[n_sym-1], soft complex[n_sym-1] = derotated d_k, info dict).
+    exact_taps=True runs the matched filter with the unquantised float64 RRC (see rrc_taps)."""
     x = np.asarray(x, dtype=np.complex128)
     sps = sample_rate / SYMBOL_RATE
-    h = rrc_taps(sps)
+    h = rrc_taps(sps, exact=exact_taps)
     y = matched_filter(x, h)
     n = len(y)
     tau_b = timing_estimates(y, sps)

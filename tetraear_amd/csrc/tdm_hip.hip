@@ -1015,6 +1015,108 @@ int tdm_plan_stage_times(tdm_plan *plan, int32_t max_stages, const char **names,
     return TDM_OK;
 }
 
+// ---- measured HBM ceilings (the roofline denominator is a copy-kernel figure from the box the bench
+// runs on, next to the 8 TB/s of the data sheet) ---------------------------------------------------------------------
+}  // extern "C"
+namespace {
+typedef float ceil_f4 __attribute__((ext_vector_type(4)));
+// (four 16-byte accesses in flight per lane and trip; n16 is a multiple of 4 x the grid's stride for the sizes measured,
+// the remainder loop covers any other)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_ceiling_copy(const ceil_f4 *__restrict__ a, ceil_f4 *__restrict__ b, size_t n16)
+{
+    const size_t S = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * S < n16; i += 4 * S) {
+        ceil_f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = NT ? __builtin_nontemporal_load(a + i + u * S) : a[i + u * S];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (NT) __builtin_nontemporal_store(v[u], b + i + u * S);
+            else b[i + u * S] = v[u];
+        }
+    }
+    for (; i < n16; i += S) b[i] = a[i];
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void k_ceiling_read(const ceil_f4 *__restrict__ a, float *sink, size_t n16)
+{
+    ceil_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t S = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * S < n16; i += 4 * S) {
+        ceil_f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = NT ? __builtin_nontemporal_load(a + i + u * S) : a[i + u * S];
+        acc += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (; i < n16; i += S)
+        acc += a[i];
+    const float s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 123456.789f) sink[0] = s;   // (keeps the loads; never true for the zero-filled buffer)
+}
+__global__ __launch_bounds__(256) void k_ceiling_write(ceil_f4 *__restrict__ b, size_t n16)
+{
+    const ceil_f4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) b[i] = v;
+}
+}  // namespace
+extern "C" {
+
+int tdm_hbm_ceiling(int32_t device, size_t bytes, int32_t reps, double *gbs)
+{
+    if (!gbs || reps < 1 || bytes < (1u << 20)) return fail(TDM_ERR_INVALID, "tdm_hbm_ceiling: gbs[3], reps >= 1, bytes >= 1 MiB");
+    int rc = use_device(device);
+    if (rc) return rc;
+    const size_t n16 = bytes / 16;
+    ceil_f4 *a = nullptr, *b = nullptr;
+    HIP_TRY(hipMalloc((void **)&a, n16 * 16));
+    if (hipMalloc((void **)&b, n16 * 16) != hipSuccess) {
+        (void)hipFree(a);
+        return fail(TDM_ERR_NOMEM, "tdm_hbm_ceiling: hipMalloc");
+    }
+    hipStream_t st = g_cur_stream;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipMemsetAsync(a, 0, n16 * 16, st);
+    hipMemsetAsync(b, 0, n16 * 16, st);
+    gbs[0] = gbs[1] = gbs[2] = 0.0;
+    hipError_t err = hipSuccess;
+    // grid-stride kernels, 16 bytes per lane, 8 workgroups of 256 threads per compute unit (2048) and twice that; the best of
+    // the plain / non-temporal forms and of the two grids is the ceiling of each direction
+    for (int variant = 0; variant < 4 && err == hipSuccess; ++variant) {   // plain / non-temporal x 2048 / 8192 workgroups
+        const bool nt = variant & 1;
+        const int grid = (variant & 2) ? 8192 : 2048;
+        for (int what = 0; what < 3; ++what) {
+            if (what == 2 && nt) continue;
+            auto launch = [&]() {
+                if (what == 0) { if (nt) hipLaunchKernelGGL(k_ceiling_copy<true>, dim3(grid), dim3(256), 0, st, a, b, n16); else hipLaunchKernelGGL(k_ceiling_copy<false>, dim3(grid), dim3(256), 0, st, a, b, n16); }
+                else if (what == 1) { if (nt) hipLaunchKernelGGL(k_ceiling_read<true>, dim3(grid), dim3(256), 0, st, a, (float *)b, n16); else hipLaunchKernelGGL(k_ceiling_read<false>, dim3(grid), dim3(256), 0, st, a, (float *)b, n16); }
+                else hipLaunchKernelGGL(k_ceiling_write, dim3(grid), dim3(256), 0, st, b, n16);
+            };
+            for (int i = 0; i < 3; ++i) launch();
+            hipEventRecord(e0, st);
+            for (int i = 0; i < reps; ++i) launch();
+            hipEventRecord(e1, st);
+            err = hipEventSynchronize(e1);
+            if (err != hipSuccess) break;
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double moved = (what == 0 ? 2.0 : 1.0) * (double)(n16 * 16) * reps;
+            const double rate = moved / ((double)ms * 1e-3) / 1e9;
+            if (rate > gbs[what]) gbs[what] = rate;
+        }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (err != hipSuccess) return fail(TDM_ERR_HIP, std::string("tdm_hbm_ceiling: ") + hipGetErrorString(err));
+    return TDM_OK;
+}
+
 // ---- device memory helpers --------------------------------------------------------------------
 int tdm_dev_alloc(int32_t device, size_t bytes, void **ptr)
 {

@@ -100,7 +100,7 @@ __device__ __forceinline__ float atan2_turns(float y, float x)
 {
     const float ax = fabsf(x), ay = fabsf(y);
     const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
-    const float a = hi > 0.f ? __fdividef(lo, hi) : 0.f;
+    const float a = hi > 0.f ? lo * __builtin_amdgcn_rcpf(hi) : 0.f;   // (v_rcp_f32: 1 ulp; __fdividef is a full division here)
     const float s = a * a;
     float r = a * (0.99997726f + s * (-0.33262347f + s * (0.19354346f + s * (-0.11643287f + s * (0.05265332f + s * -0.01172120f)))));
     r *= 0.15915494309189535f;
@@ -109,9 +109,9 @@ __device__ __forceinline__ float atan2_turns(float y, float x)
     return y < 0.f ? -r : r;
 }
 
-// waves per SIMD the register allocation aims for (LDS holds three workgroups of 256 threads or two of 512)
+// waves per SIMD the register allocation aims for (LDS holds four workgroups of 256 threads or two of 512)
 #ifndef TDM_TETRA_WAVES
-#define TDM_TETRA_WAVES(NT) (kRrcThreads == 512 ? 4 : 3)
+#define TDM_TETRA_WAVES(NT) 4
 #endif
 
 #ifdef TDM_TETRA_TIMING
@@ -146,20 +146,21 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                                                               int32_t *timing_milli, double *min_margin)
 {
     static_assert(kRrcPerThread == 8 && kRrcThreads % 64 == 0 && kTimingBlock == 256, "a wavefront owns two timing sub-blocks of a tile");
-    static_assert(kRing % 512 == 0 && kRing - kRrcTile - kTimingBlock * (2 * kTimingHalfWin + 1) / 2 >= kTimingBlock, "ring too short");
+    static_assert(kRing % kTimingBlock == 0 && kRing - kRrcTile - kTimingBlock * (2 * kTimingHalfWin + 1) / 2 >= kTimingBlock / 2, "ring too short");
     constexpr int PER = kRrcPerThread;
     constexpr int HALO = NT - 1, H2 = HALO / 2;
     constexpr int KS = (kRrcRun + HALO + 31) / 32;        // matrix-core steps (32 window positions each) per run of 16 outputs
     constexpr int NS = kRrcTile - kRrcRun + 32 * KS;      // samples staged per tile: base - H2 .. base - H2 + NS
     constexpr int NP = (NS / 2 + kRrcThreads - 1) / kRrcThreads;   // 16-byte sample pairs per thread
-    constexpr int PLANE = (NS / 2 + 63) / 64 * 64;        // dwords per plane of bf16 pairs
+    constexpr int PLANE = (NS / 2 + 3) / 4 * 4;           // dwords per plane of bf16 pairs (16-byte operand loads: a multiple of 4)
     static_assert(NS % 2 == 0 && kRrcThreads * (NP - 1) < NS / 2, "only the last pair of a thread can fall outside the staged window");
     // staged input, four planes of bf16: leading / trailing halves of the real parts, then of the imaginary parts; sample
     // q of a plane is half q of the plane's dwords.  (No padding: a 16-byte operand load of lane l starts at sample
     // 16 (l & 15) + 8 (l >> 4) of its block, and the lane groups the LDS serves together cover 256 distinct bytes.)
     __shared__ __attribute__((aligned(16))) uint32_t xsb[4 * PLANE];
     __shared__ float2 yring[kRing + 4];   // + the first three samples again past the end: a symbol's four never wrap
-    __shared__ float2 Cst[2 * kTileBlocks];   // the statistic of two tiles' sub-blocks
+    constexpr int kCstRing = 4 * kTileBlocks;   // the statistic of the previous and the current tile's sub-blocks, and zeros in the next tile's slots
+    __shared__ float2 Cst[kCstRing];
     __shared__ float tau[kTauRing];
     __shared__ float tau_mid_s;
     __shared__ float sm[kRrcThreads / 64];
@@ -294,6 +295,8 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
 #ifdef TDM_TETRA_TIMING
     unsigned long long tt[12] = {0}, tt_last = __builtin_readcyclecounter();
 #endif
+    static_assert(kTimingHalfWin <= kTileBlocks, "the slots below sub-block 0 must be free during the first tile");
+    if (tid < kCstRing) Cst[tid] = make_float2(0.f, 0.f);   // (made visible by the first barrier of the loop)
     fetch(0);
     stage(0);
     if (ntiles > 1) fetch(1);
@@ -382,44 +385,59 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 const unsigned r0 = r[0], r1 = r[1];
                 z = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
             }
+            // (sub-blocks past the end of the chunk, in this tile and in the next one's slots, are stored as zero: the
+            // averaging window below reads its +-TW neighbours without masks)
             const int b = i * kTileBlocks + 2 * wv + (lane & 1);
-            if (lane < 4 && b < nb) ((float *)Cst)[2 * (b & (2 * kTileBlocks - 1)) + (lane >> 1)] = z;
+            if (lane < 4) ((float *)Cst)[2 * (b & (kCstRing - 1)) + (lane >> 1)] = b < nb ? z : 0.f;
+            if (last && lane < 4) ((float *)Cst)[2 * ((b + kTileBlocks) & (kCstRing - 1)) + (lane >> 1)] = 0.f;
         }
         TT_MARK(3)
-        // ---- matched-filter output into the ring (a wavefront's 512 outputs never straddle its end)
-        {
-            const int pw = (base + 512 * wv) % kRing;
+        // ---- matched-filter output into the ring (the ring is a whole number of sub-blocks: a sub-block's 256 outputs
+        // never straddle its end)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int pw = (base + 512 * wv + 256 * bb) % kRing;
             float2 *yw = yring + rrc_slot(pw) + ring_lane;
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) yw[rrc_slot(256 * bb + 16 * r)] = make_float2(cre[bb][r], cim[bb][r]);
-            if (pw == 0 && lane < 3) yring[rrc_slot(kRing) + lane] = make_float2(cre[0][0], cim[0][0]);   // (kRing is a multiple of 8)
+            for (int r = 0; r < 4; ++r) yw[rrc_slot(16 * r)] = make_float2(cre[bb][r], cim[bb][r]);
+            if (pw == 0 && lane < 3) yring[rrc_slot(kRing) + lane] = make_float2(cre[bb][0], cim[bb][0]);
         }
         TT_MARK(4)
         __syncthreads();   // ring, statistic visible; staging buffer free
         TT_MARK(5)
+        // ---- timing estimates that are final now: vector average over +-TW sub-blocks, argument, unwrap.  ONE wavefront
+        // computes them (the duty rotates with the tile, so that over a carrier every SIMD of the compute unit does a
+        // quarter of this work) while the other three stage the next tile; a third barrier hands the estimates over.
+        // (Round 2 had every wavefront compute them, identically: no barrier, but ~75 vector instructions per wavefront and
+        // tile, an eighth of the loop, spent three times over.)
+#ifndef TDM_TETRA_EST_ALL
+        const bool est_duty = wv == (i & (kRrcThreads / 64 - 1));
+#else
+        const bool est_duty = true;
+#endif
+        const int b_known = last ? nb - 1 : (i + 1) * kTileBlocks - 1 - kTimingHalfWin;
+#ifndef TDM_TETRA_EST_ALL
+        if (!est_duty && !last) {
+#else
         if (!last) {
+#endif
             stage(i + 1);
             if (i + 2 < ntiles) fetch(i + 2);
         }
         TT_MARK(6)
-        // ---- timing estimates that are final now: vector average over +-TW sub-blocks, argument, unwrap
-        const int b_known = last ? nb - 1 : (i + 1) * kTileBlocks - 1 - kTimingHalfWin;
-        // (every wavefront computes them, identically, in its first lanes: cheaper than a barrier around one that does)
-        {
+        if (est_duty) {
+#ifndef TDM_TETRA_EST_ALL
+            if (b_done > 0) tau_prev = tau[(b_done - 1) & (kTauRing - 1)];   // (the last estimate of the previous duty wavefront)
+#endif
             const int lane = tid & 63;
             const int cnt = b_known - b_done + 1;   // <= kTileBlocks + kTimingHalfWin
             const int b = b_done + lane;
             float cr = 0.f, ci = 0.f;
-            const int lo = max(0, b - kTimingHalfWin), hi = min(nb - 1, b + kTimingHalfWin);
 #pragma unroll
-            for (int e = 0; e < 2 * kTimingHalfWin + 1; ++e) {   // loaded unconditionally (one LDS round trip), masked
-                const int j = b - kTimingHalfWin + e;
-                const float2 c = Cst[j & (2 * kTileBlocks - 1)];
-                const bool ok = j >= lo && j <= hi;
-                cr += ok ? c.x : 0.f;
-                ci += ok ? c.y : 0.f;
+            for (int e = 0; e < 2 * kTimingHalfWin + 1; ++e) {   // (slots outside [0, nb) hold zeros)
+                const float2 c = Cst[(b - kTimingHalfWin + e) & (kCstRing - 1)];
+                cr += c.x;
+                ci += c.y;
             }
             float tb = -atan2_turns(ci, cr);
             // a non-finite input sample makes the statistic NaN: such a carrier demodulates garbage, but it must
@@ -442,6 +460,13 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             }
         }
         b_done = b_known + 1;
+#ifndef TDM_TETRA_EST_ALL
+        __syncthreads();   // estimates visible
+        if (est_duty && !last) {
+            stage(i + 1);
+            if (i + 2 < ntiles) fetch(i + 2);
+        }
+#endif
         TT_MARK(7)
         TT_MARK(8)
         // ---- symbols whose two timing estimates are final: t_k = (k + tau(k sps)) sps, in [1, n-3]
@@ -674,7 +699,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             w[u >> 2] |= h << (8 * (u & 3));
             const float ax = fabsf(dd.x), ay = fabsf(dd.y);
             const float lo = fminf(ax, ay), hi = fmaxf(ax, ay);
-            const float ratio = hi > 0.f ? __fdividef(lo, hi) : 0.f;
+            const float ratio = hi > 0.f ? lo * __builtin_amdgcn_rcpf(hi) : 0.f;
             if (!TAIL || (i0 + u < ns && i0 + u >= 1)) mratio = fminf(mratio, ratio);
         }
         if (!TAIL && i0 > 0) {

@@ -23,10 +23,12 @@ constexpr int kMaxTimingBlocks = 512;
 constexpr int kTileBlocks = kRrcTile / kTimingBlock;      // sub-blocks per tile
 // Matched-filter outputs kept in LDS: after tile i the ring holds samples [T(i+1) - kRing, T(i+1)), T = kRrcTile.  Round
 // i emits the symbols whose nominal position lies in [T i - 640, T(i+1) - 640) (640 = 2.5 sub-blocks: their two timing
-// estimates are final then), so the ring covers them with kRing - T - 640 samples to spare below and 640 above: that
-// is how far the unwrapped timing estimate may carry a symbol instant from its nominal position (48 symbols at 8
-// samples/symbol) before the symbol takes the direct path (its four filter outputs recomputed from the input).
-constexpr int kRing = kRrcTile + 1024;
+// estimates are final then), so the ring covers them with kRing - T - 640 = 128 samples to spare below and 640 above:
+// that is how far the unwrapped timing estimate may carry a symbol instant from its nominal position (16 symbols
+// behind / 80 ahead at 8 samples/symbol) before the symbol takes the direct path (its four filter outputs recomputed
+// from the input).  Round 3: 1024 -> 768 extra samples, which with the unpadded staging planes brings a workgroup
+// under 40 KB of LDS: four workgroups per compute unit, and 4096 carriers are exactly four dispatch rounds.
+constexpr int kRing = kRrcTile + 768;
 constexpr int kTauRing = 32;                              // timing estimates kept (a round reads at most kTileBlocks + 2 of them)
 
 struct TetraParams {

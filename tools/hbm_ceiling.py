@@ -1,14 +1,25 @@
-"""Measured HBM ceilings on the box (torch used only as a quick way to launch fill/copy kernels)."""
-import torch, time
-n = 1 << 30
-a = torch.empty(n, dtype=torch.uint8, device="cuda"); b = torch.empty(n, dtype=torch.uint8, device="cuda")
-def t(f, reps=20):
-    for _ in range(3): f()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps): f()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
-af = a.view(torch.float32)
-print("fill  (write only) GB/s:", n / t(lambda: af.fill_(1.0)) / 1e9)
-print("zero  (memset)     GB/s:", n / t(lambda: a.zero_()) / 1e9)
-print("copy  (r+w)        GB/s:", 2 * n / t(lambda: b.copy_(a)) / 1e9)
-print("sum   (read only)  GB/s:", n / t(lambda: af.sum()) / 1e9)
+#!/usr/bin/env python3
+"""Measured HBM ceilings of the box through the library's own copy / read / write kernels (tdm_hbm_ceiling; no tensor
+framework).  usage: tools/hbm_ceiling.py [out.json]"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tetraear_amd import _lib  # noqa: E402
+
+L = _lib.load()
+out = {}
+for gib in (1, 2):
+    g = (C.c_double * 3)()
+    _lib.check(L.tdm_hbm_ceiling(0, gib << 30, 20, g))
+    out[f"{gib}GiB"] = {"copy_GBps": g[0], "read_GBps": g[1], "write_GBps": g[2]}
+res = {"what": "tdm_hbm_ceiling: grid-stride kernels, 16 B per lane, plain and non-temporal forms, 2048 and 4096 workgroups of 256; "
+               "best of each; 20 timed launches after 3; copy counts bytes read + bytes written",
+       "buffers": out, "spec_GBps": 8000.0,
+       "ceiling_GBps": max(v["copy_GBps"] for v in out.values())}
+print(json.dumps(res))
+if len(sys.argv) > 1:
+    with open(sys.argv[1], "w") as f:
+        json.dump(res, f, indent=1)
