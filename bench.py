@@ -32,6 +32,130 @@ FLOP_PER_INPUT_SAMPLE = 150.0
 # what the parallel-form kernel executes on cu8 input: 5080 fp64 FMAs per lane of 120 input samples (recurrences 3840,
 # two-tap outputs 384, start-state responses 384, lane scans 448, direct term 24), 2 flop each
 EXECUTED_FLOP_PER_INPUT_SAMPLE = 5080 * 2 / 120.0
+# the part of those no implementation of the filter can avoid: the recurrences themselves, 3840 FMAs per 120 samples
+IRREDUCIBLE_FLOP_PER_INPUT_SAMPLE = 3840 * 2 / 120.0
+
+_CEILING = None
+
+
+def hbm_ceiling(device=0):
+    """Measured HBM ceilings of THIS box (the roofline denominator is an on-box copy-kernel figure): the
+    library's own copy / read / write kernels over 2 x 1 GiB, once per bench process (~0.3 s)."""
+    global _CEILING
+    if _CEILING is None:
+        import ctypes as C
+        from tetraear_amd import _lib
+        g = (C.c_double * 3)()
+        try:
+            _lib.check(_lib.load().tdm_hbm_ceiling(device, 1 << 30, 10, g))
+            _CEILING = {"copy": g[0], "read": g[1], "write": g[2], "unit": "GB/s",
+                        "how": "tdm_hbm_ceiling: 16 B per lane over 1 GiB buffers, best of the flat form (one access per lane, one workgroup per 4 KB) and grid-stride forms (plain / non-temporal, 2048 / 8192 workgroups), 10 launches after 3, HIP events"}
+        except Exception as e:  # noqa: BLE001
+            _CEILING = {"error": str(e)}
+    return _CEILING
+
+
+def hbm_roofline(kernel, bytes_alg, ms, read_bytes=None, traffic=None, traffic_src=None, device=0, **extra):
+    """roofline object of an HBM-bound kernel: algorithmic bytes over the measured launch time against the data-sheet
+    peak (`frac`) and against the box's measured ceilings (`frac_of_measured`: the copy figure; `frac_of_mix`: the time
+    the same read / write split would take at the measured read-only and write-only rates)."""
+    ach = bytes_alg / (ms * 1e-3) / 1e9
+    out = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+           "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": ms}
+    if traffic_src:
+        out["traffic_source"] = traffic_src
+    c = hbm_ceiling(device)
+    if "copy" in c:
+        out["peak_measured"] = c["copy"]
+        out["frac_of_measured"] = ach / c["copy"]
+        if read_bytes is not None:
+            t_mix = read_bytes / c["read"] + (bytes_alg - read_bytes) / c["write"]   # (GB/s -> bytes / 1e9 per second)
+            out["peak_measured_mix"] = bytes_alg / t_mix
+            out["frac_of_mix"] = ach / (bytes_alg / t_mix)
+    out.update(extra)
+    return out
+
+
+class TorchGroup:
+    """barrier / max / sum on torch.distributed: the fallback of the multi-GPU bench when librccl cannot be used through
+    ctypes on every rank, and the group of the gloo test (tests/test_dist_cpu.py).  Lives here, not in the package: the
+    product path imports no tensor framework."""
+
+    def __init__(self, dist, device=None):
+        self.dist, self.device = dist, device
+
+    def _reduce(self, value, dtype, op):
+        import torch
+        t = torch.tensor([value], dtype=dtype, device=self.device)
+        self.dist.all_reduce(t, op=op)
+        return t.item()
+
+    def max_f64(self, x):
+        import torch
+        return float(self._reduce(float(x), torch.float64, self.dist.ReduceOp.MAX))
+
+    def sum_i64(self, x):
+        import torch
+        return int(self._reduce(int(x), torch.int64, self.dist.ReduceOp.SUM))
+
+    def barrier(self):
+        self.dist.barrier()
+        if self.device is not None:
+            import torch
+            torch.cuda.synchronize()
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def load_checks():
+    """Definition-pinned expectations of the north-star legs (tests/golden/bench_checks.npz, written on the CPU by
+    tests/golden/make_bench_checks.py from the fp64 definitions of oracle/): data only, the bench never imports oracle/
+    outside its cpu_baseline leg."""
+    path = os.path.join(HERE, "tests", "golden", "bench_checks.npz")
+    try:
+        return np.load(path, allow_pickle=False)
+    except OSError:
+        return None
+
+
+def rows_digest(hard, n_soft, rows):
+    import hashlib
+    h = hashlib.sha256()
+    for r in rows:
+        ns = int(n_soft[r])
+        h.update(np.int32(ns).tobytes())
+        h.update(np.ascontiguousarray(hard[r, :max(ns - 1, 0)]).tobytes())
+    return h.hexdigest()
+
+
+# ---- workloads of the north-star legs (shared with tests/golden/make_bench_checks.py) ---------------------------------
+TETRA_FS, TETRA_N, TETRA_DISTINCT = 72000.0, 32768, 8
+PFB_M, PFB_D, PFB_NIN, PFB_FS = 400, 125, 1048576, 10e6
+WIDEBAND_CHANNELS = (0, 1, 57, 133, 199, 201, 310, 398, 399)   # band edges, both sides of DC, neighbours
+
+
+def tetra_rows():
+    """the 8 distinct channelised carriers of the tetra leg: cf32 at 72 kS/s (4 samples/symbol), own symbol seed and
+    timing offset each, noise at 20 dB"""
+    from tetraear_amd import synth
+    base = [synth.dqpsk_baseband(TETRA_N, TETRA_FS, 700 + i, timing_offset=0.07 * i)[0].astype(np.complex64) for i in range(TETRA_DISTINCT)]
+    rng = np.random.default_rng(5)
+    return [b + (0.07 * (rng.standard_normal(TETRA_N) + 1j * rng.standard_normal(TETRA_N))).astype(np.complex64) for b in base]
+
+
+def pfb_stream():
+    """the channeliser leg's 10 MS/s cu8 stream (uniform random bytes: full-scale wideband noise)"""
+    from tetraear_amd import synth
+    return synth.noise_cu8(PFB_NIN, 1)
+
+
+def wideband_stream():
+    """BASELINE config 5's stream for the end-to-end leg: 10 MS/s, 1 Mi samples, pi/4-DQPSK carriers on nine channels of
+    the 25 kHz grid at 25 dB, cu8.  Returns (u8, {channel: dibits})."""
+    from tetraear_amd import synth
+    x, dibs = synth.grid_carriers(PFB_NIN, PFB_FS, WIDEBAND_CHANNELS, PFB_M, seed0=300, snr_db=25.0)
+    return synth.quantise_cu8(x, scale=1.0 / (4.0 * np.sqrt(len(WIDEBAND_CHANNELS) + 1.0))), dibs
 
 
 def make_batch(carriers, chunk, fmt, rank):
@@ -50,6 +174,11 @@ def make_batch(carriers, chunk, fmt, rank):
     if fmt == "cf64":
         return x, foffs
     raise ValueError(fmt)
+
+
+def shared_offsets(carriers):
+    """--shared: the carriers' input-rate shifts, a 25 kHz grid centred on the stream (squeezed when more than 64 share it)"""
+    return (np.arange(carriers) - (carriers - 1) / 2.0) * 25000.0 * (64.0 / max(carriers, 64))
 
 
 def output_digest(hard, n_soft, best_phase):
@@ -173,22 +302,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     group, collective = None, "none (single process)"
     if world > 1 or os.environ.get("TDM_FORCE_DIST") == "1":   # the env switch lets a 1-GPU box exercise this path
-        # barrier + two 8-byte all-reduces: librccl through ctypes (no tensor framework in the product path); if that
-        # binding cannot initialise, torch.distributed's "nccl" backend (the same RCCL) does the same three operations
+        # barrier + three 8-byte all-reduces: librccl through ctypes (no tensor framework in the product path).  The choice
+        # of backend is COLLECTIVE: RcclGroup's bring-up ends with the same decision on every rank (tetraear_amd/rccl.py), so
+        # either all ranks run on librccl or all of them take torch.distributed's "nccl" backend (the same RCCL); any other
+        # failure is fatal for the job instead of being papered over on one rank.
+        from tetraear_amd.rccl import RcclGroup, RcclUnavailable
         try:
-            if os.environ.get("TDM_DIST_BACKEND", "rccl") != "rccl":
-                raise RuntimeError("torch.distributed requested")
-            from tetraear_amd.rccl import RcclGroup
+            if os.environ.get("TDM_DIST_BACKEND", "rccl") != "rccl":   # (an environment switch is the same on every rank)
+                raise RcclUnavailable("torch.distributed requested")
             group = RcclGroup(rank, world, local_rank)
-            collective = "librccl via ctypes (ncclAllReduce x2 + barrier)"
-        except Exception as e:  # noqa: BLE001
+            collective = "librccl via ctypes (ncclAllReduce x3 + barrier)"
+        except RcclUnavailable as e:
             import torch
             import torch.distributed as dist
-            from tetraear_amd.shard import TorchGroup
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             group = TorchGroup(dist, "cuda")
-            collective = f"torch.distributed nccl (ctypes binding unavailable: {e})"
+            collective = f"torch.distributed nccl (librccl through ctypes not usable on every rank: {e})"
 
     from tetraear_amd.batch import BatchDemodulator
     from tetraear_amd.shard import carrier_range, reduce_job
@@ -206,7 +336,7 @@ def main():
     if args.shared:
         iq, foffs = make_batch(1, args.chunk, args.fmt, rank)
         foffs = np.zeros(carriers)
-        pre = (np.arange(carriers) - (carriers - 1) / 2.0) * 25000.0 * (64.0 / max(carriers, 64))
+        pre = shared_offsets(carriers)
         bd.upload(iq, freq_offsets=None, pre_shifts=pre)
     elif strong:
         iq, foffs = make_batch(args.total_carriers, args.chunk, args.fmt, 0)
@@ -259,13 +389,22 @@ def main():
     # the output of the last timed step is checked, not just counted: its digest must equal the one pinned to the oracle
     dkey = digest_key(carriers, args.chunk, args.fmt, args.rate, rank, args.shared) + (f":strong{lo}-{hi}of{args.total_carriers}" if strong and world > 1 else "")
     digest, want = output_digest(hard, n_soft, bp), expected_digest(dkey)
-    if want is not None and digest != want and not args.zero_foff:
-        raise SystemExit(f"bench: output digest {digest} differs from the oracle-pinned {want} for {dkey}")
+    mismatch = want is not None and digest != want and not args.zero_foff
     output_check = {"key": dkey, "sha256": digest,
                     "status": "matches oracle-pinned digest" if want == digest else
-                              ("no pinned digest for this workload" if want is None else "not compared")}
+                              ("no pinned digest for this workload" if want is None else
+                               ("DIFFERS from the oracle-pinned digest" if mismatch else "not compared"))}
 
-    dt, total_sym_per_step = reduce_job(group, dt, sym_per_step)
+    # (a rank whose check failed still takes part in the reductions: the failure count is reduced with the job and ALL
+    # ranks stop together below; leaving early would strand the others inside ncclAllReduce)
+    dt, total_sym_per_step, n_bad = reduce_job(group, dt, sym_per_step, 1 if mismatch else 0)
+    if n_bad:
+        if mismatch:
+            print(f"bench: rank {rank}: output digest {digest} differs from the oracle-pinned {want} for {dkey}", file=sys.stderr)
+        bd.close()
+        if group is not None:
+            group.close()
+        raise SystemExit(f"bench: the output check failed on {n_bad} rank(s)")
 
     if rank == 0:
         value = total_sym_per_step * args.steps / dt / 1e6
@@ -275,8 +414,13 @@ def main():
         in_bytes = {"cu8": 2, "cf32": 8, "cf64": 16}[args.fmt]
         n_dec = bd.info.n_dec
         k1_bytes = samples_per_launch * in_bytes + carriers * n_dec * 16
-        achieved_tf = samples_per_launch * FLOP_PER_INPUT_SAMPLE / (k1_ms * 1e-3) / 1e12
-        executed_tf = samples_per_launch * EXECUTED_FLOP_PER_INPUT_SAMPLE / (k1_ms * 1e-3) / 1e12
+        contract_tf = samples_per_launch * FLOP_PER_INPUT_SAMPLE / (k1_ms * 1e-3) / 1e12
+        # executed flops: exact for the raw-byte kernel (dec_engine 3, the bench's case); the double-based kernel executes
+        # 52.5 FMAs per sample and the cascade engine 133 issue slots: other engines report the same field from their counts
+        exec_flop = {3: EXECUTED_FLOP_PER_INPUT_SAMPLE, 2: 105.0, 1: 266.0}.get(bd.info.dec_engine, EXECUTED_FLOP_PER_INPUT_SAMPLE)
+        executed_tf = samples_per_launch * exec_flop / (k1_ms * 1e-3) / 1e12
+        irreducible_tf = samples_per_launch * IRREDUCIBLE_FLOP_PER_INPUT_SAMPLE / (k1_ms * 1e-3) / 1e12
+        ceil = hbm_ceiling(local_rank) if world == 1 else {}
         traffic, traffic_src = measured_traffic(samples_per_launch, args.fmt)
         total = args.total_carriers if strong else carriers * world
         out = {
@@ -314,25 +458,32 @@ def main():
                            "k_pz_block (the same decimator with the samples held as doubles: few carriers, or a wire format other than cu8)"
                            if bd.info.dec_engine == 2 else "k_zp_block (cascade engine)"),
                 "bound": "valu_fp64",
-                "achieved": achieved_tf,
+                # frac = what the fp64 vector ALUs execute over their peak (never > 1); round 2 reported SURVEY 8(d)'s
+                # operation count over the measured time here, which the parallel form undercuts (1.02 "of peak")
+                "achieved": executed_tf,
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved_tf / PEAK_FP64_TFLOPS,
+                "frac": executed_tf / PEAK_FP64_TFLOPS,
+                "flop_per_input_sample": exec_flop,
+                "avg_launch_ms": k1_ms,
+                "irreducible": {"flop_per_input_sample": IRREDUCIBLE_FLOP_PER_INPUT_SAMPLE, "achieved": irreducible_tf,
+                                "frac": irreducible_tf / PEAK_FP64_TFLOPS,
+                                "note": "the recurrences alone (2 FMAs per real sample, pole pair and direction): what no form of this filter avoids"},
+                "contract_survey_8d": {"flop_per_input_sample": FLOP_PER_INPUT_SAMPLE, "algorithmic_flop_per_launch": samples_per_launch * FLOP_PER_INPUT_SAMPLE,
+                                       "rate": contract_tf, "rate_over_peak": contract_tf / PEAK_FP64_TFLOPS,
+                                       "note": "SURVEY 8(d) prices the cascade (150 flop/sample); the parallel form executes 84.7, so this "
+                                               "rate can exceed the ALU peak and is NOT a fraction of anything the kernel does"},
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "algorithmic_flop_per_launch": samples_per_launch * FLOP_PER_INPUT_SAMPLE,
-                "avg_launch_ms": k1_ms,
-                "executed": {"flop_per_input_sample": EXECUTED_FLOP_PER_INPUT_SAMPLE, "achieved": executed_tf,
-                             "frac": executed_tf / PEAK_FP64_TFLOPS,
-                             "note": "the parallel form needs fewer operations than the cascade SURVEY 8(d) prices (150 flop/sample): "
-                                     "5080 fp64 FMAs per lane of 120 samples; `achieved` above is the contract's algorithmic figure "
-                                     "over the measured time, this is what the ALUs actually execute"},
                 "hbm": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                        "peak_measured": ceil.get("copy"),
+                        "frac_of_measured": (k1_bytes / (k1_ms * 1e-3) / 1e9 / ceil["copy"]) if "copy" in ceil else None,
                         "algorithmic_bytes_per_launch": k1_bytes},
-                "note": "no MFMA on this path; the kernel is fp64-vector-ALU bound, "
-                        "peak = MI355X fp64 vector FMA rate; the HBM view of the same launch is under 'hbm'",
+                "note": "no MFMA on this path; the kernel is fp64-vector-ALU bound (78.6 TFLOP/s = 16 fp64 FMA lanes per SIMD and "
+                        "clock); the HBM view of the same launch is under 'hbm'",
             },
+            "hbm_ceiling_measured": ceil or None,
         }
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.chunk)
@@ -427,48 +578,60 @@ def main_stream(args):
 def leg_pfb(carriers, steps, warmup):
     """Channeliser leg (BASELINE config 5): 10 MS/s cu8 -> 400 x 25 kHz channels at 80 kS/s (D = 125),
     1 048 576-sample chunks.  Algorithmic bytes: n_in*2 in + 400*n_out*8 out (SURVEY 8(d) 'PFB stage').
-    Timed with HIP events on the stream the kernel runs on (a plan's stream made current)."""
+    Timed with HIP events on the stream the kernel runs on (a plan's stream made current); the output of the last step is
+    compared with the fp64 definition's values at the pinned probe points."""
     import ctypes as C
-    from tetraear_amd import _lib, synth
+    from tetraear_amd import _lib
     from tetraear_amd._lib import MODE_TETRA
     from tetraear_amd.batch import BatchDemodulator, DeviceBuffer
     L = _lib.load()
-    M, D, n_in = 400, 125, int(os.environ.get("TDM_BENCH_PFB_NIN", 1048576))
+    M, D, n_in = PFB_M, PFB_D, int(os.environ.get("TDM_BENCH_PFB_NIN", PFB_NIN))
     n_out = (n_in + D - 1) // D
     streams = max(1, carriers // 400)
-    u8 = synth.noise_cu8(n_in, 1)
+    u8 = pfb_stream()[:2 * n_in]
     din = DeviceBuffer(0, streams * n_in * 2)
     pitch = (n_out + 15) // 16 * 16   # 128-byte aligned channel rows
     dout = DeviceBuffer(0, streams * M * pitch * 8)
-    din.upload(np.concatenate([np.roll(u8, 2 * 977 * i) for i in range(streams)]))
+    din.upload(np.concatenate([np.roll(u8, 2 * 977 * i) for i in range(streams)]))   # (stream 0 is the pinned one)
     no = C.c_int64()
     clock = BatchDemodulator(80000.0, 4096, 1, "cf32", mode=MODE_TETRA)   # (only its stream and event pair are used)
     clock.make_stream_current()
-
-    def step():
-        # one launch for all streams (grid.y = stream)
-        _lib.check(L.tdm_channelise_batch(din.ptr, 0, n_in, streams, M, D, dout.ptr, pitch, C.byref(no), 1, 0))
-    for _ in range(max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
-        step()
-    clock.sync()
-    clock.time_begin()
-    for _ in range(steps):
-        step()
-    ms = clock.time_end() / steps
-    clock.release_stream()
-    clock.close()
+    try:
+        def step():
+            # one launch for all streams (grid.y = stream)
+            _lib.check(L.tdm_channelise_batch(din.ptr, 0, n_in, streams, M, D, dout.ptr, pitch, C.byref(no), 1, 0))
+        for _ in range(max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
+            step()
+        clock.sync()
+        clock.time_begin()
+        for _ in range(steps):
+            step()
+        ms = clock.time_end() / steps
+    finally:
+        clock.release_stream()
+        clock.close()
+    check = {"status": "no pinned probes for this workload"}
+    chk = load_checks()
+    if chk is not None and n_in == PFB_NIN and "pfb_channels" in chk.files:
+        y0 = dout.download(np.complex64, M * pitch).reshape(M, pitch)   # stream 0
+        ref, chans, stride = chk["pfb_ref"], chk["pfb_channels"], int(chk["pfb_time_stride"])
+        scale = float(chk["pfb_scale"])
+        err = max(float(np.max(np.abs(y0[int(k), 0:n_out:stride] - ref[i]))) for i, k in enumerate(chans)) / scale
+        check = {"against": "oracle/pfb_np.py (fp64 definition), pinned by tests/golden/make_bench_checks.py",
+                 "probes": int(ref.size), "channels": [int(k) for k in chans], "max_err_rel": err, "tolerance": 2e-5,
+                 "status": "matches the definition at the pinned probes" if err < 2e-5 else "DIFFERS from the definition"}
     din.free()
     dout.free()
     bytes_alg = streams * (n_in * 2 + M * n_out * 8)
+    traffic, traffic_src = measured_traffic(streams * n_in, "tetra-cf32", key="pfb")
     return {"metric": "channeliser throughput (tetra mode, polyphase DFT filter bank)", "value": streams * n_in / (ms * 1e-3) / 1e6,
             "unit": "Msamples/s in", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": ms,
             "higher_is_better": True, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{streams} x (10 MS/s cu8, {n_in} samples -> 400 channels x {n_out} cf32 @80 kS/s)"},
             "realtime_10MSps_streams": streams * n_in / (ms * 1e-3) / 10e6,
-            "roofline": {"kernel": "k_pfb_fft<20,20,3,32>", "bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9,
-                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": ms,
-                         "timing": "HIP events on the kernel's stream, one kernel per step"}}
+            "output_check": check,
+            "roofline": hbm_roofline("k_pfb_fft<20,20,3,32>", bytes_alg, ms, read_bytes=streams * n_in * 2, traffic=traffic,
+                                     traffic_src=traffic_src, timing="HIP events on the kernel's stream, one kernel per step")}
 
 
 def main_pfb(args):
@@ -478,16 +641,15 @@ def main_pfb(args):
 def leg_wideband(carriers, steps, warmup):
     """BASELINE config 5 end to end on the device: `streams` x (10 MS/s cu8, 1 048 576 samples) -> polyphase
     channeliser (400 x 80 kS/s, row pitch 8400) -> TETRA-mode demodulation of every channel (RRC, timing,
-    Farrow, slicer), all on one stream without host synchronisation.  No reference oracle for this mode."""
+    Farrow, slicer), all on one stream without host synchronisation.  The stream carries nine pi/4-DQPSK carriers on the
+    25 kHz grid (every stream of the batch is a copy of it); the hard decisions of the occupied channels are compared with
+    the digest of the fp64 definition chain (oracle/pfb_np.py -> oracle/tetra_np.py), every stream against stream 0."""
     from tetraear_amd.wideband import WidebandReceiver
-    M, D, n_in, fs = 400, 125, 1048576, 10e6
+    M, D, n_in, fs = PFB_M, PFB_D, PFB_NIN, PFB_FS
     streams = max(1, carriers // 400)
-    # 400 pi/4-DQPSK carriers on the 25 kHz grid would take minutes to synthesise on the host: wideband noise
-    # exercises the same arithmetic (decisions are data-independent work); correctness is tests/test_tetra_mode.py
-    rng = np.random.default_rng(3)
-    u8 = rng.integers(0, 256, size=2 * n_in, dtype=np.uint8)
+    u8, _ = wideband_stream()
     rx = WidebandReceiver(fs, n_in, M, D, streams=streams, fmt="cu8")
-    rx.d_in.upload(np.concatenate([np.roll(u8, 2 * 977 * i) for i in range(streams)]))
+    rx.d_in.upload(np.tile(u8, streams))
     bd = rx.demod
     for _ in range(max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
         rx.enqueue()
@@ -499,13 +661,23 @@ def leg_wideband(carriers, steps, warmup):
     st = bd.stage_times()
     hard, soft, n_soft, bp, mm = bd.download()
     nsym = int(np.maximum(n_soft - 1, 0).sum())
+    occupied = [int(k) for k in WIDEBAND_CHANNELS]
+    digest = rows_digest(hard, n_soft, occupied)
+    same = all(rows_digest(hard, n_soft, [sidx * M + k for k in occupied]) == digest for sidx in range(1, streams))
+    chk = load_checks()
+    want = str(chk["wideband_digest"]) if chk is not None and "wideband_digest" in chk.files else None
+    check = {"against": "oracle/pfb_np.py -> oracle/tetra_np.py (fp64 definitions) on the nine occupied channels, pinned by tests/golden/make_bench_checks.py",
+             "sha256": digest, "streams_identical": bool(same),
+             "status": ("matches the definition-pinned digest" if want == digest and same else
+                        ("no pinned digest for this workload" if want is None else "DIFFERS from the definition-pinned digest"))}
     rx.close()
     return {"metric": "Msymbols/s demodulated from wideband IQ (tetra mode: channeliser + per-channel demod)",
             "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
             "ms_per_step": ms, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{streams} x (10 MS/s cu8, {n_in} samples) -> {streams * M} channels x {rx.n_out} cf32 -> symbols"},
+            "config": {"workload": f"{streams} x (10 MS/s cu8, {n_in} samples, 9 pi/4-DQPSK carriers on the 25 kHz grid) -> {streams * M} channels x {rx.n_out} cf32 -> symbols"},
             "realtime_10MSps_streams": streams * n_in / (ms * 1e-3) / fs,
             "realtime_carriers_18ksym": nsym / (ms * 1e-3) / 18000.0,
+            "output_check": check,
             "stage_ms_per_launch": st, "timing": "HIP events on the one stream all kernels run on", "vs_baseline": None}
 
 
@@ -521,18 +693,16 @@ def leg_tetra(carriers, steps, warmup):
     """TETRA-mode leg (no reference oracle; SURVEY 8(d) 'tetra mode'): `carriers` channelised carriers,
     cf32 at 72 kS/s (4 samples/symbol), chunks of 32768 samples.  ONE kernel (matched filter -> timing ->
     Farrow -> carrier offset -> decisions), HBM-bound: algorithmic bytes = the input once + soft + hard symbols,
-    R*8 + 8 + 1 B/symbol (SURVEY 8(d) 'fused': 41 B/symbol at R = 4)."""
-    from tetraear_amd import synth
+    R*8 + 8 + 1 B/symbol (SURVEY 8(d) 'fused': 41 B/symbol at R = 4).  The output of the last step is checked: hard
+    decisions of every row against the digest of the fp64 definition's, soft symbols at the pinned probes within 1e-5."""
     from tetraear_amd._lib import MODE_TETRA
     from tetraear_amd.batch import BatchDemodulator
-    fs, n = 72000.0, 32768
+    fs, n = TETRA_FS, TETRA_N
     rows = carriers
     bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA)
     bd.alloc_device_io()
-    base = [synth.dqpsk_baseband(n, fs, 700 + i, timing_offset=0.07 * i)[0].astype(np.complex64) for i in range(8)]
-    rng = np.random.default_rng(5)
-    base = [b + (0.07 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64) for b in base]
-    bd.upload(np.concatenate([base[i % 8] for i in range(rows)]))
+    base = tetra_rows()
+    bd.upload(np.concatenate([base[i % TETRA_DISTINCT] for i in range(rows)]))
     for _ in range(max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
         bd.enqueue()
     bd.sync()
@@ -549,19 +719,31 @@ def leg_tetra(carriers, steps, warmup):
     rrc_ms = st.get("tetra_fused", float("nan"))
     bytes_alg = rows * n * 8 + int(np.sum(n_soft.astype(np.int64))) * 9
     traffic, traffic_src = measured_traffic(rows * n, "tetra-cf32", key="tetra_fused")
+    # ---- output check against the definition's pinned results
+    d8 = [rows_digest(hard, n_soft, [r]) for r in range(min(rows, TETRA_DISTINCT))]
+    same = all(rows_digest(hard, n_soft, [r]) == d8[r % TETRA_DISTINCT] for r in range(TETRA_DISTINCT, rows))
+    chk = load_checks()
+    check = {"status": "no pinned digest for this workload"}
+    if chk is not None and "tetra_digests" in chk.files and rows >= TETRA_DISTINCT:
+        want = [str(x) for x in chk["tetra_digests"]]
+        idx, ref = chk["tetra_soft_idx"], chk["tetra_soft_ref"]
+        err = max(float(np.max(np.abs(soft[r, idx[r]] - ref[r])) / np.max(np.abs(ref[r]))) for r in range(TETRA_DISTINCT))
+        ok = want == d8 and same and err < 1e-5
+        check = {"against": "oracle/tetra_np.py (fp64 definition, unquantised RRC for the soft probes), pinned by tests/golden/make_bench_checks.py",
+                 "hard_sha256_row0": d8[0], "rows_equal_their_prototype": bool(same), "soft_probes": int(idx.size),
+                 "soft_max_err_rel": err, "soft_tolerance": 1e-5,
+                 "status": "hard decisions match the definition-pinned digests, soft within 1e-5" if ok else "DIFFERS from the definition"}
     out = {"metric": "Msymbols/s demodulated (TETRA mode: RRC + feed-forward timing + Farrow + quadrant slicer)",
            "value": nsym * steps / dt / 1e6, "unit": "Msym/s", "n_gpus": 1, "steps": steps,
            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32 (matched filter: split-bf16 products accumulated in fp32; soft symbols median 3e-6 / max 6e-6 of full scale from the fp64 definition)", "data": "synthetic",
+           "vs_baseline": None, "dtype": "f32 (matched filter: split-bf16 products accumulated in fp32; soft symbols max 6.2e-6 of full scale from the unquantised fp64 definition over 2048 carriers, tests/test_tetra_precision.py)", "data": "synthetic",
            "config": {"workload": f"{rows} channelised 25 kHz carriers, cf32 @72 kS/s, {n}-sample chunks", "mode": "tetra"},
            "realtime_carriers": nsym * steps / dt / 18000.0, "event_ms_per_step": ev_ms / steps,
            "stage_ms_per_launch": st,
-           "roofline": {"kernel": "k_tetra_fused<33> (RRC matched filter on the matrix cores (split-bf16 products, fp32 accumulate) -> timing -> Farrow -> slicer, one pass over the input)", "bound": "hbm",
-                        "achieved": bytes_alg / (rrc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": bytes_alg / (rrc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
-                        "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": bytes_alg, "bytes_per_symbol": bytes_alg / max(nsym, 1),
-                        "avg_launch_ms": rrc_ms}}
+           "output_check": check,
+           "roofline": hbm_roofline("k_tetra_fused<33> (RRC matched filter on the matrix cores (split-bf16 products, fp32 accumulate) -> timing -> Farrow -> slicer, one pass over the input)",
+                                    bytes_alg, rrc_ms, read_bytes=rows * n * 8, traffic=traffic, traffic_src=traffic_src,
+                                    bytes_per_symbol=bytes_alg / max(nsym, 1))}
     bd.close()
     return out
 

@@ -222,6 +222,11 @@ TDM_API int tdm_dev_free(int32_t device, void *ptr);
 TDM_API int tdm_dev_upload(int32_t device, void *dst_dev, const void *src_host, size_t bytes);
 TDM_API int tdm_dev_download(int32_t device, void *dst_host, const void *src_dev, size_t bytes);
 TDM_API int tdm_dev_sync(int32_t device);
+/* Page-lock a host buffer the caller keeps reusing for tdm_process (a capture loop's read buffers: the recording reader
+ * of tetraear_amd/ingest.py keeps two of them, filled in turn, like the read buffer of decrypt_capture.py:101-107):
+ * host->device copies out of registered memory run at the link's rate without a bounce through a staging page. */
+TDM_API int tdm_host_register(int32_t device, void *ptr, size_t bytes);
+TDM_API int tdm_host_unregister(int32_t device, void *ptr);
 /* Measured HBM ceilings of the box ("public-spec peaks must be replaced by a measured on-box copy-kernel
  * ceiling for the denominator"): grid-stride kernels with 16-byte accesses over two buffers of `bytes` each (use more
  * than the 256 MiB of the last-level cache), `reps` timed launches after 3, HIP events on the current stream.

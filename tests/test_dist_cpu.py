@@ -29,6 +29,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle.oracle import OracleSignalProcessor
     from tetraear_amd import synth
+    import bench
     from tetraear_amd.shard import carrier_range, reduce_job
     dist.init_process_group("gloo", rank=rank, world_size=world)
     total = 5
@@ -43,7 +44,8 @@ def _worker(rank, world, port, q):
         digest.append((c, int(out.sum())))
     dist.barrier()
     # ... and only the bookkeeping is reduced
-    t, s = reduce_job(dist, 0.1 * (rank + 1), n_sym)
+    t, s, bad = reduce_job(bench.TorchGroup(dist), 0.1 * (rank + 1), n_sym, n_failed=rank)
+    assert bad == 1                    # rank 1's failed check is known on every rank
     q.put((rank, t, s, digest))
     dist.destroy_process_group()
 

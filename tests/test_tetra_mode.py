@@ -174,18 +174,7 @@ def test_gpu_tetra_instants_beyond_the_ring():
 
 def _wideband(n, fs, ks, M, seed0=300, snr_db=25.0):
     """Sum of pi/4-DQPSK carriers on the channeliser grid (channel index k -> k*fs/M, k >= M/2 negative)."""
-    acc = np.zeros(n, dtype=np.complex128)
-    t = np.arange(n, dtype=np.float64)
-    dibs = {}
-    for i, k in enumerate(ks):
-        x, dib = synth.dqpsk_baseband(n, fs, seed0 + i, timing_offset=0.11 * i)
-        f = (k if k < M // 2 else k - M) * fs / M
-        acc += x * np.exp(2j * np.pi * f * t / fs)
-        dibs[k] = dib
-    rng = np.random.default_rng(seed0 - 1)
-    sigma2 = (fs / 18000.0) / 10 ** (snr_db / 10)
-    acc += np.sqrt(sigma2 / 2) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
-    return acc, dibs
+    return synth.grid_carriers(n, fs, ks, M, seed0=seed0, snr_db=snr_db)
 
 
 @pytest.mark.gpu

@@ -58,6 +58,8 @@ SIGNATURES = {
     "tdm_channelise": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _vp, _P(_i64), _i32, _i32]),
     "tdm_channelise_batch": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _P(_i64), _i32, _i32]),
     "tdm_hbm_ceiling": (C.c_int, [_i32, _sz, _i32, _P(_f64)]),
+    "tdm_host_register": (C.c_int, [_i32, _vp, _sz]),
+    "tdm_host_unregister": (C.c_int, [_i32, _vp]),
     "tdm_dev_alloc": (C.c_int, [_i32, _sz, _P(_vp)]),
     "tdm_dev_free": (C.c_int, [_i32, _vp]),
     "tdm_dev_upload": (C.c_int, [_i32, _vp, _vp, _sz]),

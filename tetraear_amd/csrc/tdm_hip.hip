@@ -158,11 +158,15 @@ __global__ __launch_bounds__(kFinishThreads) void k_detect(const DetectArgs A)
 }
 
 // from_bits bit 0: units are bits (else dibit symbols); bit 1: n_units holds n_soft of tdm_process_device (symbols + 1)
-__device__ __forceinline__ int64_t sync_row_bits(int32_t n_units, int from_bits)
+// bits of a row, never more than the scratch row holds (max_bits - 1): with device pointers the counts stay on the
+// device and the documented bound "rows are bounded by row_stride" is enforced here, not assumed
+__device__ __forceinline__ int64_t sync_row_bits(int32_t n_units, int from_bits, int64_t max_bits)
 {
     int64_t n = n_units;
     if (from_bits & 2) n = n > 0 ? n - 1 : 0;
-    return (from_bits & 1) ? n : 2 * n;
+    if (n < 0) n = 0;
+    n = (from_bits & 1) ? n : 2 * n;
+    return n < max_bits - 1 ? n : max_bits - 1;
 }
 
 __global__ __launch_bounds__(256) void k_sync_count(const uint8_t *sym, int64_t row_stride, const int32_t *n_units,
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint8_t *sym, int64_t 
 {
     const int row = blockIdx.y;
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n_bits = sync_row_bits(n_units[row], from_bits);
+    const int64_t n_bits = sync_row_bits(n_units[row], from_bits, max_bits);
     sync_count_body(sym + (int64_t)row * row_stride, n_bits, pos, from_bits & 1, counts + (int64_t)row * max_bits);
 }
 
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64) void k_sync_walk(const uint16_t *counts, const 
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
-    const int64_t n_bits = sync_row_bits(n_units[row], from_bits);
+    const int64_t n_bits = sync_row_bits(n_units[row], from_bits, max_bits);
     double mc;
     n_pos[row] = sync_walk_body(counts + (int64_t)row * max_bits, n_bits, threshold,
                                 positions + (int64_t)row * max_pos, max_pos, &mc);
@@ -380,6 +384,7 @@ constexpr size_t kMaxVariants = 32;
 
 struct tdm_plan {
     int rows = 0, fmt = 0, mode = 0, device = 0;
+    double sample_rate = 0.0;
     bool allow_raw = true;
     int64_t raw_min_blocks = 0;
     std::map<int64_t, std::unique_ptr<Variant>> variants;
@@ -445,6 +450,20 @@ static int shared_on_device(tdm_plan *plan, const std::shared_ptr<const ZpShared
 }
 
 // Make the variant for chunk length n current (reference mode).
+// shared tables no variant refers to any more (only this map's own reference is left) are released; called where the
+// plan's stream has just been synchronised.  The variant under construction holds its tables through its RefPlanHost.
+static void shared_gc(tdm_plan *plan)
+{
+    for (auto it = plan->d_shared.begin(); it != plan->d_shared.end();) {
+        if (it->second.first.use_count() == 1) {
+            (void)hipFree(it->second.second);
+            it = plan->d_shared.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
 {
     auto hit = plan->variants.find(n);
@@ -455,7 +474,13 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
     }
     const int rows = plan->rows;
     std::unique_ptr<Variant> v(new Variant);
-    v->h = build_ref_plan(sample_rate, n, 25000.0, true, plan->allow_raw ? plan->fmt : -1, plan->cur ? &plan->cur->h : nullptr);
+    // designs and length-independent tables come from a variant that has them: the current one, else any other (a short
+    // chunk that skips the decimator must not make the next long one rebuild and re-upload the shared tables)
+    const RefPlanHost *base = plan->cur ? &plan->cur->h : nullptr;
+    if (!base || !base->dec.shared)
+        for (auto &kv : plan->variants)
+            if (kv.second->h.dec.shared) { base = &kv.second->h; break; }
+    v->h = build_ref_plan(sample_rate, n, 25000.0, true, plan->allow_raw ? plan->fmt : -1, base);
     const RefPlanHost &h = v->h;
     // ---- tables: the length-dependent ones of all stages in one allocation and one copy
     const bool use_lpf = h.lpf && !h.lp2.ok;
@@ -499,14 +524,22 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
     const size_t need = (h.decimated ? zp_work_doubles(v->dec, rows) : 0) + (use_lpf ? zp_work_doubles(v->lpf, rows) : 0) +
                         (h.raw_S ? zp_work_doubles(v->dec_raw, rows) : 0) + n_zt + n_lp2p + (need_y ? nd : 0) + (need_z ? nd : 0) + n_part;
     if (need > plan->work_doubles) {
-        // kernels of earlier calls may still be using the buffer; the other variants' pointers into it go stale
-        HIP_TRY(hipStreamSynchronize(plan->stream));
+        // the new buffer first: if the allocation fails the plan keeps serving the lengths it has.  Then: kernels of
+        // earlier calls may still be using the old buffer, and the other variants' pointers into it go stale
+        double *grown = nullptr;
+        if (hipMalloc(&grown, need * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TDM_ERR_NOMEM, "plan work buffer: hipMalloc of " + std::to_string(need * sizeof(double)) + " bytes failed");
+        }
+        if (hipStreamSynchronize(plan->stream) != hipSuccess) {
+            (void)hipFree(grown);
+            return fail(TDM_ERR_HIP, "hipStreamSynchronize(plan->stream)");
+        }
         plan->cur = nullptr;
         plan->variants.clear();
+        shared_gc(plan);
         if (plan->d_work) (void)hipFree(plan->d_work);
-        plan->d_work = nullptr;
-        plan->work_doubles = 0;
-        HIP_TRY(hipMalloc(&plan->d_work, need * sizeof(double)));
+        plan->d_work = grown;
         plan->work_doubles = need;
     }
     double *w = plan->d_work;
@@ -542,6 +575,7 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
         // (its tables may still be read by kernels in flight)
         HIP_TRY(hipStreamSynchronize(plan->stream));
         plan->variants.erase(old);
+        shared_gc(plan);
     }
     v->stamp = ++plan->clock;
     v->id = plan->clock;
@@ -677,6 +711,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p->ev0));
     HIP_TRY(hipEventCreate(&p->ev1));
+    p->sample_rate = sample_rate;
     if ((rc = plan_select(p.get(), sample_rate, n_samples))) return rc;
     *out = p.release();
     return TDM_OK;
@@ -693,9 +728,7 @@ int tdm_plan_resize(tdm_plan *plan, int64_t n_samples)
     if (n_samples < 1 || n_samples > (int64_t(1) << 31)) return fail(TDM_ERR_INVALID, "bad n_samples");
     if (plan->cur && plan->cur->h.n == n_samples) return TDM_OK;
     HIP_TRY(hipSetDevice(plan->device));
-    const double fs = plan->cur ? plan->cur->h.sample_rate : 0.0;
-    if (!(fs > 0)) return fail(TDM_ERR_INVALID, "plan has no current length (an earlier resize failed)");
-    return plan_select(plan, fs, n_samples);
+    return plan_select(plan, plan->sample_rate, n_samples);
 }
 
 int tdm_plan_destroy(tdm_plan *plan)
@@ -1056,6 +1089,26 @@ __global__ __launch_bounds__(256) void k_ceiling_read(const ceil_f4 *__restrict_
     const float s = acc.x + acc.y + acc.z + acc.w;
     if (s == 123456.789f) sink[0] = s;   // (keeps the loads; never true for the zero-filled buffer)
 }
+// the flat forms: one 16-byte access per lane, one workgroup per 4 KB -- the form that reached the highest copy rate
+// of all those tried on MI355X (6.29 TB/s; grid-stride forms 5.0-5.7, hipMemcpyDtoD 5.0: tools/harness/copy_bench.hip)
+__global__ __launch_bounds__(256) void k_ceiling_copy_flat(const ceil_f4 *__restrict__ a, ceil_f4 *__restrict__ b, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_ceiling_read_flat(const ceil_f4 *__restrict__ a, float *sink, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) {
+        const ceil_f4 v = a[i];
+        if (v.x + v.y + v.z + v.w == 123456.789f) sink[0] = v.x;   // (never true for the zero-filled buffer)
+    }
+}
+__global__ __launch_bounds__(256) void k_ceiling_write_flat(ceil_f4 *__restrict__ b, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) b[i] = ceil_f4{1.f, 2.f, 3.f, 4.f};
+}
 __global__ __launch_bounds__(256) void k_ceiling_write(ceil_f4 *__restrict__ b, size_t n16)
 {
     const ceil_f4 v = {1.f, 2.f, 3.f, 4.f};
@@ -1086,12 +1139,18 @@ int tdm_hbm_ceiling(int32_t device, size_t bytes, int32_t reps, double *gbs)
     hipError_t err = hipSuccess;
     // grid-stride kernels, 16 bytes per lane, 8 workgroups of 256 threads per compute unit (2048) and twice that; the best of
     // the plain / non-temporal forms and of the two grids is the ceiling of each direction
-    for (int variant = 0; variant < 4 && err == hipSuccess; ++variant) {   // plain / non-temporal x 2048 / 8192 workgroups
-        const bool nt = variant & 1;
-        const int grid = (variant & 2) ? 8192 : 2048;
+    for (int variant = 0; variant < 5 && err == hipSuccess; ++variant) {   // plain / non-temporal x 2048 / 8192 workgroups, then the flat forms
+        const bool nt = variant & 1, flat = variant == 4;
+        const int grid = flat ? (int)((n16 + 255) / 256) : ((variant & 2) ? 8192 : 2048);
         for (int what = 0; what < 3; ++what) {
             if (what == 2 && nt) continue;
             auto launch = [&]() {
+                if (flat) {
+                    if (what == 0) hipLaunchKernelGGL(k_ceiling_copy_flat, dim3(grid), dim3(256), 0, st, a, b, n16);
+                    else if (what == 1) hipLaunchKernelGGL(k_ceiling_read_flat, dim3(grid), dim3(256), 0, st, a, (float *)b, n16);
+                    else hipLaunchKernelGGL(k_ceiling_write_flat, dim3(grid), dim3(256), 0, st, b, n16);
+                    return;
+                }
                 if (what == 0) { if (nt) hipLaunchKernelGGL(k_ceiling_copy<true>, dim3(grid), dim3(256), 0, st, a, b, n16); else hipLaunchKernelGGL(k_ceiling_copy<false>, dim3(grid), dim3(256), 0, st, a, b, n16); }
                 else if (what == 1) { if (nt) hipLaunchKernelGGL(k_ceiling_read<true>, dim3(grid), dim3(256), 0, st, a, (float *)b, n16); else hipLaunchKernelGGL(k_ceiling_read<false>, dim3(grid), dim3(256), 0, st, a, (float *)b, n16); }
                 else hipLaunchKernelGGL(k_ceiling_write, dim3(grid), dim3(256), 0, st, b, n16);
@@ -1145,6 +1204,21 @@ int tdm_dev_download(int32_t device, void *dst_host, const void *src_dev, size_t
     int rc = use_device(device);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return TDM_OK;
+}
+int tdm_host_register(int32_t device, void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(TDM_ERR_INVALID, "tdm_host_register: null buffer");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return TDM_OK;
+}
+int tdm_host_unregister(int32_t device, void *ptr)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipHostUnregister(ptr));
     return TDM_OK;
 }
 int tdm_dev_sync(int32_t device)
@@ -1492,6 +1566,23 @@ int tdm_detect(const double *x, int64_t n, int32_t rows, double sample_rate, dou
 }
 
 // ---- burst sync: TetraDecoder.find_sync on the hard symbols, batched ---------------
+namespace {
+struct SyncScratch { void *p = nullptr; size_t bytes = 0; };
+struct SyncScratchMap {
+    std::map<std::pair<int, hipStream_t>, SyncScratch> m;
+    SyncScratch &of(int device, hipStream_t st) { return m[std::make_pair(device, st)]; }
+    ~SyncScratchMap()   // thread exit: give the buffers back (errors ignored: the runtime may already be gone at process exit)
+    {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return;
+        for (auto &kv : m)
+            if (kv.second.p && hipSetDevice(kv.first.first) == hipSuccess) (void)hipFree(kv.second.p);
+        (void)hipSetDevice(cur);
+    }
+};
+thread_local SyncScratchMap tl_sync_scratch;
+}  // namespace
+
 int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_units, int32_t rows, int32_t from_bits,
                   double threshold, int32_t max_pos, int32_t *positions, int32_t *n_pos, double *max_corr,
                   int32_t device_pointers, int32_t device)
@@ -1525,19 +1616,24 @@ int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_uni
         HIP_TRY(hipMemcpy(dn.p, n_units, rows * 4, hipMemcpyHostToDevice));
         u = du.as<uint8_t>(); nu = dn.as<int32_t>(); pp = dp.as<int32_t>(); np_ = dnp.as<int32_t>(); mc = dmc.as<double>();
     }
-    // scratch for the per-position counts: pooled per thread for the device-pointer form (asynchronous: it must outlive
-    // the call), released with the call otherwise
+    // scratch for the per-position counts: for the device-pointer form (asynchronous: it must outlive the call) one
+    // buffer per (calling thread, device, stream) -- launches on one stream are ordered, so they can share it; another
+    // device or another stream gets its own -- released with the call otherwise
     uint16_t *cnt = nullptr;
     const size_t cnt_bytes = (size_t)rows * max_bits * 2;
     if (device_pointers) {
-        static thread_local void *pool = nullptr;
-        static thread_local size_t pool_bytes = 0;
-        if (pool_bytes < cnt_bytes) {
-            if (pool) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(pool); pool = nullptr; pool_bytes = 0; }
-            HIP_TRY(hipMalloc(&pool, cnt_bytes));
-            pool_bytes = cnt_bytes;
+        SyncScratch &sc = tl_sync_scratch.of(device, st);
+        if (sc.bytes < cnt_bytes) {
+            if (sc.p) {
+                HIP_TRY(hipStreamSynchronize(st));   // the only stream that ever used this buffer
+                (void)hipFree(sc.p);
+                sc.p = nullptr;
+                sc.bytes = 0;
+            }
+            HIP_TRY(hipMalloc(&sc.p, cnt_bytes));
+            sc.bytes = cnt_bytes;
         }
-        cnt = (uint16_t *)pool;
+        cnt = (uint16_t *)sc.p;
     } else {
         if ((rc = dcnt.alloc(cnt_bytes))) return rc;
         cnt = dcnt.as<uint16_t>();

@@ -3,41 +3,114 @@
 The reference has no file reader; the format defined here is rtl_sdr's raw output:
 interleaved unsigned bytes I,Q ("cu8"), converted on the GPU exactly as pyrtlsdr converts them.
 A capture loop in the reference reads fixed-size chunks and demodulates each one independently
-(decrypt_capture.py:101-107: read_samples(256*1024) -> process()); a recording is therefore cut
-into the same chunks, which become the rows of pipelined GPU batches.
+(decrypt_capture.py:101-107: `samples = capture.read_samples(chunk_size); processor.process(samples)`;
+ui/modern.py:1908-1912 reads 128 Ki samples per turn), so a recording is cut into the same reads.
+
+`iter_recording` is that loop as a generator over a file, a pipe or an array: it never holds more than two batches of
+reads in memory.  Two page-locked host buffers are filled in turn by a reader thread while the GPU works on the other
+one (rows of a batch = consecutive reads); ONE plan serves the whole recording -- the remainder batch runs on the
+same plan with its unused rows blank, the last, shorter read through tdm_plan_resize.
 """
+import io
+import threading
+
 import numpy as np
 
+from tetraear_amd import _lib
+from tetraear_amd._lib import check, ptr
 from tetraear_amd.batch import BatchDemodulator
 
 
-def demodulate_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0, rows_per_batch=64, device=0):
-    """source: path of a cu8 file, or a uint8 array of interleaved I,Q.
-    Returns a list with one uint8 symbol array per chunk (what process() returned per read)."""
-    u8 = np.fromfile(source, dtype=np.uint8) if isinstance(source, (str, bytes)) else np.ascontiguousarray(source, np.uint8)
-    n_chunks = (len(u8) // 2) // chunk
-    out = []
-    if n_chunks > 0:
-        rows = min(rows_per_batch, n_chunks)
-        n_batches = n_chunks // rows
+def _open(source):
+    """-> (readinto(buffer) -> bytes read, close())"""
+    if isinstance(source, (str, bytes)):
+        f = open(source, "rb", buffering=0)
+        return f.readinto, f.close
+    if hasattr(source, "readinto"):          # file object, pipe (sys.stdin.buffer), socket file
+        return source.readinto, (lambda: None)
+    arr = np.ascontiguousarray(source, dtype=np.uint8).reshape(-1)
+    f = io.BytesIO(arr.data)                  # (no copy: a view of the caller's array)
+    return f.readinto, f.close
+
+
+def _fill(readinto, view):
+    """read until `view` is full or the source ends (a pipe hands out short reads); returns the byte count"""
+    got = 0
+    while got < len(view):
+        k = readinto(view[got:])
+        if not k:
+            break
+        got += k
+    return got
+
+
+def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0, rows_per_batch=64, device=0):
+    """source: path of a cu8 file, an object with readinto() (open file, pipe), or a uint8 array of interleaved I,Q.
+    Yields, in order, one uint8 symbol array per read of `chunk` samples -- what process() returned per read in the
+    reference's loop -- and last the shorter final read, if the recording does not end on a read boundary."""
+    readinto, close = _open(source)
+    lib = _lib.load()
+    rows = int(rows_per_batch)
+    batch_bytes = 2 * chunk * rows
+    bufs = [np.zeros(batch_bytes, dtype=np.uint8) for _ in range(2)]
+    pinned = []
+    bd = None
+    try:
+        for b in bufs:
+            check(lib.tdm_host_register(device, ptr(b), b.nbytes))
+            pinned.append(b)
         bd = BatchDemodulator(sample_rate, chunk, rows, "cu8", device=device)
-        hard, soft, n_soft, bp, mm = bd.process_stream(u8[:2 * chunk * rows * n_batches], n_batches,
-                                                       freq_offsets=[float(freq_offset)] * rows)
-        for b in range(n_batches):
-            for r in range(rows):
-                out.append(hard[b, r, :max(int(n_soft[b, r]) - 1, 0)].copy())
-        bd.close()
-        done = rows * n_batches
-        if done < n_chunks:   # remaining chunks: one smaller batch
-            rem = n_chunks - done
-            bd = BatchDemodulator(sample_rate, chunk, rem, "cu8", device=device)
-            hards, _, _, _ = bd.process(u8[2 * chunk * done:2 * chunk * n_chunks], freq_offsets=[float(freq_offset)] * rem)
-            out.extend(hards)
+        foffs = [float(freq_offset)] * rows
+        # reader thread: fills the buffer the GPU is not working on
+        filled = [0, 0]
+        state = {"err": None}
+
+        def read_into(slot):
+            try:
+                filled[slot] = _fill(readinto, memoryview(bufs[slot]))
+            except Exception as e:  # noqa: BLE001 -- re-raised by the consumer
+                state["err"] = e
+                filled[slot] = 0
+
+        read_into(0)
+        slot = 0
+        while True:
+            if state["err"]:
+                raise state["err"]
+            got = filled[slot]
+            if got == 0:
+                break
+            t = None
+            if got == batch_bytes:               # (a short batch means the source has ended)
+                t = threading.Thread(target=read_into, args=(slot ^ 1,))
+                t.start()
+            n_reads, tail = divmod(got // 2, chunk)
+            if n_reads:
+                if n_reads < rows:
+                    bufs[slot][2 * chunk * n_reads + 2 * tail:] = 128     # blank rows (mid-scale bytes); their output is dropped
+                hards, _, _, _ = bd.resize(chunk).process(bufs[slot], freq_offsets=foffs)
+                for r in range(n_reads):
+                    yield hards[r]
+            if tail:
+                # the last, shorter read of the recording: same plan, another chunk length, row 0
+                seg = bufs[slot][2 * chunk * n_reads: 2 * (chunk * n_reads + tail)].copy()
+                bufs[slot][:] = 128
+                bufs[slot][:2 * tail] = seg
+                bd.resize(tail)
+                hards, _, _, _ = bd.process(bufs[slot][:2 * tail * rows], freq_offsets=foffs)
+                yield hards[0]
+            if t is None:
+                break
+            t.join()
+            slot ^= 1
+    finally:
+        if bd is not None:
             bd.close()
-    tail = (len(u8) // 2) - n_chunks * chunk
-    if tail > 0:              # the last, shorter read
-        bd = BatchDemodulator(sample_rate, tail, 1, "cu8", device=device)
-        hards, _, _, _ = bd.process(u8[2 * chunk * n_chunks:2 * (chunk * n_chunks + tail)], freq_offsets=[float(freq_offset)])
-        out.extend(hards)
-        bd.close()
-    return out
+        for b in pinned:
+            lib.tdm_host_unregister(device, ptr(b))
+        close()
+
+
+def demodulate_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0, rows_per_batch=64, device=0):
+    """the whole recording at once: a list with one uint8 symbol array per read (see iter_recording)"""
+    return list(iter_recording(source, sample_rate, chunk, freq_offset, rows_per_batch, device))

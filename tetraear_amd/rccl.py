@@ -2,11 +2,25 @@
 timed region of a multi-GPU run (carriers are sharded, SURVEY.md section 8(e): no data-path collective), so the
 launcher's ranks talk to librccl directly instead of importing a tensor framework.
 
-One process per GPU on ONE node.  The ncclUniqueId travels from rank 0 to the others through a file in /tmp named
-after MASTER_PORT, the launcher's run id and the launcher's process id (all ranks share the node's /tmp and their parent)."""
+One process per GPU on ONE node.  Bring-up is collective by construction:
+
+1. every rank loads librccl and binds its device, and notes whether that worked;
+2. the ranks meet on a TCP socket that rank 0 opens on MASTER_ADDR (ports MASTER_PORT + 1 + k, k = 0..63: the first one
+   it can bind; MASTER_PORT itself belongs to the launcher's store).  A connection starts with a token made of the
+   launcher's run id, the world size and the launcher's pid, so a foreign listener or a stale run on one of those ports
+   is recognised and skipped;
+3. rank 0 collects every rank's "librccl usable" flag and answers each with the SAME decision: all usable -> the
+   ncclUniqueId follows and all ranks enter ncclCommInitRank; otherwise every rank raises RcclUnavailable and the caller
+   may choose another backend -- on ALL ranks, never on some (a per-rank fallback leaves the rest blocked inside
+   ncclCommInitRank for ever).
+
+After the decision there is no fallback: an error inside ncclCommInitRank / ncclAllReduce is fatal for the job.
+"""
 import contextlib
 import ctypes as C
 import os
+import socket
+import struct
 import sys
 import time
 
@@ -15,6 +29,12 @@ from . import _lib
 NCCL_UNIQUE_ID_BYTES = 128
 ncclFloat64, ncclInt64 = 8, 4
 ncclSum, ncclMax = 0, 2
+_PORT_SPAN = 64
+_MAGIC = b"TDMRCCL2"
+
+
+class RcclUnavailable(RuntimeError):
+    """raised on EVERY rank when at least one rank cannot use librccl (the decision is collective)"""
 
 
 @contextlib.contextmanager
@@ -37,40 +57,153 @@ class _UniqueId(C.Structure):
     _fields_ = [("internal", C.c_byte * NCCL_UNIQUE_ID_BYTES)]
 
 
-class RcclGroup:
-    def __init__(self, rank, world, device, tag=None, timeout_s=120.0):
-        self.rank, self.world, self.device = int(rank), int(world), int(device)
-        self.lib = C.CDLL("librccl.so")
-        self.lib.ncclGetErrorString.restype = C.c_char_p
+class DeviceMemory:
+    """the 16-byte exchange buffer of the all-reduces in device memory, through libtetrahip's helpers"""
+
+    def __init__(self, device):
+        self.device = int(device)
         self.tdm = _lib.load()
         _lib.check(self.tdm.tdm_dev_sync(self.device))          # binds this process to its device (hipSetDevice)
-        # (the launcher's pid is the same for all ranks of one launch and differs between launches: an id file left behind
-        #  by a crashed earlier run on the same port can never be taken for this run's)
-        tag = tag or f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}_{os.getppid()}"
-        path = f"/tmp/tdm_rccl_{tag}_{self.world}.id"
+        p = C.c_void_p()
+        _lib.check(self.tdm.tdm_dev_alloc(self.device, 16, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, cvalue):
+        _lib.check(self.tdm.tdm_dev_upload(self.device, self.ptr, C.byref(cvalue), 8))
+
+    def download(self, cvalue):
+        _lib.check(self.tdm.tdm_dev_sync(self.device))
+        _lib.check(self.tdm.tdm_dev_download(self.device, C.byref(cvalue), self.ptr, 8))
+
+    def free(self):
+        self.tdm.tdm_dev_free(self.device, self.ptr)
+
+
+def _recv_exact(sock, n):
+    buf = b""
+    while len(buf) < n:
+        part = sock.recv(n - len(buf))
+        if not part:
+            raise ConnectionError("rendezvous peer closed the connection")
+        buf += part
+    return buf
+
+
+def _token(world):
+    run = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}|{world}|{os.getppid()}".encode()
+    return _MAGIC + struct.pack("<H", len(run)) + run
+
+
+def rendezvous(rank, world, usable, make_payload, timeout_s=120.0, addr=None, base_port=None):
+    """Collective decision + payload hand-off.  Every rank passes `usable`; rank 0 also passes make_payload() -> bytes
+    (called only when every rank is usable).  Returns (all_usable, payload or b"")."""
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    base = int(base_port if base_port is not None else os.environ.get("MASTER_PORT", "29500")) + 1
+    token = _token(world)
+    deadline = time.time() + timeout_s
+    if world == 1:
+        return bool(usable), (make_payload() if usable else b"")
+    if rank == 0:
+        srv = None
+        for k in range(_PORT_SPAN):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((addr, base + k))
+                s.listen(world)
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise RuntimeError(f"rccl rendezvous: no free port in {base}..{base + _PORT_SPAN - 1} on {addr}")
+        peers, flags = {}, {0: bool(usable)}
+        try:
+            while len(peers) < world - 1:
+                srv.settimeout(max(0.1, deadline - time.time()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise TimeoutError(f"rccl rendezvous: {world - 1 - len(peers)} rank(s) never arrived") from None
+                try:
+                    conn.settimeout(10.0)
+                    if _recv_exact(conn, len(token)) != token:
+                        conn.close()          # not one of this launch's ranks
+                        continue
+                    r, ok = struct.unpack("<iB", _recv_exact(conn, 5))
+                    conn.sendall(_MAGIC)      # immediate acknowledgement: the peer knows it found this launch's rank 0
+                except (OSError, ConnectionError, struct.error):
+                    conn.close()
+                    continue
+                if 0 < r < world and r not in peers:
+                    peers[r], flags[r] = conn, bool(ok)
+                else:
+                    conn.close()
+            decision = all(flags.values())
+            payload = make_payload() if decision else b""
+            for conn in peers.values():
+                conn.sendall(struct.pack("<BI", 1 if decision else 0, len(payload)) + payload)
+        finally:
+            for conn in peers.values():
+                conn.close()
+            srv.close()
+        return decision, payload
+    # ranks > 0: find rank 0's socket among the candidate ports (a listener that is not ours never answers the token)
+    last = None
+    while time.time() < deadline:
+        for k in range(_PORT_SPAN):
+            try:
+                s = socket.create_connection((addr, base + k), timeout=1.0)
+            except OSError as e:
+                last = e
+                continue
+            try:
+                s.settimeout(3.0)
+                s.sendall(token + struct.pack("<iB", rank, 1 if usable else 0))
+                if _recv_exact(s, len(_MAGIC)) != _MAGIC:
+                    continue                  # something else listens on this port
+                s.settimeout(max(1.0, deadline - time.time()))   # the decision comes when every rank has arrived
+                head = _recv_exact(s, 5)
+                decision, n = struct.unpack("<BI", head)
+                payload = _recv_exact(s, n) if n else b""
+                return bool(decision), payload
+            except (OSError, ConnectionError, struct.error) as e:
+                last = e
+            finally:
+                s.close()
+        time.sleep(0.05)
+    raise TimeoutError(f"rccl rendezvous: rank {rank} found no rank 0 on {addr}:{base}..{base + _PORT_SPAN - 1} ({last})")
+
+
+class RcclGroup:
+    """barrier / max_f64 / sum_i64 over librccl.  `lib_path` and `memory` exist for the CPU-tier test, which runs this class
+    against a stub library over host memory (tests/rccl_stub)."""
+
+    def __init__(self, rank, world, device, timeout_s=120.0, lib_path="librccl.so", memory=None):
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self.lib, self.mem, err = None, None, None
+        try:
+            self.lib = C.CDLL(lib_path)
+            self.lib.ncclGetErrorString.restype = C.c_char_p
+            self.mem = memory if memory is not None else DeviceMemory(self.device)
+        except Exception as e:  # noqa: BLE001 -- reported to the other ranks, then raised on all of them
+            err = e
         uid = _UniqueId()
-        if self.rank == 0:
+
+        def make_id():
             with _stdout_to_stderr():
                 self._ok(self.lib.ncclGetUniqueId(C.byref(uid)))
-            tmp = path + f".{os.getpid()}"
-            with open(tmp, "wb") as f:
-                f.write(bytes(uid.internal))
-            os.replace(tmp, path)
-        else:
-            t0 = time.time()
-            while not (os.path.exists(path) and os.path.getsize(path) == NCCL_UNIQUE_ID_BYTES):
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError(f"no ncclUniqueId at {path}")
-                time.sleep(0.01)
-            with open(path, "rb") as f:
-                C.memmove(uid.internal, f.read(), NCCL_UNIQUE_ID_BYTES)
+            return bytes(uid.internal)
+
+        ok, payload = rendezvous(self.rank, self.world, err is None, make_id, timeout_s)
+        if not ok:
+            if self.mem is not None and memory is None:
+                self.mem.free()
+            raise RcclUnavailable(f"librccl is not usable on every rank (this rank: {err or 'ok'})")
+        C.memmove(uid.internal, payload, NCCL_UNIQUE_ID_BYTES)
         self.comm = C.c_void_p()
         with _stdout_to_stderr():
             self._ok(self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank))
-        self._path = path
-        p = C.c_void_p()
-        _lib.check(self.tdm.tdm_dev_alloc(self.device, 16, C.byref(p)))
-        self.buf = p
 
     def _ok(self, rc):
         if rc != 0:
@@ -78,10 +211,9 @@ class RcclGroup:
 
     def _allreduce(self, ctype, nccl_type, op, value):
         v = ctype(value)
-        _lib.check(self.tdm.tdm_dev_upload(self.device, self.buf, C.byref(v), 8))
-        self._ok(self.lib.ncclAllReduce(self.buf, self.buf, C.c_size_t(1), nccl_type, op, self.comm, C.c_void_p(0)))
-        _lib.check(self.tdm.tdm_dev_sync(self.device))
-        _lib.check(self.tdm.tdm_dev_download(self.device, C.byref(v), self.buf, 8))
+        self.mem.upload(v)
+        self._ok(self.lib.ncclAllReduce(self.mem.ptr, self.mem.ptr, C.c_size_t(1), nccl_type, op, self.comm, C.c_void_p(0)))
+        self.mem.download(v)
         return v.value
 
     def max_f64(self, x):
@@ -98,8 +230,6 @@ class RcclGroup:
             self.barrier()
             with _stdout_to_stderr():
                 self.lib.ncclCommDestroy(self.comm)
-            self.tdm.tdm_dev_free(self.device, self.buf)
-            if self.rank == 0 and os.path.exists(self._path):
-                os.remove(self._path)
+            self.mem.free()
         except Exception:
             pass

@@ -1,10 +1,10 @@
 """Work split of independent carriers across ranks (one process per GPU).
 
 The path has no exchange step: carriers are partitioned statically and the
-only cross-rank traffic is a barrier plus two tiny reductions (max elapsed time, sum of symbols).
-`group` is any object with max_f64 / sum_i64 / barrier: tetraear_amd.rccl.RcclGroup (librccl through ctypes, what
-bench.py uses on GPUs), or TorchGroup below around torch.distributed ("gloo" in the CPU tests, "nccl" = RCCL as the
-fallback when the ctypes binding cannot initialise).
+only cross-rank traffic is a barrier plus three tiny reductions (max elapsed time, sum of symbols, sum of
+output-check failures).  `group` is any object with max_f64 / sum_i64 / barrier:
+tetraear_amd.rccl.RcclGroup (librccl through ctypes, what bench.py uses on GPUs) or a test double.
+Nothing in this package imports a tensor framework.
 """
 
 
@@ -16,41 +16,11 @@ def carrier_range(n_total, rank, world):
     return lo, hi
 
 
-class TorchGroup:
-    """the same three operations on an initialised torch.distributed process group"""
-
-    def __init__(self, dist, device=None):
-        self.dist, self.device = dist, device
-
-    def max_f64(self, x):
-        import torch
-        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def sum_i64(self, x):
-        import torch
-        t = torch.tensor([int(x)], dtype=torch.int64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return int(t.item())
-
-    def barrier(self):
-        self.dist.barrier()
-        if self.device is not None:
-            import torch
-            torch.cuda.synchronize()
-
-    def close(self):
-        self.dist.destroy_process_group()
-
-
-def reduce_job(group, elapsed_s, n_symbols, device=None):
-    """(max elapsed over ranks, total symbols over ranks).  `group`: see the module docstring; None = single process;
-    a torch.distributed module is accepted too (wrapped)."""
+def reduce_job(group, elapsed_s, n_symbols, n_failed=0):
+    """(max elapsed over ranks, total symbols over ranks, total failed output checks over ranks).
+    `group`: see the module docstring; None = single process.  Every rank must call it (the reductions are
+    collective), in particular a rank whose own output check failed: the failure count travels with the job and every
+    rank learns of it, so that all of them can stop together instead of one leaving the others inside an all-reduce."""
     if group is None:
-        return float(elapsed_s), int(n_symbols)
-    if hasattr(group, "all_reduce"):          # torch.distributed itself
-        if not group.is_initialized() or group.get_world_size() == 1:
-            return float(elapsed_s), int(n_symbols)
-        group = TorchGroup(group, device)
-    return group.max_f64(elapsed_s), group.sum_i64(n_symbols)
+        return float(elapsed_s), int(n_symbols), int(n_failed)
+    return group.max_f64(elapsed_s), group.sum_i64(n_symbols), group.sum_i64(n_failed)

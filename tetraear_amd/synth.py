@@ -116,3 +116,21 @@ def multicarrier_cu8(n_samples, sample_rate, offsets_hz, seed0=100, esn0_db=20.0
     acc += np.sqrt(sigma2 / 2.0) * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
     peak = 4.0 * np.sqrt(len(offsets_hz) + sigma2)
     return quantise_cu8(acc, scale=1.0 / peak), all_dibits
+
+
+def grid_carriers(n_samples, sample_rate, channels, M, seed0=300, snr_db=25.0):
+    """Sum of pi/4-DQPSK carriers on a channeliser grid: channel index k sits at k*fs/M (k >= M/2: negative
+    frequencies), own symbol seed seed0 + i and timing offset 0.11 i each, white noise for `snr_db` Es/N0.
+    Returns (complex128 stream, {channel: dibits sent})."""
+    acc = np.zeros(n_samples, dtype=np.complex128)
+    t = np.arange(n_samples, dtype=np.float64)
+    dibs = {}
+    for i, k in enumerate(channels):
+        x, dib = dqpsk_baseband(n_samples, sample_rate, seed0 + i, timing_offset=0.11 * i)
+        f = (k if k < M // 2 else k - M) * sample_rate / M
+        acc += x * np.exp(2j * np.pi * f * t / sample_rate)
+        dibs[k] = dib
+    rng = np.random.default_rng(seed0 - 1)
+    sigma2 = (sample_rate / SYMBOL_RATE) / 10 ** (snr_db / 10)
+    acc += np.sqrt(sigma2 / 2) * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
+    return acc, dibs

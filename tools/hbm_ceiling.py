@@ -15,8 +15,8 @@ for gib in (1, 2):
     g = (C.c_double * 3)()
     _lib.check(L.tdm_hbm_ceiling(0, gib << 30, 20, g))
     out[f"{gib}GiB"] = {"copy_GBps": g[0], "read_GBps": g[1], "write_GBps": g[2]}
-res = {"what": "tdm_hbm_ceiling: grid-stride kernels, 16 B per lane, plain and non-temporal forms, 2048 and 4096 workgroups of 256; "
-               "best of each; 20 timed launches after 3; copy counts bytes read + bytes written",
+res = {"what": "tdm_hbm_ceiling: 16 B per lane; flat form (one access per lane, one workgroup per 4 KB) and grid-stride forms (plain / "
+               "non-temporal, 2048 / 8192 workgroups); best of each; 20 timed launches after 3; copy counts bytes read + bytes written",
        "buffers": out, "spec_GBps": 8000.0,
        "ceiling_GBps": max(v["copy_GBps"] for v in out.values())}
 print(json.dumps(res))
