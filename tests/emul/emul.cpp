@@ -331,6 +331,7 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
         B.lp2.lane_m = h.lp2.lane_m.data();
         B.lp2.cst = h.lp2.cst.data();
         B.lp2.seeds = h.lp2.seeds.data();
+        B.lp2.items = (const int32_t *)h.lp2.items.data();
         if (h.raw_S) {
             dec_raw.t = h.dec_raw;
             dec_raw.bind(rows);
@@ -344,6 +345,7 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
             B.lp2_raw.lane_m = h.lp2.lane_m.data();
             B.lp2_raw.cst = h.lp2_raw.cst.data();
             B.lp2_raw.seeds = h.lp2_raw.seeds.data();
+            B.lp2_raw.items = (const int32_t *)h.lp2_raw.items.data();
         }
     }
     const double nan = std::numeric_limits<double>::quiet_NaN();

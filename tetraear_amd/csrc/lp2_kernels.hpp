@@ -18,6 +18,8 @@
 //   Comm: tid(), sync() (workgroup barrier), stage() -> LDS of Lp2Lds::kStage doubles, small() -> Lp2Lds::kSmall doubles,
 //   and the wavefront shuffles of pz_kernels.hpp (row_shr2, row_shl2, row_total_prev2, row_total_next2, wave_shr1, wave_shl1).
 #pragma once
+#include <type_traits>
+
 #include "lp2_tables.hpp"
 #include "pz_kernels.hpp"
 
@@ -34,6 +36,12 @@ extern __device__ unsigned long long g_lp2_dbg[16];
 #else
 #define LP2_T(i)
 #define LP2_T0()
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TDM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TDM_SCHED_FENCE() do { } while (0)
 #endif
 
 namespace tdm {
@@ -63,8 +71,10 @@ struct Lp2SrcPlain {   // c128 rows already at the low rate (no decimation: k_co
     TDM_HD double foff(int) const { return 0.0; }
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(x + (int64_t)row * row_stride * 2); }
     struct Pref {};
-    TDM_HD void prefetch(const Lp2Params &, int, int64_t, Pref &) const {}
-    TDM_HD void finish_lane(const Lp2Params &, const Pref &, double *, double *) const {}
+    template <class Comm>
+    TDM_HD void prefetch(const Lp2Params &, int, int, Comm &, Pref &) const {}
+    template <class Comm>
+    TDM_HD void fix_phase(const Lp2Params &, int, int, f64x2 *, Comm &, const Pref &) const {}
 };
 
 struct Lp2SrcDec {     // block-local output of the parallel-form decimator + carries; freq_offset applied here
@@ -74,56 +84,126 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     static constexpr bool kFix = true;
     TDM_HD double foff(int row) const { return freq_offset ? freq_offset[row] : 0.0; }
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(dec.y0 + (int64_t)row * dec.n_out * 2); }
-    // Operands of a lane's carry responses, requested at the very start of the kernel so that their latency
-    // overlaps the staging of the samples: table rows r0, r0+1 (causal) and r0+La-2, r0+La-1 (anticausal) of the
-    // lane's decimator block and that block's carries.
+    // The decimator's carry responses (y = y0 + T1.Gf + T2.Hb), added to the staged samples in place.  For the La
+    // consecutive outputs of a group they are, per pole pair and direction, a second-order recurrence at the decimated
+    // rate seeded by two table rows.  They decay from the block's ends, so only the groups near a block boundary need them,
+    // and only for the slowly decaying pairs: the plan lists the (group, direction, pairs) items of every chunk, costliest
+    // first (Lp2Params::items), and the workgroup's threads work the list off -- thread k takes item k, whatever group
+    // that is, so that a wavefront's 64 items cost the same.  (Round 2 ran all four pairs in both directions over every
+    // lane's own samples: 768 of the kernel's 4076 vector instructions per lane, for responses that are below 1e-30 of the
+    // signal in three groups out of four.)
+    // operands of a thread's first item, requested before the samples are staged so that their latency overlaps the
+    // staging: the item's two words, its seed rows and its block's carries
     struct Pref {
-        f64x2 t1[2 * PzLayout::kMaxPairs], t2[2 * PzLayout::kMaxPairs], g[2 * PzLayout::kMaxPairs], h[2 * PzLayout::kMaxPairs];
+        int w0 = 0, w1 = 0;
+        f64x2 sd[2 * PzLayout::kMaxPairs], cy[2 * PzLayout::kMaxPairs];
     };
-    TDM_HD void prefetch(const Lp2Params &P, int row, int64_t js, Pref &o) const
+    TDM_HD void item_operands(const Lp2Params &P, int row, int w0, int w1, f64x2 (&sdv)[2 * PzLayout::kMaxPairs], f64x2 (&cyv)[2 * PzLayout::kMaxPairs]) const
     {
-        constexpr int La = kLp2La, ND = PzLayout::kMaxPairs, D = 2 * ND;
-        const int Bn = kWave * dec.L;
-        const int64_t pos = dec.k0L + js * dec.out_stride;
-        const int b = (int)(pos / Bn);
-        const int t = (int)((pos - (int64_t)b * Bn) / (dec.out_stride * La));   // group of La outputs inside the block
+        constexpr int ND = PzLayout::kMaxPairs, D = 2 * ND;
+        const int dir = (w0 >> 8) & 1, b = w1 >> 8, t = w1 & 255;
         const bool last = (b == dec.nb - 1);
-        // the seed rows of all lanes of the chip come from one small table (a few KB, cache-resident): lanes of a
-        // wavefront touch only `groups` distinct entries instead of 64 distinct rows of the full tables
-        const f64x2 *sd = (const f64x2 *)(P.seeds + ((size_t)(last ? P.seed_groups : 0) + t) * kLp2SeedDoubles);
-        const f64x2 *G = (const f64x2 *)(dec.Gf + ((int64_t)row * dec.nb + b) * D * 2);
-        const f64x2 *Hh = (const f64x2 *)(dec.Hb + ((int64_t)row * dec.nb + b) * D * 2);
+        // seed rows of the group: outputs 16t, 16t+1 (causal), 16t+14, 16t+15 (anticausal); the block's carries
+        const f64x2 *sd = (const f64x2 *)(P.seeds + ((size_t)(last ? P.seed_groups : 0) + t) * kLp2SeedDoubles) + (dir ? 2 * ND : 0);   // (rows 16t, 16t+1 or 16t+14, 16t+15)
+        const f64x2 *cy = (const f64x2 *)((dir ? dec.Hb : dec.Gf) + ((int64_t)row * dec.nb + b) * D * 2);
 #pragma unroll
-        for (int k = 0; k < 2 * ND; ++k) { o.t1[k] = sd[k]; o.t2[k] = sd[2 * ND + k]; o.g[k] = G[k]; o.h[k] = Hh[k]; }
+        for (int k = 0; k < 2 * ND; ++k) { sdv[k] = sd[k]; cyv[k] = cy[k]; }
     }
-    // a lane's kLp2La consecutive samples, all inside one decimator block: carry responses by recurrence
-    TDM_HD void finish_lane(const Lp2Params &P, const Pref &o, double *yr, double *yi) const
+    template <class Comm>
+    TDM_HD void prefetch(const Lp2Params &P, int row, int chunk, Comm &cm, Pref &o) const
+    {
+        const int32_t *it = P.items + (size_t)chunk * P.items_stride;
+        const int k = cm.tid();
+        if (k < it[0]) {
+            o.w0 = it[2 + 2 * k];
+            o.w1 = it[3 + 2 * k];
+            item_operands(P, row, o.w0, o.w1, o.sd, o.cy);
+        }
+    }
+    // The decimator's carry responses (y = y0 + T1.Gf + T2.Hb), added to the staged samples in place.  For the La
+    // consecutive outputs of a group they are, per pole pair and direction, a second-order recurrence at the decimated
+    // rate seeded by two table rows.  They decay from the block's ends, so only the groups near a block boundary need them,
+    // and only for the slowly decaying pairs: the plan lists the (group, direction, pairs) items of every chunk, costliest
+    // first (Lp2Params::items), and the workgroup's threads work the list off -- thread k takes item k, whatever group
+    // that is, so that a wavefront's 64 items cost the same.  (Round 2 ran all four pairs in both directions over every
+    // lane's own samples: 768 of the kernel's 4076 vector instructions per lane, for responses that are below 1e-30 of the
+    // signal in three groups out of four.)
+    // Header of a chunk's list: it[0] = items of the first pass, it[1] = items of a second pass behind a barrier (only when
+    // some group has a causal AND an anticausal item, i.e. blocks shorter than twice the reach: the two would update the
+    // same samples), 0 otherwise.
+    // one item: the group's samples leave LDS in the order the recurrence visits them (anticausal: last output first),
+    // take the responses of the pairs in `mask` and go back
+    TDM_HD void run_item(const Lp2Params &P, f64x2 *stage, int w0, const f64x2 (&sdv)[2 * PzLayout::kMaxPairs],
+                         const f64x2 (&cyv)[2 * PzLayout::kMaxPairs]) const
     {
         constexpr int La = kLp2La, ND = PzLayout::kMaxPairs;
+        const int g = w0 & 255, dir = (w0 >> 8) & 1, mask = (w0 >> 9) & 15;
+        const int base = g * La, sw = g & 15;          // lp2_slot(16 g + i) = 16 g + (i ^ (g & 15))
+        const int flip = dir ? La - 1 : 0;             // (La is a power of two: La - 1 - i == i ^ (La - 1))
+        double vr[La], vi[La];
+#pragma unroll
+        for (int i = 0; i < La; ++i) {
+            const f64x2 v = stage[base + ((i ^ flip) ^ sw)];
+            vr[i] = v.x;
+            vi[i] = v.y;
+        }
 #pragma unroll
         for (int s = 0; s < ND; ++s) {
-            // pair s is components 2s, 2s+1 of a table row; g/h hold (re, im) of each carry component
-            const f64x2 ta = o.t1[s], tb = o.t1[ND + s], ua = o.t2[s], ub = o.t2[ND + s];
-            const f64x2 g0 = o.g[2 * s], g1 = o.g[2 * s + 1], h0 = o.h[2 * s], h1 = o.h[2 * s + 1];
+            if (!((mask >> s) & 1)) continue;
+            // pair s is components 2s, 2s+1 of a table row; cy holds (re, im) of each carry component.  Anticausal:
+            // the rows arrive as (16t+14, 16t+15) and are visited last output first
+            const f64x2 r0 = sdv[s], r1 = sdv[ND + s];
+            const f64x2 ta = dir ? r1 : r0, tb = dir ? r0 : r1;
+            const f64x2 g0 = cyv[2 * s], g1 = cyv[2 * s + 1];
             const double p1 = P.dec_p1[s], np2 = -P.dec_p2[s];
-            double c0r = fma(ta.x, g0.x, ta.y * g1.x), c0i = fma(ta.x, g0.y, ta.y * g1.y);   // causal response at sample 0
-            double c1r = fma(tb.x, g0.x, tb.y * g1.x), c1i = fma(tb.x, g0.y, tb.y * g1.y);   // ... 1
-            yr[0] += c0r; yi[0] += c0i; yr[1] += c1r; yi[1] += c1i;
+            double c0r = fma(ta.x, g0.x, ta.y * g1.x), c0i = fma(ta.x, g0.y, ta.y * g1.y);   // response at the first output visited
+            double c1r = fma(tb.x, g0.x, tb.y * g1.x), c1i = fma(tb.x, g0.y, tb.y * g1.y);   // ... the second
+            vr[0] += c0r; vi[0] += c0i; vr[1] += c1r; vi[1] += c1i;
 #pragma unroll
             for (int i = 2; i < La; ++i) {
                 const double nr = fma(p1, c1r, np2 * c0r), ni = fma(p1, c1i, np2 * c0i);
                 c0r = c1r; c0i = c1i; c1r = nr; c1i = ni;
-                yr[i] += nr; yi[i] += ni;
+                vr[i] += nr; vi[i] += ni;
             }
-            double a0r = fma(ub.x, h0.x, ub.y * h1.x), a0i = fma(ub.x, h0.y, ub.y * h1.y);   // anticausal response at sample La-1
-            double a1r = fma(ua.x, h0.x, ua.y * h1.x), a1i = fma(ua.x, h0.y, ua.y * h1.y);   // ... La-2
-            yr[La - 1] += a0r; yi[La - 1] += a0i; yr[La - 2] += a1r; yi[La - 2] += a1i;
+        }
 #pragma unroll
-            for (int i = La - 3; i >= 0; --i) {
-                const double nr = fma(p1, a1r, np2 * a0r), ni = fma(p1, a1i, np2 * a0i);
-                a0r = a1r; a0i = a1i; a1r = nr; a1i = ni;
-                yr[i] += nr; yi[i] += ni;
-            }
+        for (int i = 0; i < La; ++i) stage[base + ((i ^ flip) ^ sw)] = f64x2{vr[i], vi[i]};
+    }
+    // The decimator's carry responses (y = y0 + T1.Gf + T2.Hb), added to the staged samples in place.  For the La
+    // consecutive outputs of a group they are, per pole pair and direction, a second-order recurrence at the decimated
+    // rate seeded by two table rows.  They decay from the block's ends, so only the groups near a block boundary need them,
+    // and only for the slowly decaying pairs: the plan lists the (group, direction, pairs) items of every chunk, costliest
+    // first (Lp2Params::items), and the workgroup's threads work the list off -- thread k takes item k, whatever group
+    // that is, so that a wavefront's 64 items cost the same.  (Round 2 ran all four pairs in both directions over every
+    // lane's own samples: 768 of the kernel's 4076 vector instructions per lane, for responses that are below 1e-30 of the
+    // signal in three groups out of four.)
+    // Header of a chunk's list: it[0] = items of the first pass, it[1] = items of a second pass behind a barrier (only when
+    // some group has a causal AND an anticausal item, i.e. blocks shorter than twice the reach: the two would update the
+    // same samples), 0 otherwise.
+    template <class Comm>
+    TDM_HD void fix_phase(const Lp2Params &P, int row, int chunk, f64x2 *stage, Comm &cm, const Pref &pf) const
+    {
+        constexpr int ND = PzLayout::kMaxPairs;
+        const int32_t *it = P.items + (size_t)chunk * P.items_stride;
+        const int cnt1 = it[0], cnt2 = it[1];
+        if (cm.tid() < cnt1) run_item(P, stage, pf.w0, pf.sd, pf.cy);   // (operands requested before the staging)
+#pragma unroll 1
+        for (int k = cm.tid() + kLp2Lanes; k < cnt1; k += kLp2Lanes) {
+            f64x2 sdv[2 * ND], cyv[2 * ND];
+            const int w0 = it[2 + 2 * k], w1 = it[3 + 2 * k];
+            item_operands(P, row, w0, w1, sdv, cyv);
+            run_item(P, stage, w0, sdv, cyv);
+        }
+        if (cnt2 == 0) return;
+        cm.sync();
+        // (the second pass hands its list out from the last thread downwards: its costly head falls to the wavefronts the
+        // first pass left idle)
+#pragma unroll 1
+        for (int k = kLp2Lanes - 1 - cm.tid(); k < cnt2; k += kLp2Lanes) {
+            f64x2 sdv[2 * ND], cyv[2 * ND];
+            const int w0 = it[2 + 2 * (cnt1 + k)], w1 = it[3 + 2 * (cnt1 + k)];
+            item_operands(P, row, w0, w1, sdv, cyv);
+            run_item(P, stage, w0, sdv, cyv);
         }
     }
 };
@@ -143,8 +223,10 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     // ---------------- input: coalesced through LDS, then each lane takes its La consecutive samples ----------------
     LP2_T0();
     const bool any_sig = (js + La > 0 && js < n);          // the lane holds at least one sample of the row
+    // chunks that hold an end of the row: odd extension and start states (workgroup-uniform)
+    const bool wg_edge = (jc < 0) || (jc + (int64_t)kLp2Span > n);
     typename Src::Pref pref;
-    if (any_sig) src.prefetch(P, row, js, pref);
+    if (Src::kFix) src.prefetch(P, row, chunk, cm, pref);
     {
         const f64x2 *rowp = src.raw_row(row);
         const int64_t jw = jc + (int64_t)wave * (kWave * La);
@@ -171,6 +253,15 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     }
     cm.sync();
     LP2_T(0);
+#ifdef TDM_LP2_MEMONLY   // experiment: loads, staging and stores only (results are wrong, timing only)
+    if (false)
+#else
+    if (Src::kFix)
+#endif
+    {
+        src.fix_phase(P, row, chunk, stage, cm, pref);
+        cm.sync();
+    }
     double yr[La], yi[La];
 #pragma unroll
     for (int i = 0; i < La; ++i) {
@@ -178,37 +269,44 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         yr[i] = v.x;
         yi[i] = v.y;
     }
-    // lanes that hold signal samples: carry responses + NCO (for a lane that is only partly inside the row the values at
-    // positions outside it are meaningless here and are replaced by the odd extension below)
+    // lanes that hold signal samples: NCO (for a lane that is only partly inside the row the values at positions outside
+    // it are meaningless here and are replaced by the odd extension below; lanes outside the row hold zeros)
     const bool inside = (js >= 0 && js + La <= n);
-    if (any_sig) {
-        if (Src::kFix) {
-            const double f = src.foff(row);
+#ifdef TDM_LP2_MEMONLY
+    if (false) {
+#else
+    if (any_sig && Src::kFix) {
+#endif
+        const double f = src.foff(row);
+        if (f != 0.0) {
             NcoRunT<1> nco;
-            if (f != 0.0) nco.init(js, f, src.fs_out);   // (out-of-line sincos first, while few registers are live)
-            src.finish_lane(P, pref, yr, yi);
-            if (f != 0.0) {
+            nco.init(js, f, src.fs_out);
 #pragma unroll
-                for (int i = 0; i < La; ++i) {
-                    double c = nco.ar, sn = nco.ai;
-                    if (i > 0) nco.next(f, src.fs_out, c, sn);
-                    const double a = yr[i], b = yi[i];
-                    yr[i] = a * c - b * sn;
-                    yi[i] = a * sn + b * c;
-                }
+            for (int i = 0; i < La; ++i) {
+                double c = nco.ar, sn = nco.ai;
+                if (i > 0) nco.next(f, src.fs_out, c, sn);
+                const double a = yr[i], b = yi[i];
+                yr[i] = a * c - b * sn;
+                yi[i] = a * sn + b * c;
             }
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < La; ++i) { yr[i] = 0; yi[i] = 0; }
     }
-    // publish the finished samples; the odd extension (scipy odd_ext: 2 x[0] - x[-j], 2 x[n-1] - x[2n-2-j]) of the lanes
-    // around the ends of the row reads them from there
+    LP2_T(1);
+    auto Y = [&](int64_t j) { return stage[lp2_slot((int)(j - jc))]; };
+    // the empty lanes next to the ends of the extended row carry the start states of the two banks (lp2_tables.hpp)
+    const int64_t t_head = ((-(int64_t)edge - jc) >= 0 ? (-(int64_t)edge - jc) / La : -((jc + edge + La - 1) / La)) - 1;   // empty lane before position -edge
+    const int64_t t_l1 = (n + edge - 1 - jc) / La;          // lane holding the last extended sample
+    const int64_t t_tail = (n + edge - jc) / La + 1;        // empty lane after the lane holding position n + edge
+    const bool has_head = wg_edge && (t_head >= 0 && t_head < kLp2Lanes);
+    const bool has_tail = wg_edge && (n + edge - 1 - jc >= 0 && t_tail < kLp2Lanes && t_l1 >= 0);
+    double e0r = 0, e0i = 0, xlr = 0, xli = 0;
+    if (wg_edge) {
+    // a chunk that holds an end of the row: publish the finished samples; the odd extension (scipy odd_ext: 2 x[0] - x[-j],
+    // 2 x[n-1] - x[2n-2-j]) of the lanes around the end reads them from there.  (Interior chunks -- six of the eight of a
+    // 26 215-sample row -- skip the sixteen stores, the barrier and everything below.)
 #pragma unroll
     for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{yr[i], yi[i]};
     cm.sync();
-    LP2_T(1);
-    auto Y = [&](int64_t j) { return stage[lp2_slot((int)(j - jc))]; };
     if (!inside) {
 #pragma unroll
         for (int i = 0; i < La; ++i) {
@@ -227,13 +325,6 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
             }
         }
     }
-    // the empty lanes next to the ends of the extended row carry the start states of the two banks (lp2_tables.hpp)
-    const int64_t t_head = ((-(int64_t)edge - jc) >= 0 ? (-(int64_t)edge - jc) / La : -((jc + edge + La - 1) / La)) - 1;   // empty lane before position -edge
-    const int64_t t_l1 = (n + edge - 1 - jc) / La;          // lane holding the last extended sample
-    const int64_t t_tail = (n + edge - jc) / La + 1;        // empty lane after the lane holding position n + edge
-    const bool has_head = (t_head >= 0 && t_head < kLp2Lanes);
-    const bool has_tail = (n + edge - 1 - jc >= 0 && t_tail < kLp2Lanes && t_l1 >= 0);
-    double e0r = 0, e0i = 0, xlr = 0, xli = 0;
     if (has_head && tid == t_head) {
         const f64x2 a = Y(0), b = Y(edge);
         e0r = 2 * a.x - b.x;
@@ -244,7 +335,14 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         xlr = 2 * a.x - b.x;
         xli = 2 * a.y - b.y;
     }
+    }   // wg_edge
 
+#ifdef TDM_LP2_MEMONLY
+    double or_[La], oi[La];
+#pragma unroll
+    for (int i = 0; i < La; ++i) { or_[i] = yr[i]; oi[i] = yi[i]; }
+    (void)e0r; (void)e0i; (void)xlr; (void)xli; (void)has_head; (void)lane;
+#else
     // (requested here, used by the scans: the latency overlaps pass 1)
     double lmf[NP][4], lmb[NP][4];   // C^(La (k+1)), k = lane's distance to the previous / next row of 16 lanes (scan)
     {
@@ -286,26 +384,22 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     }
     LP2_T(2);
     // ---------------- scans.  dir 0: causal (inclusive from the left); dir 1: anticausal (from the right) ----------------
-#pragma unroll
-    for (int dir = 0; dir < 2; ++dir) {
+    // Per direction: (1) four Kogge-Stone steps inside each row of 16 lanes (DPP row shifts), the row's total to LDS;
+    // (2) after ONE barrier every lane forms the state that enters its row from the totals of the P.scan_rows rows before
+    // it (Horner in C^(16 La); the filter's memory has decayed below 1e-24 beyond that: two rows at the usual cutoffs),
+    // adds its share C^(La (k+1)) of it and takes its start state from its neighbour inside the row.
+    // Round 2 passed row totals on with two more cross-lane steps (the anticausal ones through ds_bpermute), then wave
+    // totals through LDS and a serial loop over the other wavefronts with a scalar load per turn: six barriers and a long
+    // chain of dependent round trips -- a quarter of the kernel's time for a seventh of its instructions.
+    // The two directions are independent EXCEPT in the chunk that holds the end of the row, where the anticausal bank
+    // starts from the causal bank's state there (scipy: zi * forward[last]): that chunk runs them one after the other.
+    constexpr int kRows = kLp2Lanes / 16;
+    static_assert(2 * kRows * NP * 4 <= Lp2Lds::oPow, "row totals of both directions");
+    double *tail_cst = small + Lp2Lds::oPow;     // (the power partials' area is free until the output stage)
+    auto scan_rows = [&](auto dir_c) __attribute__((always_inline)) {
+        constexpr int dir = decltype(dir_c)::value;
         double(*vr)[2] = dir == 0 ? zr : ur;
         double(*vq)[2] = dir == 0 ? zq : uq;
-        if (dir == 1) {
-            // the anticausal bank starts from the causal bank's state at the end of the row (scipy: zi * forward[last])
-            if (has_tail && tid == t_tail) {
-                const double *cst = small + Lp2Lds::oTot + 128;   // causal state of lane t_l1, left there below
-                const double *tm = P.cst + Lp2Cst::tail_m, *tx = P.cst + Lp2Cst::tail_x;
-#pragma unroll
-                for (int r = 0; r < kLp2D; ++r) {
-                    double ar = tx[r] * xlr, ai = tx[r] * xli;
-#pragma unroll
-                    for (int k = 0; k < kLp2D; ++k) { ar = fma(tm[r * kLp2D + k], cst[2 * k], ar); ai = fma(tm[r * kLp2D + k], cst[2 * k + 1], ai); }
-                    vr[r / 2][r % 2] = ar;
-                    vq[r / 2][r % 2] = ai;
-                }
-            }
-        }
-        // inside a wavefront: four steps inside each row of 16 lanes, then the row totals are passed on twice
         const double *Msc = P.cst + Lp2Cst::Mscan;
         TDM_OPAQUE_SPTR(Msc);
 #pragma unroll
@@ -326,95 +420,106 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
                 vq[s][1] = fma(M[2], jq[s][0], fma(M[3], jq[s][1], q1));
             }
         }
+        LP2_T(7 + 4 * dir);
+        // the row's total: [dir][row of the workgroup][pair][4]
+        if ((lane & 15) == (dir == 0 ? 15 : 0)) {
+            double *o = small + Lp2Lds::oTot + ((dir * kRows + (tid >> 4)) * NP) * 4;
 #pragma unroll
-        for (int step = 0; step < 2; ++step) {
-            double jr[NP][2], jq[NP][2];
-#pragma unroll
-            for (int s = 0; s < NP; ++s) {
-                if (dir == 0) cm.template row_total_prev2<2>(vr[s], vq[s], jr[s], jq[s], step);
-                else cm.template row_total_next2<2>(vr[s], vq[s], jr[s], jq[s], step);
-            }
-#pragma unroll
-            for (int s = 0; s < NP; ++s) {
-                if (step == 1) {
-                    const auto M = TDM_CPTR(P.cst + Lp2Cst::Mrow + s * 4);
-                    const bool far = dir == 0 ? lane >= 48 : lane < 16;
-                    const double a0 = fma(M[0], jr[s][0], M[1] * jr[s][1]), a1 = fma(M[2], jr[s][0], M[3] * jr[s][1]);
-                    const double b0 = fma(M[0], jq[s][0], M[1] * jq[s][1]), b1 = fma(M[2], jq[s][0], M[3] * jq[s][1]);
-                    jr[s][0] = far ? a0 : jr[s][0]; jr[s][1] = far ? a1 : jr[s][1];
-                    jq[s][0] = far ? b0 : jq[s][0]; jq[s][1] = far ? b1 : jq[s][1];
-                }
-                const double *M = dir == 0 ? lmf[s] : lmb[s];
-                const double o0 = vr[s][0], o1 = vr[s][1], q0 = vq[s][0], q1 = vq[s][1];
-                vr[s][0] = fma(M[0], jr[s][0], fma(M[1], jr[s][1], o0));
-                vr[s][1] = fma(M[2], jr[s][0], fma(M[3], jr[s][1], o1));
-                vq[s][0] = fma(M[0], jq[s][0], fma(M[1], jq[s][1], q0));
-                vq[s][1] = fma(M[2], jq[s][0], fma(M[3], jq[s][1], q1));
-            }
+            for (int s = 0; s < NP; ++s) { o[s * 4] = vr[s][0]; o[s * 4 + 1] = vr[s][1]; o[s * 4 + 2] = vq[s][0]; o[s * 4 + 3] = vq[s][1]; }
         }
-        // across the wavefronts of the workgroup: totals through LDS, each wavefront forms the prefix that enters it
-        double *tot = small + Lp2Lds::oTot;   // [wave][pair][4]
-        cm.sync();                            // (previous use of the area)
-        if (lane == (dir == 0 ? kWave - 1 : 0)) {
-#pragma unroll
-            for (int s = 0; s < NP; ++s) {
-                double *o = tot + (wave * NP + s) * 4;
-                o[0] = vr[s][0]; o[1] = vr[s][1]; o[2] = vq[s][0]; o[3] = vq[s][1];
-            }
-        }
-        cm.sync();
-        double pr[NP][2], pq[NP][2];   // state entering this wavefront
+        LP2_T(8 + 4 * dir);
+    };
+    auto scan_apply = [&](auto dir_c) __attribute__((always_inline)) {
+        constexpr int dir = decltype(dir_c)::value;
+        double(*vr)[2] = dir == 0 ? zr : ur;
+        double(*vq)[2] = dir == 0 ? zq : uq;
+        const double *tot = small + Lp2Lds::oTot + dir * (kRows * NP * 4);
+        const int g = tid >> 4;                  // the lane's row in the workgroup
+        double pr[NP][2], pq[NP][2];             // state entering the row
 #pragma unroll
         for (int s = 0; s < NP; ++s) { pr[s][0] = 0; pr[s][1] = 0; pq[s][0] = 0; pq[s][1] = 0; }
+        double mrow[NP][4];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const auto M = TDM_CPTR(P.cst + Lp2Cst::Mrow + s * 4);
+            mrow[s][0] = M[0]; mrow[s][1] = M[1]; mrow[s][2] = M[2]; mrow[s][3] = M[3];
+        }
 #pragma unroll 1
-        for (int k = 1; k < kLp2Waves; ++k) {
-            // wavefronts in order of increasing distance ... processed from the farthest: P <- C^(64 La) P + T_v
-            const int v = dir == 0 ? k - 1 : kLp2Waves - k;          // causal: v = 0 .. wave-1 ; anticausal: v = W-1 .. wave+1
-            const bool use = dir == 0 ? (v < wave) : (v > wave);
-            if (!use) continue;
+        for (int i = P.scan_rows; i >= 1; --i) {          // the farthest row first: P <- C^(16 La) P + T
+            const int src = dir == 0 ? g - i : g + i;
+            const bool in = src >= 0 && src < kRows;      // (rows beyond the workgroup: zero -- that is what the halo is for)
+            const double *t = tot + (in ? src : g) * (NP * 4);
 #pragma unroll
             for (int s = 0; s < NP; ++s) {
-                const auto M = TDM_CPTR(P.cst + Lp2Cst::Mwave + s * 4);
-                const double *t = tot + (v * NP + s) * 4;
-                const double a0 = fma(M[0], pr[s][0], fma(M[1], pr[s][1], t[0]));
-                const double a1 = fma(M[2], pr[s][0], fma(M[3], pr[s][1], t[1]));
-                const double b0 = fma(M[0], pq[s][0], fma(M[1], pq[s][1], t[2]));
-                const double b1 = fma(M[2], pq[s][0], fma(M[3], pq[s][1], t[3]));
+                const double t0 = in ? t[s * 4] : 0.0, t1 = in ? t[s * 4 + 1] : 0.0, t2 = in ? t[s * 4 + 2] : 0.0, t3 = in ? t[s * 4 + 3] : 0.0;
+                const double a0 = fma(mrow[s][0], pr[s][0], fma(mrow[s][1], pr[s][1], t0));
+                const double a1 = fma(mrow[s][2], pr[s][0], fma(mrow[s][3], pr[s][1], t1));
+                const double b0 = fma(mrow[s][0], pq[s][0], fma(mrow[s][1], pq[s][1], t2));
+                const double b1 = fma(mrow[s][2], pq[s][0], fma(mrow[s][3], pq[s][1], t3));
                 pr[s][0] = a0; pr[s][1] = a1; pq[s][0] = b0; pq[s][1] = b1;
             }
         }
-        {
-            // every lane: true inclusive state = in-wave value + C^(La (distance in lanes)) * prefix
-            const int kk = dir == 0 ? lane : kWave - 1 - lane;
-            const f64x2 *tm = (const f64x2 *)P.lane_m + (size_t)kk * NP * 2;
+        LP2_T(9 + 4 * dir);
+        // every lane: true inclusive state = in-row value + C^(La (position in the row + 1)) * (state entering the row)
 #pragma unroll
-            for (int s = 0; s < NP; ++s) {
-                const f64x2 m0 = tm[s * 2], m1 = tm[s * 2 + 1];
-                vr[s][0] = fma(m0.x, pr[s][0], fma(m0.y, pr[s][1], vr[s][0]));
-                vr[s][1] = fma(m1.x, pr[s][0], fma(m1.y, pr[s][1], vr[s][1]));
-                vq[s][0] = fma(m0.x, pq[s][0], fma(m0.y, pq[s][1], vq[s][0]));
-                vq[s][1] = fma(m1.x, pq[s][0], fma(m1.y, pq[s][1], vq[s][1]));
-            }
+        for (int s = 0; s < NP; ++s) {
+            const double *M = dir == 0 ? lmf[s] : lmb[s];
+            vr[s][0] = fma(M[0], pr[s][0], fma(M[1], pr[s][1], vr[s][0]));
+            vr[s][1] = fma(M[2], pr[s][0], fma(M[3], pr[s][1], vr[s][1]));
+            vq[s][0] = fma(M[0], pq[s][0], fma(M[1], pq[s][1], vq[s][0]));
+            vq[s][1] = fma(M[2], pq[s][0], fma(M[3], pq[s][1], vq[s][1]));
         }
         if (dir == 0 && has_tail && tid == t_l1) {
-            double *cst = small + Lp2Lds::oTot + 128;
 #pragma unroll
             for (int s = 0; s < NP; ++s) {
-                cst[(2 * s) * 2] = vr[s][0]; cst[(2 * s) * 2 + 1] = vq[s][0];
-                cst[(2 * s + 1) * 2] = vr[s][1]; cst[(2 * s + 1) * 2 + 1] = vq[s][1];
+                tail_cst[(2 * s) * 2] = vr[s][0]; tail_cst[(2 * s) * 2 + 1] = vq[s][0];
+                tail_cst[(2 * s + 1) * 2] = vr[s][1]; tail_cst[(2 * s + 1) * 2 + 1] = vq[s][1];
             }
         }
-        // start state of a lane = inclusive state of its neighbour (the wavefront's prefix at the wavefront's edge)
+        // start state of a lane = inclusive state of its neighbour in the row; the row's first lane starts from the state
+        // that enters the row
         double sr[NP][2], sq[NP][2];
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
-            if (dir == 0) cm.template wave_shr1<2>(vr[s], vq[s], sr[s], sq[s]);
-            else cm.template wave_shl1<2>(vr[s], vq[s], sr[s], sq[s]);
-            const bool at_edge = dir == 0 ? lane == 0 : lane == kWave - 1;
+            if (dir == 0) cm.template row_shr2<2>(vr[s], vq[s], sr[s], sq[s], 1);
+            else cm.template row_shl2<2>(vr[s], vq[s], sr[s], sq[s], 1);
+            const bool at_edge = (lane & 15) == (dir == 0 ? 0 : 15);
             vr[s][0] = at_edge ? pr[s][0] : sr[s][0]; vr[s][1] = at_edge ? pr[s][1] : sr[s][1];
             vq[s][0] = at_edge ? pq[s][0] : sq[s][0]; vq[s][1] = at_edge ? pq[s][1] : sq[s][1];
         }
-        if (dir == 0) cm.sync();   // (cst visible before the anticausal start is formed)
+        LP2_T(10 + 4 * dir);
+    };
+    using D0 = std::integral_constant<int, 0>;
+    using D1 = std::integral_constant<int, 1>;
+    if (!has_tail) {
+        scan_rows(D0{});
+        TDM_SCHED_FENCE();   // (one direction after the other: interleaved, their temporaries overflow the register file)
+        scan_rows(D1{});
+        cm.sync();
+        LP2_T(15);
+        scan_apply(D0{});
+        TDM_SCHED_FENCE();
+        scan_apply(D1{});
+    } else {
+        scan_rows(D0{});
+        cm.sync();
+        scan_apply(D0{});
+        cm.sync();   // (the causal state at the end of the row visible)
+        if (tid == t_tail) {
+            // the anticausal bank starts from the causal bank's state at the end of the row (scipy: zi * forward[last])
+            const double *tm = P.cst + Lp2Cst::tail_m, *tx = P.cst + Lp2Cst::tail_x;
+#pragma unroll
+            for (int r = 0; r < kLp2D; ++r) {
+                double ar = tx[r] * xlr, ai = tx[r] * xli;
+#pragma unroll
+                for (int k = 0; k < kLp2D; ++k) { ar = fma(tm[r * kLp2D + k], tail_cst[2 * k], ar); ai = fma(tm[r * kLp2D + k], tail_cst[2 * k + 1], ai); }
+                ur[r / 2][r % 2] = ar;
+                uq[r / 2][r % 2] = ai;
+            }
+        }
+        scan_rows(D1{});
+        cm.sync();
+        scan_apply(D1{});
     }
     LP2_T(3);
     // ---------------- pass 2: recurrences from the true start states, outputs accumulated ----------------
@@ -442,6 +547,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
             a2r = a1r; a1r = vr_; a2q = a1q; a1q = vq_;
         }
     }
+#endif   // TDM_LP2_MEMONLY
     LP2_T(4);
     // ---------------- output: through LDS; one thread per (timing phase, group) stores its phase's samples and sums their powers ----------------
     cm.sync();   // (all lanes have taken their input out of the staging area)

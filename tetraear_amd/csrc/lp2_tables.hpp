@@ -4,6 +4,7 @@
 // carrier's low-rate samples plus a halo on either side.  The halo is long enough for the filter's memory to decay
 // below 1e-21 (five decades under the rounding of the samples themselves), so chunks need no carries from their neighbours and the filter output is final when it is written.
 #pragma once
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -28,6 +29,7 @@ struct Lp2Params {
     int32_t n_chunks;
     int32_t sps;        // timing phases for the power partials (extract_symbols), 0 = none
     int32_t edge;       // odd-extension length (15)
+    int32_t scan_rows;  // rows of 16 lanes whose totals still reach a lane's start state (|C^(16 La k)| < 1e-24 beyond)
     // ---- channel filter in parallel form
     double na1[kLp2Pairs], na2[kLp2Pairs], b0[kLp2Pairs], b1[kLp2Pairs], dx;
     // constant block in device memory (read with scalar loads where it is used; as kernel arguments the matrices would
@@ -41,6 +43,16 @@ struct Lp2Params {
     // first the regular blocks' tables, then the last block's
     const double *seeds;
     int32_t seed_groups;   // groups per decimator block + 1
+    // The carry responses decay from the block's ends (pole pair s by |lambda_s|^q per output): a group of La outputs
+    // needs pair s's causal response only within reach_s outputs of its block's start and the anticausal one within
+    // reach_s of its end (beyond, the response is below kLp2FixTol of the signal).  The (group, direction, pairs) items a
+    // chunk needs are listed on the host, costliest first, so that the wavefronts of the workgroup that work them off
+    // hold items of equal cost:  two words per item after a two-word header:
+    //   w0 = group in the workgroup's span | direction << 8 | pair mask << 9,   w1 = decimator block << 8 | group in block
+    // with header items[chunk * items_stride + 0 / 1] = items of the first pass / of a second pass behind a barrier (used
+    // only when some group has an item in both directions: then causal items first, anticausal second)
+    const int32_t *items;
+    int32_t items_stride;
     // ---- outputs
     double *zt;          // [rows][sps][zt_k] c128: filter output, phase-major (sample p + sps*k at [p][k]); plain [n] when sps == 0
     int64_t zt_k;
@@ -63,8 +75,12 @@ struct Lp2Cst {   // offsets (doubles) into Lp2Params::cst
 struct Lp2Host {
     Lp2Params p;
     std::vector<double> lane_m, seeds, cst;
+    std::vector<double> items;   // int32 words, two per double slot (kept in the plan's table blob of doubles)
     bool ok = false;
 };
+// what a group may ignore of a carry response (relative to a unit carry; the carries are O(100) x the signal, the
+// responses start at O(10)): twelve decades under one rounding of a sample
+constexpr long double kLp2FixTol = 1e-30L;
 
 // sos: the channel filter as biquads g*[1,2,1]/a (Tf4::sos); dec: the decimator's tables when its output feeds this
 // stage (parallel form only), else null
@@ -123,6 +139,63 @@ inline Lp2Host build_lp2(const double (*sos)[6], int64_t n, int edge, int sps, c
     }
     p.n_chunks = (int32_t)((n + p.off + p.U - 1) / p.U);
     p.dx = (double)dz.dx;
+    if (dec) {
+        // ---- fix-up items of every chunk (see Lp2Params::items)
+        const int q = dec->out_stride, nsec = dec->nsec;
+        const int64_t Bn = (int64_t)kWave * dec->L;
+        int reach[PzLayout::kMaxPairs] = {0, 0, 0, 0};   // outputs
+        for (int s = 0; s < nsec; ++s) {
+            const ldbl mu = std::sqrt(std::fabs((ldbl)p.dec_p2[s]));   // |lambda_s|^q
+            reach[s] = mu < 1 ? (int)std::ceil(std::log(kLp2FixTol) / std::log(mu)) : (1 << 30);
+        }
+        std::vector<std::vector<int32_t>> per_chunk(p.n_chunks);
+        size_t max_words = 0;
+        for (int c = 0; c < p.n_chunks; ++c) {
+            const int64_t jc = (int64_t)c * p.U - p.H - p.off;
+            std::vector<std::pair<int, std::pair<int32_t, int32_t>>> it;   // (cost key, words)
+            bool both = false;
+            for (int g = 0; g < kLp2Lanes; ++g) {
+                const int64_t js = jc + (int64_t)g * La;
+                if (!(js + La > 0 && js < n)) continue;                 // no sample of the row in this group
+                const int64_t pos = dec->k0L + js * q;                  // extended-domain index of the group's first output
+                if (pos < 0) continue;                                  // (a group wholly before the row is excluded above; partly: its row samples start at 0)
+                const int b = (int)(pos / Bn);
+                const int64_t m = pos - (int64_t)b * Bn;                // in-block offset (input samples), a multiple of q
+                const int t = (int)(m / ((int64_t)q * La));
+                const int64_t len_b = b == dec->nb - 1 ? dec->len_last : Bn;
+                const int64_t d_c = m / q;                               // outputs between the block's start and the group
+                int64_t d_a = (len_b - 1 - (m + (int64_t)(La - 1) * q)) / q;   // ... between the group's last output and the block's end
+                if (d_a < 0) d_a = 0;
+                int mc = 0, ma = 0;
+                for (int s = 0; s < nsec; ++s) {
+                    if (d_c < reach[s]) mc |= 1 << s;
+                    if (d_a < reach[s]) ma |= 1 << s;
+                }
+                auto bits = [](int v) { int k = 0; for (; v; v &= v - 1) ++k; return k; };
+                if (mc && ma) both = true;
+                // sort key (filled in below): pass, then costliest first
+                if (mc) it.push_back({16 - bits(mc), {g | (0 << 8) | (mc << 9), (b << 8) | t}});
+                if (ma) it.push_back({16 - bits(ma) + 1000, {g | (1 << 8) | (ma << 9), (b << 8) | t}});
+            }
+            // one pass when no group has an item in both directions (long decimator blocks: the usual case); otherwise the
+            // causal items, a barrier, the anticausal items
+            if (!both)
+                for (auto &e : it) e.first %= 1000;
+            std::stable_sort(it.begin(), it.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            auto &w = per_chunk[c];
+            int n_1 = 0;
+            for (auto &e : it) n_1 += e.first < 1000;
+            w.push_back(n_1);
+            w.push_back((int32_t)it.size() - n_1);
+            for (auto &e : it) { w.push_back(e.second.first); w.push_back(e.second.second); }
+            if (w.size() > max_words) max_words = w.size();
+        }
+        p.items_stride = (int32_t)((max_words + 1) & ~(size_t)1);
+        std::vector<int32_t> flat((size_t)p.items_stride * p.n_chunks, 0);
+        for (int c = 0; c < p.n_chunks; ++c) std::copy(per_chunk[c].begin(), per_chunk[c].end(), flat.begin() + (size_t)c * p.items_stride);
+        h.items.assign(flat.size() / 2, 0.0);
+        std::memcpy(h.items.data(), flat.data(), flat.size() * sizeof(int32_t));
+    }
     h.lane_m.assign((size_t)kWave * NP * 4, 0.0);
     h.cst.assign(Lp2Cst::size, 0.0);
     double *cst = h.cst.data();
@@ -179,6 +252,20 @@ inline Lp2Host build_lp2(const double (*sos)[6], int64_t n, int edge, int sps, c
                 }
             }
         }
+    }
+    {
+        // how many rows of 16 lanes back the scan has to look: the state entering a row from k rows away has passed
+        // through C^(16 La (k-1)) at least
+        int k = 1;
+        for (; k < kLp2Lanes / 16; ++k) {
+            ldbl worst = 0;
+            for (int s = 0; s < NP; ++s) {
+                const M2 m = m2pow(dz.C[s], 16L * La * k);
+                worst = std::fmax(worst, std::fmax(std::fmax(std::fabs(m.a), std::fabs(m.b)), std::fmax(std::fabs(m.c), std::fabs(m.d))));
+            }
+            if (worst < 1e-24L) break;
+        }
+        p.scan_rows = k;
     }
     p.zt_k = sps > 0 ? (n + sps - 1) / sps : n;
     h.ok = true;

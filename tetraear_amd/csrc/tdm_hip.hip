@@ -491,6 +491,7 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
     const size_t o_raw = h.raw_S ? put(h.dec_raw.blob) : 0;
     const size_t o_lm = h.lp2.ok ? put(h.lp2.lane_m) : 0, o_lc = h.lp2.ok ? put(h.lp2.cst) : 0, o_ls = h.lp2.ok ? put(h.lp2.seeds) : 0;
     const size_t o_rc = h.raw_S ? put(h.lp2_raw.cst) : 0, o_rs = h.raw_S ? put(h.lp2_raw.seeds) : 0;
+    const size_t o_li = h.lp2.ok ? put(h.lp2.items) : 0, o_ri = h.raw_S ? put(h.lp2_raw.items) : 0;
     if (!tab.empty()) {
         HIP_TRY(hipMalloc(&v->d_tab, tab.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(v->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -553,6 +554,7 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
         v->lp2.lane_m = v->d_tab + o_lm;
         v->lp2.cst = v->d_tab + o_lc;
         if (!h.lp2.seeds.empty()) v->lp2.seeds = v->d_tab + o_ls;
+        if (!h.lp2.items.empty()) v->lp2.items = (const int32_t *)(v->d_tab + o_li);
         if (h.raw_S) {
             // the raw-integer decimator's geometry: own tables and work buffers, same low-rate outputs
             // (the edge constants depend on the lane grid's offset, which follows the decimator's block geometry)
@@ -562,6 +564,7 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
             v->lp2_raw.lane_m = v->lp2.lane_m;
             v->lp2_raw.cst = v->d_tab + o_rc;
             v->lp2_raw.seeds = v->d_tab + o_rs;
+            v->lp2_raw.items = (const int32_t *)(v->d_tab + o_ri);
         }
     }
     if (need_y) { v->d_y = w; w += nd; }
