@@ -21,7 +21,10 @@ class WidebandReceiver:
     """`streams` wideband streams of `n_in` samples at `sample_rate` -> M channels each, spaced
     sample_rate/M and decimated by D (channel rate sample_rate/D), all demodulated per call."""
 
-    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0):
+    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0, slots=1):
+        """slots = 2: two independent (channel buffer, demodulator plan) pairs, each with its own stream.  Consecutive
+        batches go to alternating slots (enqueue(slot=k % 2)), so the channeliser of batch k+1 -- bound by its output
+        stores -- runs beside the demodulation of batch k -- bound by instruction issue -- instead of behind it."""
         self.lib = _lib.load()
         self.fmt = _FMT_OF[fmt]
         self.device = device
@@ -29,10 +32,14 @@ class WidebandReceiver:
         self.n_out = (self.n_in + self.D - 1) // self.D
         self.pitch = aligned_pitch(self.n_out)
         self.d_in = DeviceBuffer(device, self.streams * self.n_in * FMT_BYTES[self.fmt])
-        self.d_ch = DeviceBuffer(device, self.streams * self.M * self.pitch * 8)
-        self.demod = BatchDemodulator(self.sample_rate / self.D, self.n_out, self.streams * self.M, "cf32",
-                                      device=device, mode=MODE_TETRA)
-        self.demod.alloc_device_io()
+        self.slots = []
+        for _ in range(int(slots)):
+            d_ch = DeviceBuffer(device, self.streams * self.M * self.pitch * 8)
+            demod = BatchDemodulator(self.sample_rate / self.D, self.n_out, self.streams * self.M, "cf32",
+                                     device=device, mode=MODE_TETRA)
+            demod.alloc_device_io()
+            self.slots.append((d_ch, demod))
+        self.d_ch, self.demod = self.slots[0]
 
     def process(self, iq):
         """iq: the streams back to back in the plan's wire format.  Returns (hard, n_sym, timing, margin):
@@ -48,22 +55,30 @@ class WidebandReceiver:
         n_sym = np.maximum(n_soft - 1, 0).reshape(shape)
         return hard.reshape(shape + (-1,)), n_sym, timing.reshape(shape), margin.reshape(shape)
 
-    def enqueue(self):
-        """channeliser and demodulator back to back on the demodulator plan's stream (no host synchronisation)"""
+    def enqueue(self, slot=0, d_in=None):
+        """channeliser and demodulator back to back on the slot's demodulator plan's stream (no host synchronisation);
+        `d_in`: another device input buffer than the receiver's own (a capture loop's second read buffer)"""
         no = C.c_int64()
-        self.demod.make_stream_current()
+        d_ch, demod = self.slots[slot]
+        demod.make_stream_current()
         try:
-            check(self.lib.tdm_channelise_batch(self.d_in.ptr, self.fmt, self.n_in, self.streams, self.M, self.D,
-                                                self.d_ch.ptr, self.pitch, C.byref(no), 1, self.device))
-            self.demod.enqueue(iq_ptr=self.d_ch.ptr, stride=self.pitch)
+            check(self.lib.tdm_channelise_batch((d_in or self.d_in).ptr, self.fmt, self.n_in, self.streams, self.M, self.D,
+                                                d_ch.ptr, self.pitch, C.byref(no), 1, self.device))
+            demod.enqueue(iq_ptr=d_ch.ptr, stride=self.pitch)
         finally:
-            self.demod.release_stream()
+            demod.release_stream()
+
+    def sync(self):
+        for _, demod in self.slots:
+            demod.sync()
 
     def channel_frequency(self, k):
         """centre frequency of channel k relative to the stream's centre [Hz]"""
         return (k if k < self.M // 2 else k - self.M) * self.sample_rate / self.M
 
     def close(self):
-        self.demod.close()
+        for d_ch, demod in self.slots:
+            demod.close()
+            d_ch.free()
+        self.slots = []
         self.d_in.free()
-        self.d_ch.free()

@@ -6,6 +6,7 @@ TAG=$1; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+python tools/hbm_ceiling.py $OUT/hbm_ceiling.json > /dev/null 2>&1
 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
 # per-kernel time (same command, fewer steps)

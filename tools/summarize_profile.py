@@ -39,7 +39,7 @@ def main():
     src = os.path.join(HERE, "gpurun_out", tag)
     dst = os.path.join(HERE, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for name in ("bench", "bench_forcedist_rccl", "bench_strong1024", "bench_tetra", "bench_pfb", "bench_single", "bench_cf64_256", "bench_shared64", "bench_wideband"):
+    for name in ("hbm_ceiling", "bench", "bench_forcedist_rccl", "bench_strong1024", "bench_tetra", "bench_pfb", "bench_single", "bench_cf64_256", "bench_shared64", "bench_wideband"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(dst, f"{tag}_{name}.json"))
