@@ -80,9 +80,9 @@ __device__ __forceinline__ float2 farrow_eval(const FarrowTaps &f)
     return make_float2(r.x, r.y);
 }
 // piecewise-linear timing estimate at sample position pos (sub-block centres at (b+0.5)*TB)
-__device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
+__device__ __forceinline__ float tau_at(const float2 *tau, int nb, double pos)
 {
-    if (nb == 1) return tau[0];   // (tau: ring of kTauRing estimates)
+    if (nb == 1) return tau[0].x;   // (tau: ring of kTauRing estimates, each with its successor: see the kernel)
     const double u = pos / (double)kTimingBlock - 0.5;
     int b0 = (int)floor(u);
     if (b0 < 0) b0 = 0;
@@ -90,7 +90,7 @@ __device__ __forceinline__ float tau_at(const float *tau, int nb, double pos)
     double f = u - (double)b0;
     if (f < 0.0) f = 0.0;
     if (f > 1.0) f = 1.0;
-    return (float)((double)tau[b0 & (kTauRing - 1)] * (1.0 - f) + (double)tau[(b0 + 1) & (kTauRing - 1)] * f);
+    return (float)((double)tau[b0 & (kTauRing - 1)].x * (1.0 - f) + (double)tau[(b0 + 1) & (kTauRing - 1)].x * f);
 }
 
 
@@ -161,9 +161,12 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     __shared__ float2 yring[kRing + 4];   // + the first three samples again past the end: a symbol's four never wrap
     constexpr int kCstRing = 4 * kTileBlocks;   // the statistic of the previous and the current tile's sub-blocks, and zeros in the next tile's slots
     __shared__ float2 Cst[kCstRing];
-    __shared__ float tau[kTauRing];
+    // timing estimates: slot b holds (tau_b, tau_{b+1}) -- the pair a symbol's interpolation needs comes out of one 8-byte
+    // read; the second half of a slot is written when the next estimate is formed (same round, or the first lane of the
+    // next round's duty wavefront), the last sub-block's successor is itself
+    __shared__ float2 tau[kTauRing];
     __shared__ float tau_mid_s;
-    __shared__ float sm[kRrcThreads / 64];
+    __shared__ float sm[kRrcThreads / 64], sm2[kRrcThreads / 64];
     __shared__ float delta_s;
     const int row = blockIdx.x;
     const int tid = threadIdx.x;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         TT_MARK(6)
         if (est_duty) {
 #ifndef TDM_TETRA_EST_ALL
-            if (b_done > 0) tau_prev = tau[(b_done - 1) & (kTauRing - 1)];   // (the last estimate of the previous duty wavefront)
+            if (b_done > 0) tau_prev = tau[(b_done - 1) & (kTauRing - 1)].x;   // (the last estimate of the previous duty wavefront)
 #endif
             const int lane = tid & 63;
             const int cnt = b_known - b_done + 1;   // <= kTileBlocks + kTimingHalfWin
@@ -454,9 +457,14 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 stp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, stp), 0x142, 0x2, 0xf, false));   // row_bcast:15 into row 1
             tb += stp;
             tau_prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tb), cnt - 1));
-            if (lane < cnt) {
-                tau[b & (kTauRing - 1)] = tb;
-                if (b == nb / 2) tau_mid_s = tb;
+            {
+                // the successor's estimate from the lane to the right (wave_shl:1); the last new sub-block has none yet
+                const float nxt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tb), 0x130, 0xf, 0xf, false));
+                if (lane < cnt) {
+                    tau[b & (kTauRing - 1)] = make_float2(tb, (lane == cnt - 1) ? tb : nxt);
+                    if (b == nb / 2) tau_mid_s = tb;
+                }
+                if (lane == 0 && b_done > 0) tau[(b_done - 1) & (kTauRing - 1)].y = tb;
             }
         }
         b_done = b_known + 1;
@@ -517,8 +525,9 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 const int b0 = max(min(t >> 8, b0_max), 0);
                 static_assert(kTimingBlock == 256, "shift");
                 ff[u] = __builtin_amdgcn_fmed3f(((float)(t - (b0 << 8)) + tk[u]) * (1.f / (float)kTimingBlock), 0.f, 1.f);
-                ta[u] = tau[b0 & (kTauRing - 1)];
-                tb2[u] = tau[min(b0 + 1, nb - 1) & (kTauRing - 1)];
+                const float2 tp = tau[b0 & (kTauRing - 1)];   // (tau_b0, tau_{b0+1}: b0 + 1 <= b_known <= nb - 1, or nb == 1: its own)
+                ta[u] = tp.x;
+                tb2[u] = tp.y;
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
@@ -677,14 +686,27 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         products(c0, d);
         power4(d);
     }
-    a4r = block_sum(a4r, sm);
-    a4i = block_sum(a4i, sm);
-    if (tid == 0) delta_s = (a4r == 0.f && a4i == 0.f) ? 0.f : atan2f(-a4i, -a4r) * 0.25f;
-    __syncthreads();
+    {
+        // both sums through one exchange (same order of additions as two block_sum calls)
+        a4r = wave_sum(a4r);
+        a4i = wave_sum(a4i);
+        constexpr int NW = kRrcThreads / 64;
+        if (lane == 0) { sm[wv] = a4r; sm2[wv] = a4i; }
+        __syncthreads();
+        if (tid == 0) {
+            float r = 0.f, q = 0.f;
+            for (int i = 0; i < NW; ++i) { r += sm[i]; q += sm2[i]; }
+            delta_s = (r == 0.f && q == 0.f) ? 0.f : atan2f(-q, -r) * 0.25f;
+        }
+        __syncthreads();
+    }
     float rs, rc;
     __sincosf(-delta_s, &rs, &rc);   // |delta| <= pi/4
     // ---- quadrant decision of d_k exp(-i delta): +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3
-    float mratio = 3.4e38f;   // smallest min(|re|,|im|) / max(|re|,|im|): the angular distance to the nearest boundary is its atan
+    // smallest min(|re|,|im|) / max(|re|,|im|) (the angular distance to the nearest boundary is its atan), kept as the pair
+    // (lo, hi) and compared by cross-multiplication: one reciprocal per thread at the end instead of one per symbol
+    float mlo = 1.f, mhi = 0.f;
+    bool mhave = false;           // (a NaN symbol never enters: hi >= lo fails for it)
     uint8_t *hr = hard + (int64_t)row * P.max_soft;
     auto decide = [&](int c0, float2 (&d)[CH], auto tail_c) {
         constexpr bool TAIL = decltype(tail_c)::value;
@@ -699,8 +721,9 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             w[u >> 2] |= h << (8 * (u & 3));
             const float ax = fabsf(dd.x), ay = fabsf(dd.y);
             const float lo = fminf(ax, ay), hi = fmaxf(ax, ay);
-            const float ratio = hi > 0.f ? lo * __builtin_amdgcn_rcpf(hi) : 0.f;
-            if (!TAIL || (i0 + u < ns && i0 + u >= 1)) mratio = fminf(mratio, ratio);
+            // lo / hi < mlo / mhi  <=>  lo * mhi < mlo * hi (all non-negative); the first symbol (mhi = 0) always replaces
+            const bool take = (hi >= lo) && (!mhave || lo * mhi < mlo * hi);
+            if ((!TAIL || (i0 + u < ns && i0 + u >= 1)) && take) { mlo = lo; mhi = hi; mhave = true; }
         }
         if (!TAIL && i0 > 0) {
             *(u32x2_a1 *)(hr + i0 - 1) = u32x2{w[0], w[1]};
@@ -722,6 +745,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         products(c0, d);
         decide_chunk(c0, d);
     }
+    const float mratio = !mhave ? 3.4e38f : (mhi > 0.f ? mlo * __builtin_amdgcn_rcpf(mhi) : 0.f);
     float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;   // (a NaN ratio never replaces the running minimum)
     margin = block_min(margin, sm);
     TT_MARK(11)
