@@ -81,6 +81,8 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     ZpParams dec;
     const double *freq_offset;   // per row or null
     double fs_out;
+    int inline_carry;            // 1: the items form the block carries themselves from the decimator's block-local end
+                                 //    states (pz_carry_compute): no carry launch between the decimator and this kernel
     static constexpr bool kFix = true;
     TDM_HD double foff(int row) const { return freq_offset ? freq_offset[row] : 0.0; }
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(dec.y0 + (int64_t)row * dec.n_out * 2); }
@@ -105,9 +107,19 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
         const bool last = (b == dec.nb - 1);
         // seed rows of the group: outputs 16t, 16t+1 (causal), 16t+14, 16t+15 (anticausal); the block's carries
         const f64x2 *sd = (const f64x2 *)(P.seeds + ((size_t)(last ? P.seed_groups : 0) + t) * kLp2SeedDoubles) + (dir ? 2 * ND : 0);   // (rows 16t, 16t+1 or 16t+14, 16t+15)
-        const f64x2 *cy = (const f64x2 *)((dir ? dec.Hb : dec.Gf) + ((int64_t)row * dec.nb + b) * D * 2);
 #pragma unroll
-        for (int k = 0; k < 2 * ND; ++k) { sdv[k] = sd[k]; cyv[k] = cy[k]; }
+        for (int k = 0; k < 2 * ND; ++k) sdv[k] = sd[k];
+        if (kLp2InlineCarry && inline_carry) {   // (compiled out unless -DTDM_LP2_INLINE_CARRY: see lp2_tables.hpp)
+            double c0[D], c1[D];
+            pz_carry_compute<ND, false>(dec, row, b, 0, dir, c0);
+            pz_carry_compute<ND, false>(dec, row, b, 1, dir, c1);
+#pragma unroll
+            for (int k = 0; k < D; ++k) cyv[k] = f64x2{c0[k], c1[k]};
+        } else {
+            const f64x2 *cy = (const f64x2 *)((dir ? dec.Hb : dec.Gf) + ((int64_t)row * dec.nb + b) * D * 2);
+#pragma unroll
+            for (int k = 0; k < 2 * ND; ++k) cyv[k] = cy[k];
+        }
     }
     template <class Comm>
     TDM_HD void prefetch(const Lp2Params &P, int row, int chunk, Comm &cm, Pref &o) const

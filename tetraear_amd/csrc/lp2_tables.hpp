@@ -16,6 +16,15 @@ constexpr int kLp2La = 16;       // samples per lane
 constexpr int kLp2Waves = 4;     // wavefronts per workgroup
 constexpr int kLp2Lanes = kLp2Waves * kWave;
 constexpr int kLp2Span = kLp2Lanes * kLp2La;   // positions a workgroup covers (chunk + both halos)
+// -DTDM_LP2_INLINE_CARRY: the low-rate kernel's carry-response items form the decimator's block carries themselves
+// (pz_carry_compute) and the carry launch between the decimator and the low-rate kernel falls away.  Measured on MI355X:
+// the launch it saves is 0.015 ms, the low-rate kernel grows from 0.361 to 0.481 ms (92 spilled SGPRs, dependent loads
+// ahead of the staging) -- kept as a build switch, off.
+#ifdef TDM_LP2_INLINE_CARRY
+constexpr bool kLp2InlineCarry = true;
+#else
+constexpr bool kLp2InlineCarry = false;
+#endif
 constexpr int kLp2Pairs = 2;
 constexpr int kLp2D = 2 * kLp2Pairs;
 // what a chunk may ignore of its neighbours: the states are O(10) per unit input, so the neglected part is below 1e-20 of

@@ -724,15 +724,20 @@ TDM_HD void pz_carry_last(const ZpParams &P, int row, int ch, const double *G)
 // threads near the end recompute for themselves).  Transitions are block-diagonal: 2x2 per pole pair.
 //     Gf[b] = Mf Gf[b-1] + Ef[b-1],   Hb[b-1] = Mb(b) Hb[b] + Eb[b],   Hb[nb-1] from pz_carry_last's formula
 // each evaluated as the Horner form of its series over P.carry_terms blocks (see zp_carry_fwd_body).
-template <int NSEC>
-TDM_HD void pz_carry_body(const ZpParams &P, int row, int b, int ch)
+// which = 0: the causal carry Gf[b] into block b, which = 1: the anticausal carry Hb[b]; component ch (0 re, 1 im) -> out[D].
+// Self-contained (reads only the block-local end states the decimator kernel wrote), so the low-rate kernel's carry-
+// response items can form the carry they need themselves and the separate carry launch falls away (lp2_kernels.hpp).
+// SCALAR_END: the three D x D matrices of the row-end formula through scalar loads (the carry kernel: every thread of a
+// launch may need them) or through ordinary loads inside the branch (the low-rate kernel's items: one item in hundreds
+// takes that branch, and 192 scalar registers of hoisted loads spill)
+template <int NSEC, bool SCALAR_END = true>
+TDM_HD void pz_carry_compute(const ZpParams &P, int row, int b, int ch, int which, double *out)
 {
     constexpr int D = 2 * NSEC;
     const int nb = P.nb, terms = P.carry_terms;
     const int64_t base = (int64_t)row * nb * D * 2 + ch;
     const double *Ef = P.Ef + base, *Eb = P.Eb + base;
-    const auto Mf = TDM_CPTR(P.Mf), Ml = TDM_CPTR(P.Mb_last);
-    auto step = [&](const auto &M, double *v, const double *e) {   // v <- M v + e, M block-diagonal
+    auto step_m = [&](const auto M, double *v, const double *e) {   // v <- M v + e, M block-diagonal
 #pragma unroll
         for (int s = 0; s < NSEC; ++s) {
             const double a = v[2 * s], c = v[2 * s + 1];
@@ -740,31 +745,44 @@ TDM_HD void pz_carry_body(const ZpParams &P, int row, int b, int ch)
             v[2 * s + 1] = fma(M[(2 * s + 1) * D + 2 * s], a, fma(M[(2 * s + 1) * D + 2 * s + 1], c, e[(2 * s + 1) * 2]));
         }
     };
+    // (last: the transition over the shorter last block)
+    auto step = [&](bool last, double *v, const double *e) {
+        if (SCALAR_END) {
+            if (last) step_m(TDM_CPTR(P.Mb_last), v, e);
+            else step_m(TDM_CPTR(P.Mf), v, e);
+        } else {
+            step_m(last ? P.Mb_last : P.Mf, v, e);
+        }
+    };
     auto causal_carry = [&](int blk, double *G) {
 #pragma unroll
         for (int k = 0; k < D; ++k) G[k] = 0;
-        for (int bb = blk - terms > 0 ? blk - terms : 0; bb < blk; ++bb) step(Mf, G, Ef + (int64_t)bb * D * 2);
+        for (int bb = blk - terms > 0 ? blk - terms : 0; bb < blk; ++bb) step(false, G, Ef + (int64_t)bb * D * 2);
     };
     auto row_end_start = [&](const double *G, double *H) {   // pz_carry_last's formula
         const int S = P.L / P.out_stride;
-        const auto AG = TDM_CPTR(P.pz + PzLayout::off_AG(S));
-        const auto AE = TDM_CPTR(P.pz + PzLayout::off_AE(S));
-        const auto wx = TDM_CPTR(P.pz + PzLayout::off_wx(S));
         const double *El = P.Elast + (int64_t)row * D * 2 + ch;
         const double xl = P.flast[(int64_t)row * 2 + ch];
+        auto apply = [&](const auto AG, const auto AE, const auto wx) {
 #pragma unroll
-        for (int r = 0; r < D; ++r) {
-            double acc = wx[r] * xl;
+            for (int r = 0; r < D; ++r) {
+                double acc = wx[r] * xl;
 #pragma unroll
-            for (int k = 0; k < D; ++k) acc += AG[r * D + k] * G[k] + AE[r * D + k] * El[k * 2];
-            H[r] = acc;
-        }
+                for (int k = 0; k < D; ++k) acc += AG[r * D + k] * G[k] + AE[r * D + k] * El[k * 2];
+                H[r] = acc;
+            }
+        };
+        if (SCALAR_END) apply(TDM_CPTR(P.pz + PzLayout::off_AG(S)), TDM_CPTR(P.pz + PzLayout::off_AE(S)), TDM_CPTR(P.pz + PzLayout::off_wx(S)));
+        else apply(P.pz + PzLayout::off_AG(S), P.pz + PzLayout::off_AE(S), P.pz + PzLayout::off_wx(S));
     };
-    double G[D], H[D];
-    causal_carry(b, G);
-#pragma unroll
-    for (int k = 0; k < D; ++k) P.Gf[base + ((int64_t)b * D + k) * 2] = G[k];
+    if (which == 0) {
+        causal_carry(b, out);
+        return;
+    }
+    double *H = out;
     if (b == nb - 1) {
+        double G[D];
+        causal_carry(b, G);
         row_end_start(G, H);
     } else {
         int far = b + terms;
@@ -777,11 +795,20 @@ TDM_HD void pz_carry_body(const ZpParams &P, int row, int b, int ch)
 #pragma unroll
             for (int k = 0; k < D; ++k) H[k] = 0;
         }
-        for (int bb = far; bb > b; --bb) {
-            if (bb == nb - 1) step(Ml, H, Eb + (int64_t)bb * D * 2);
-            else step(Mf, H, Eb + (int64_t)bb * D * 2);
-        }
+        for (int bb = far; bb > b; --bb) step(bb == nb - 1, H, Eb + (int64_t)bb * D * 2);
     }
+}
+
+template <int NSEC>
+TDM_HD void pz_carry_body(const ZpParams &P, int row, int b, int ch)
+{
+    constexpr int D = 2 * NSEC;
+    const int64_t base = (int64_t)row * P.nb * D * 2 + ch;
+    double G[D], H[D];
+    pz_carry_compute<NSEC>(P, row, b, ch, 0, G);
+#pragma unroll
+    for (int k = 0; k < D; ++k) P.Gf[base + ((int64_t)b * D + k) * 2] = G[k];
+    pz_carry_compute<NSEC>(P, row, b, ch, 1, H);
 #pragma unroll
     for (int k = 0; k < D; ++k) P.Hb[base + ((int64_t)b * D + k) * 2] = H[k];
 }

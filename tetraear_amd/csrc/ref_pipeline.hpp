@@ -79,9 +79,11 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
 {
     RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
     const bool use_raw = h.raw_S > 0 && FMT == FMT_CU8 && !SHIFT && (int64_t)rows * h.dec.p.nb >= h.raw_min_blocks;
+    // (the one-kernel low-rate stage forms the block carries inside its carry-response items: no carry launch)
+    const bool inline_carry = h.lp2.ok && kLp2InlineCarry;
     if (use_raw) {
         run_pz_raw(be, h, B.dec_raw_params, io.iq, io.carrier_stride, rows);
-        be.template zp_carry<2, 4>(B.dec_raw_params, h.dec_raw.p.nb, rows);
+        if (!inline_carry) be.template zp_carry<2, 4>(B.dec_raw_params, h.dec_raw.p.nb, rows);
     } else if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
         if (h.pz_S) {
@@ -90,7 +92,7 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         } else {
             be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
         }
-        be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
+        if (!(inline_carry && h.pz_S)) be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
         if (!h.lpf)  // (n_dec <= 15) nothing downstream finishes the decimator output: do it here
             be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
     } else {
@@ -119,10 +121,10 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         fa.zt = B.lp2.zt;
         fa.zt_k = B.lp2.zt_k;
         if (use_raw) {
-            Lp2SrcDec src{B.dec_raw_params, io.freq_offset, h.rate_dec};
+            Lp2SrcDec src{B.dec_raw_params, io.freq_offset, h.rate_dec, inline_carry ? 1 : 0};
             be.lp2_finish(L, src, fa, rows);
         } else if (h.decimated) {
-            Lp2SrcDec src{B.dec_params, io.freq_offset, h.rate_dec};
+            Lp2SrcDec src{B.dec_params, io.freq_offset, h.rate_dec, (inline_carry && h.pz_S) ? 1 : 0};
             be.lp2_finish(L, src, fa, rows);
         } else {
             Lp2SrcPlain src{B.y, h.n_dec};
