@@ -510,8 +510,37 @@ TDM_HD void pz_raw_cvt(const uint32_t *raw, int i, double &re, double &im)
         re = (double)(int32_t)(int16_t)(w & 0xffffu);
         im = (double)((int32_t)w >> 16);
     } else {
-        uint32_t w = raw[i / 2];
-        if (OPAQUE) TDM_OPAQUE_V(w);
+        const uint32_t w = raw[i / 2];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_OPAQUE)
+        // the byte comes out of its dword by a bit-field extract written as volatile asm: it is never merged with the
+        // other direction's extract of the same byte (which would keep 240 extracted values alive across the loop) and,
+        // unlike an opaque copy of the dword (round 2: 120 v_mov per lane), costs no instruction of its own
+        if (OPAQUE) {
+            uint32_t br, bi;
+            if (FMT8 == FMT_CU8) {
+                if (i % 2 == 0) {
+                    asm volatile("v_bfe_u32 %0, %1, 0, 8" : "=v"(br) : "v"(w));
+                    asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(bi) : "v"(w));
+                } else {
+                    asm volatile("v_bfe_u32 %0, %1, 16, 8" : "=v"(br) : "v"(w));
+                    asm volatile("v_bfe_u32 %0, %1, 24, 8" : "=v"(bi) : "v"(w));
+                }
+                re = (double)br;
+                im = (double)bi;
+            } else {
+                if (i % 2 == 0) {
+                    asm volatile("v_bfe_i32 %0, %1, 0, 8" : "=v"(br) : "v"(w));
+                    asm volatile("v_bfe_i32 %0, %1, 8, 8" : "=v"(bi) : "v"(w));
+                } else {
+                    asm volatile("v_bfe_i32 %0, %1, 16, 8" : "=v"(br) : "v"(w));
+                    asm volatile("v_bfe_i32 %0, %1, 24, 8" : "=v"(bi) : "v"(w));
+                }
+                re = (double)(int32_t)br;
+                im = (double)(int32_t)bi;
+            }
+            return;
+        }
+#endif
         const int sh = 16 * (i % 2);
         if (FMT8 == FMT_CU8) {
             re = (double)(float)((w >> sh) & 0xffu);          // v_cvt_f32_ubyteN + v_cvt_f64_f32
