@@ -1,0 +1,134 @@
+"""CPU tier, world size 2: bench.py's multi-rank control flow end to end -- environment of torch.distributed.run, the
+librccl group (against the stub library, host memory), sharding, the three reductions, ONE JSON line on rank 0 -- with
+the device replaced by a stand-in that returns fixed outputs.  Two scenarios: a clean run, and a run in which rank 1's
+output check fails: BOTH ranks must stop with the failure (no rank left waiting in an all-reduce)."""
+import json
+import multiprocessing as mp
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+STUB = os.path.join(HERE, "rccl_stub", "librccl_stub.so")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build_stub():
+    subprocess.run(["make", "-C", os.path.join(HERE, "rccl_stub")], check=True, capture_output=True)
+
+
+class _Info:
+    n_dec, dec_engine, max_soft = 410, 3, 34
+
+
+class FakeBatchDemodulator:
+    """what bench.main() touches of BatchDemodulator, without a device"""
+
+    def __init__(self, rate, chunk, carriers, fmt, device=0, **kw):
+        self.carriers, self.info = carriers, _Info()
+        self.rank = int(os.environ.get("RANK", "0"))
+
+    def sync(self): pass
+    def alloc_device_io(self, shared_input=False): pass
+    def upload(self, iq, freq_offsets=None, pre_shifts=None): pass
+    def enqueue(self): pass
+    def time_begin(self, per_stage=True): pass
+    def time_end(self): return 1.0 + self.rank
+    def stage_times(self): return {"dec_block": 0.5, "dec_carry": 0.01, "lpf_block": 0.3, "finish": 0.03}
+    def close(self): pass
+
+    def download(self):
+        rows, ms = self.carriers, self.info.max_soft
+        hard = np.full((rows, ms), self.rank, dtype=np.uint8)
+        n_soft = np.full(rows, 30 + self.rank, dtype=np.int32)
+        return hard, np.zeros((rows, ms), np.complex128), n_soft, np.zeros(rows, np.int32), np.zeros(rows)
+
+
+class _HostMem:
+    def __init__(self, device=0):
+        import ctypes as C
+        self.C = C
+        self.buf = (C.c_byte * 16)()
+        self.ptr = C.cast(self.buf, C.c_void_p)
+
+    def upload(self, v): self.C.memmove(self.buf, self.C.byref(v), 8)
+    def download(self, v): self.C.memmove(self.C.byref(v), self.buf, 8)
+    def free(self): pass
+
+
+def _rank(rank, world, port, bad_rank, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="benchdist", TDM_RCCL_LIB=STUB)
+    sys.path.insert(0, ROOT)
+    import io
+    import contextlib
+    import bench
+    import tetraear_amd.batch as batch
+    import tetraear_amd.rccl as rccl
+    batch.BatchDemodulator = FakeBatchDemodulator
+    rccl.DeviceMemory = _HostMem
+    bench.make_batch = lambda carriers, chunk, fmt, r: (np.zeros(2 * carriers * chunk, np.uint8), np.zeros(carriers))
+    if bad_rank is not None:
+        # a pinned digest that rank `bad_rank`'s output cannot have
+        real = bench.expected_digest
+        bench.expected_digest = lambda key: ("0" * 64 if f"rank{bad_rank}" in key else None)
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--carriers", "4", "--chunk", "4096",
+                "--no-cpu-baseline"]
+    out = io.StringIO()
+    status = "ok"
+    try:
+        with contextlib.redirect_stdout(out):
+            bench.main()
+    except SystemExit as e:
+        status = f"exit: {e}"
+    q.put((rank, status, out.getvalue()))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(bad_rank):
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, bad_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_bench_prints_one_line_with_job_totals():
+    (r0, s0, o0), (r1, s1, o1) = _run(None)
+    assert s0 == "ok" and s1 == "ok"
+    assert o1.strip() == ""                                    # only rank 0 prints
+    lines = [l for l in o0.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert "librccl via ctypes" in d["config"]["collective"]
+    # symbols of both ranks: 4 carriers x (29 + 30), over the slower rank's elapsed time
+    assert d["value"] > 0 and d["config"]["carriers_per_gpu"] == 4
+    assert "cpu_baseline" not in d and "tetra" not in d        # N = 1 only
+
+
+@pytest.mark.timeout(180)
+def test_failed_output_check_on_one_rank_stops_both():
+    (r0, s0, o0), (r1, s1, o1) = _run(1)
+    assert s0.startswith("exit:") and "1 rank" in s0, s0       # rank 0's own check passed; it learns of rank 1's failure
+    assert s1.startswith("exit:") and "1 rank" in s1, s1
+    assert not [l for l in o0.splitlines() if l.startswith("{")]   # no result line for a failed job

@@ -179,8 +179,10 @@ class RcclGroup:
     """barrier / max_f64 / sum_i64 over librccl.  `lib_path` and `memory` exist for the CPU-tier test, which runs this class
     against a stub library over host memory (tests/rccl_stub)."""
 
-    def __init__(self, rank, world, device, timeout_s=120.0, lib_path="librccl.so", memory=None):
+    def __init__(self, rank, world, device, timeout_s=120.0, lib_path=None, memory=None):
         self.rank, self.world, self.device = int(rank), int(world), int(device)
+        # (TDM_RCCL_LIB: another library with the same five entry points -- the CPU tier's stub)
+        lib_path = lib_path or os.environ.get("TDM_RCCL_LIB", "librccl.so")
         self.lib, self.mem, err = None, None, None
         try:
             self.lib = C.CDLL(lib_path)
