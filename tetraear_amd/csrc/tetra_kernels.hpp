@@ -309,6 +309,11 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         TT_MARK(0)
         __syncthreads();   // tile i staged; the previous round's ring reads are done
         TT_MARK(1)
+        // (a wavefront whose 512 outputs of the last tile all lie past the end of the chunk has no filter output, no
+        // statistic and nothing for the ring: a chunk of 8389 samples -- the 10 MS/s channeliser's -- ends 197 samples
+        // into its fifth tile, and three of the four wavefronts skip it)
+        const bool wave_data = !last || base + 512 * wv < n;
+        if (wave_data) {
         f32x4 cre[2], cim[2];
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
@@ -404,6 +409,11 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
 #pragma unroll
             for (int r = 0; r < 4; ++r) yw[rrc_slot(16 * r)] = make_float2(cre[bb][r], cim[bb][r]);
             if (pw == 0 && lane < 3) yring[rrc_slot(kRing) + lane] = make_float2(cre[bb][0], cim[bb][0]);
+        }
+        } else if (lane < 4) {
+            const int b = i * kTileBlocks + 2 * wv + (lane & 1);
+            ((float *)Cst)[2 * (b & (kCstRing - 1)) + (lane >> 1)] = 0.f;
+            ((float *)Cst)[2 * ((b + kTileBlocks) & (kCstRing - 1)) + (lane >> 1)] = 0.f;
         }
         TT_MARK(4)
         __syncthreads();   // ring, statistic visible; staging buffer free
