@@ -580,14 +580,18 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         (void)ph; (void)g;
         double acc = 0;
         if (p2 < sps) {
-            const int64_t np_ = (n - p2) / sps;                 // samples phase p owns: j = p + k*sps, k < np_
-            const int64_t lim = p2 + np_ * (int64_t)sps;        // first j NOT owned (extract_symbols, processor.py:199-203)
-            // first k with j = p2 + k*sps >= j_lo
-            int64_t k0 = j_lo <= p2 ? 0 : (j_lo - p2 + sps - 1) / sps;
-            for (int64_t k = k0 + g2; p2 + k * sps < j_hi; k += ngrp) {
-                const int64_t j = p2 + k * sps;
-                const f64x2 v = stage[lp2_slot((int)(j - jc))];
-                zt[(int64_t)p2 * P.zt_k + k] = v;
+            // 32-bit index arithmetic (positions are below 2^31: tdm_plan_create bounds the chunk length), strength-reduced:
+            // the staging offset and the position advance by ngrp * sps per turn, the output pointer by ngrp
+            const int n32 = (int)n, jlo = (int)j_lo, jhi = (int)j_hi, jc32 = (int)jc;
+            const int np_ = (n32 - p2) / sps;                   // samples phase p owns: j = p + k*sps, k < np_
+            const int lim = p2 + np_ * sps;                     // first j NOT owned (extract_symbols, processor.py:199-203)
+            const int k0 = jlo <= p2 ? 0 : (jlo - p2 + sps - 1) / sps;   // first k with j = p2 + k*sps >= j_lo
+            const int step = ngrp * sps;
+            int j = p2 + (k0 + g2) * sps;
+            f64x2 *po = zt + (int64_t)p2 * P.zt_k + (k0 + g2);
+            for (; j < jhi; j += step, po += ngrp) {
+                const f64x2 v = stage[lp2_slot(j - jc32)];
+                *po = v;
                 if (j < lim) acc += fma(v.x, v.x, v.y * v.y);
             }
             small[Lp2Lds::oPow + g2 * kMaxSps + p2] = acc;
