@@ -239,6 +239,18 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     const bool wg_edge = (jc < 0) || (jc + (int64_t)kLp2Span > n);
     typename Src::Pref pref;
     if (Src::kFix) src.prefetch(P, row, chunk, cm, pref);
+    // the NCO's step phasor exp(i Dd) is the same for the whole row: the last wavefront (the one with the fewest
+    // carry-response items) forms it while the samples are on their way and leaves it in LDS for all lanes (round 2:
+    // every lane's own sincos, 120 instructions in each of the four wavefronts)
+    double *nco_w = small + Lp2Lds::oPow + 16;     // (the power partials' area is free until the output stage)
+    if (Src::kFix && wave == kLp2Waves - 1) {
+        const double f = src.foff(row);
+        if (f != 0.0) {
+            double wre, wim;
+            NcoRunT<1>::step_phasor(f, src.fs_out, wre, wim);
+            if (lane == 0) { nco_w[0] = wre; nco_w[1] = wim; }
+        }
+    }
     {
         const f64x2 *rowp = src.raw_row(row);
         const int64_t jw = jc + (int64_t)wave * (kWave * La);
@@ -292,7 +304,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         const double f = src.foff(row);
         if (f != 0.0) {
             NcoRunT<1> nco;
-            nco.init(js, f, src.fs_out);
+            nco.init_with(js, f, src.fs_out, nco_w[0], nco_w[1]);
 #pragma unroll
             for (int i = 0; i < La; ++i) {
                 double c = nco.ar, sn = nco.ai;

@@ -132,6 +132,32 @@ struct NcoRunT {
         ar = p.c; ai = p.s; wr = 1; wi = 0; j_a = j; j_cur = j;
         on = true;
     }
+    // the step phasor W = exp(i STRIDE Dd) depends on (f, fs) only: a caller whose lanes share them forms it once
+    // (step_phasor) and hands it to every lane's init_with
+    TDM_HD static void step_phasor(double f, double fs, double &w_re, double &w_im)
+    {
+        const double ci = -(2.0 * M_PI) * f;
+        union { double d; uint64_t u; } v;
+        v.d = ci / fs;
+        v.u &= ~uint64_t(0x1FFF);
+        sincos((double)STRIDE * v.d, &w_im, &w_re);
+    }
+    TDM_HD void init_with(int64_t j, double f, double fs, double w_re, double w_im)
+    {
+        const double ci = -(2.0 * M_PI) * f;
+        rfs = 1.0 / fs;
+        union { double d; uint64_t u; } v;
+        v.d = ci / fs;
+        v.u &= ~uint64_t(0x1FFF);
+        dd = v.d;
+        sr = w_re;
+        si = w_im;
+        const double t = quot((double)(int32_t)j, fs, rfs);
+        th_a = ci * t;
+        const phasor p = nco_phasor(j, f, fs);
+        ar = p.c; ai = p.s; wr = 1; wi = 0; j_a = j; j_cur = j;
+        on = true;
+    }
     TDM_HD void next(double f, double fs, double &c, double &s)
     {
         const double ci = -(2.0 * M_PI) * f;
