@@ -72,7 +72,8 @@ struct Lp2SrcPlain {   // c128 rows already at the low rate (no decimation: k_co
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(x + (int64_t)row * row_stride * 2); }
     struct Pref {};
     template <class Comm>
-    TDM_HD void prefetch(const Lp2Params &, int, int, Comm &, Pref &) const {}
+    TDM_HD void prefetch_words(const Lp2Params &, int, Comm &, Pref &) const {}
+    TDM_HD void prefetch_operands(const Lp2Params &, int, Pref &) const {}
     template <class Comm>
     TDM_HD void fix_phase(const Lp2Params &, int, int, f64x2 *, Comm &, const Pref &) const {}
 };
@@ -97,7 +98,7 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     // operands of a thread's first item, requested before the samples are staged so that their latency overlaps the
     // staging: the item's two words, its seed rows and its block's carries
     struct Pref {
-        int w0 = 0, w1 = 0;
+        int w0 = 0, w1 = 0, mine = 0;
         f64x2 sd[2 * PzLayout::kMaxPairs], cy[2 * PzLayout::kMaxPairs];
     };
     TDM_HD void item_operands(const Lp2Params &P, int row, int w0, int w1, f64x2 (&sdv)[2 * PzLayout::kMaxPairs], f64x2 (&cyv)[2 * PzLayout::kMaxPairs]) const
@@ -121,16 +122,22 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
             for (int k = 0; k < 2 * ND; ++k) cyv[k] = cy[k];
         }
     }
+    // Two steps around the issue of the sample loads: the item's two words first (unconditional: a chunk's list is padded
+    // to one item per thread), so that they are the OLDEST loads in flight when the samples' sixteen follow; then, once
+    // the words are back (the samples still on their way), the seed rows and carries they name.  (As one step ahead of
+    // the sample loads the dependent pair of round trips delayed the staging of every workgroup.)
     template <class Comm>
-    TDM_HD void prefetch(const Lp2Params &P, int row, int chunk, Comm &cm, Pref &o) const
+    TDM_HD void prefetch_words(const Lp2Params &P, int chunk, Comm &cm, Pref &o) const
     {
         const int32_t *it = P.items + (size_t)chunk * P.items_stride;
         const int k = cm.tid();
-        if (k < it[0]) {
-            o.w0 = it[2 + 2 * k];
-            o.w1 = it[3 + 2 * k];
-            item_operands(P, row, o.w0, o.w1, o.sd, o.cy);
-        }
+        o.w0 = it[2 + 2 * k];
+        o.w1 = it[3 + 2 * k];
+        o.mine = k < it[0];
+    }
+    TDM_HD void prefetch_operands(const Lp2Params &P, int row, Pref &o) const
+    {
+        if (o.mine) item_operands(P, row, o.w0, o.w1, o.sd, o.cy);
     }
     // The decimator's carry responses (y = y0 + T1.Gf + T2.Hb), added to the staged samples in place.  For the La
     // consecutive outputs of a group they are, per pole pair and direction, a second-order recurrence at the decimated
@@ -198,7 +205,7 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
         constexpr int ND = PzLayout::kMaxPairs;
         const int32_t *it = P.items + (size_t)chunk * P.items_stride;
         const int cnt1 = it[0], cnt2 = it[1];
-        if (cm.tid() < cnt1) run_item(P, stage, pf.w0, pf.sd, pf.cy);   // (operands requested before the staging)
+        if (pf.mine) run_item(P, stage, pf.w0, pf.sd, pf.cy);   // (operands requested while the samples were staged)
 #pragma unroll 1
         for (int k = cm.tid() + kLp2Lanes; k < cnt1; k += kLp2Lanes) {
             f64x2 sdv[2 * ND], cyv[2 * ND];
@@ -238,19 +245,8 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     // chunks that hold an end of the row: odd extension and start states (workgroup-uniform)
     const bool wg_edge = (jc < 0) || (jc + (int64_t)kLp2Span > n);
     typename Src::Pref pref;
-    if (Src::kFix) src.prefetch(P, row, chunk, cm, pref);
-    // the NCO's step phasor exp(i Dd) is the same for the whole row: the last wavefront (the one with the fewest
-    // carry-response items) forms it while the samples are on their way and leaves it in LDS for all lanes (round 2:
-    // every lane's own sincos, 120 instructions in each of the four wavefronts)
+    if (Src::kFix) src.prefetch_words(P, chunk, cm, pref);
     double *nco_w = small + Lp2Lds::oPow + 16;     // (the power partials' area is free until the output stage)
-    if (Src::kFix && wave == kLp2Waves - 1) {
-        const double f = src.foff(row);
-        if (f != 0.0) {
-            double wre, wim;
-            NcoRunT<1>::step_phasor(f, src.fs_out, wre, wim);
-            if (lane == 0) { nco_w[0] = wre; nco_w[1] = wim; }
-        }
-    }
     {
         const f64x2 *rowp = src.raw_row(row);
         const int64_t jw = jc + (int64_t)wave * (kWave * La);
@@ -268,11 +264,31 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
             v[i] = rowp[jj];
 #endif
         }
+        // ---- while the samples are on their way: the operands of the thread's first carry-response item, and the NCO's
+        // step phasor exp(i Dd), which is the same for the whole row: the last wavefront (the one with the fewest items)
+        // forms it and leaves it in LDS for all lanes (round 2: every lane's own sincos, 120 instructions in each of the
+        // four wavefronts)
+        if (Src::kFix) {
+            src.prefetch_operands(P, row, pref);
+            if (wave == kLp2Waves - 1) {
+                const double f = src.foff(row);
+                if (f != 0.0) {
+                    double wre, wim;
+                    NcoRunT<1>::step_phasor(f, src.fs_out, wre, wim);
+                    if (lane == 0) { nco_w[0] = wre; nco_w[1] = wim; }
+                }
+            }
+        }
+        if (!wg_edge) {   // every position of the span lies inside the row: nothing to mask
 #pragma unroll
-        for (int i = 0; i < La; ++i) {
-            const int j = jw32 + i * kWave;
-            const bool ok = (j >= 0 && j < n32);
-            stage[lp2_slot(wave * (kWave * La) + i * kWave + lane)] = f64x2{ok ? v[i].x : 0.0, ok ? v[i].y : 0.0};
+            for (int i = 0; i < La; ++i) stage[lp2_slot(wave * (kWave * La) + i * kWave + lane)] = v[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < La; ++i) {
+                const int j = jw32 + i * kWave;
+                const bool ok = (j >= 0 && j < n32);
+                stage[lp2_slot(wave * (kWave * La) + i * kWave + lane)] = f64x2{ok ? v[i].x : 0.0, ok ? v[i].y : 0.0};
+            }
         }
     }
     cm.sync();

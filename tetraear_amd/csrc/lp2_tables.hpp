@@ -199,6 +199,8 @@ inline Lp2Host build_lp2(const double (*sos)[6], int64_t n, int edge, int sps, c
             for (auto &e : it) { w.push_back(e.second.first); w.push_back(e.second.second); }
             if (w.size() > max_words) max_words = w.size();
         }
+        // (at least one item slot per thread: the kernel loads its first item's words before it knows the count)
+        if (max_words < 2 + 2 * (size_t)kLp2Lanes) max_words = 2 + 2 * (size_t)kLp2Lanes;
         p.items_stride = (int32_t)((max_words + 1) & ~(size_t)1);
         std::vector<int32_t> flat((size_t)p.items_stride * p.n_chunks, 0);
         for (int c = 0; c < p.n_chunks; ++c) std::copy(per_chunk[c].begin(), per_chunk[c].end(), flat.begin() + (size_t)c * p.items_stride);
