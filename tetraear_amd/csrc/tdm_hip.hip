@@ -1748,7 +1748,25 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
     const bool force_direct = std::getenv("TDM_PFB_DIRECT") != nullptr;
     if (!force_direct && D <= 4 * M) {
         const int64_t rounds = (n_out + TB - 1) / TB;
-        Q.G = (int)std::min<int64_t>(8, std::max<int64_t>(1, rounds * n_streams / 2048));
+        {
+            // rounds per workgroup: one workgroup per compute unit is resident (146 KB of LDS at M = 400), so the launch runs
+            // in ceil(workgroups / CUs) waves of G rounds each plus a start-up of about a third of a round per workgroup;
+            // the G that minimises that (32 streams x 263 rounds: G = 3 -> 2816 workgroups = exactly 11 waves, 0.235 ms;
+            // round 2's G = 4 -> 8.25 waves, 0.244 ms)
+            static int cu_count[64] = {0};   // (per device, asked once)
+            int &cus = cu_count[device & 63];
+            if (cus == 0) {
+                hipDeviceProp_t prop;
+                cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            }
+            double best = 1e300;
+            Q.G = 1;
+            for (int g = 1; g <= 8; ++g) {
+                const int64_t wgs = ((rounds + g - 1) / g) * n_streams;
+                const double cost = (double)((wgs + cus - 1) / cus) * (g + 0.3);
+                if (cost < best - 1e-9) { best = cost; Q.G = g; }
+            }
+        }
         if (const char *e = std::getenv("TDM_PFB_G")) Q.G = std::max(1, std::atoi(e));   // experiments
         const size_t lds = pfb_fft_lds<M1, M2, P, TB>(D) * sizeof(float2);
         if (lds <= 160 * 1024) {
