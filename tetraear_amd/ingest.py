@@ -55,6 +55,7 @@ def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0,
     bufs = [np.zeros(batch_bytes, dtype=np.uint8) for _ in range(2)]
     pinned = []
     bd = None
+    t = None     # the reader thread in flight, if any (joined before the buffers go away, also when the consumer stops early)
     try:
         for b in bufs:
             check(lib.tdm_host_register(device, ptr(b), b.nbytes))
@@ -102,8 +103,11 @@ def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0,
             if t is None:
                 break
             t.join()
+            t = None
             slot ^= 1
     finally:
+        if t is not None:
+            t.join()
         if bd is not None:
             bd.close()
         for b in pinned:

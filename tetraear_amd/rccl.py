@@ -7,8 +7,8 @@ One process per GPU on ONE node.  Bring-up is collective by construction:
 1. every rank loads librccl and binds its device, and notes whether that worked;
 2. the ranks meet on a TCP socket that rank 0 opens on MASTER_ADDR (ports MASTER_PORT + 1 + k, k = 0..63: the first one
    it can bind; MASTER_PORT itself belongs to the launcher's store).  A connection starts with a token made of the
-   launcher's run id, the world size and the launcher's pid, so a foreign listener or a stale run on one of those ports
-   is recognised and skipped;
+   launcher's run id and pid (or TDM_RCCL_TOKEN, for launchers whose ranks do not share a parent), the master port and
+   the world size, so a foreign listener or a stale run on one of those ports is recognised and skipped;
 3. rank 0 collects every rank's "librccl usable" flag and answers each with the SAME decision: all usable -> the
    ncclUniqueId follows and all ranks enter ncclCommInitRank; otherwise every rank raises RcclUnavailable and the caller
    may choose another backend -- on ALL ranks, never on some (a per-rank fallback leaves the rest blocked inside
@@ -90,7 +90,10 @@ def _recv_exact(sock, n):
 
 
 def _token(world):
-    run = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}|{world}|{os.getppid()}".encode()
+    """what identifies this launch to its own ranks: TDM_RCCL_TOKEN if the launcher sets one; else the elastic launcher's
+    run id plus the launcher's pid (torch.distributed.run: every rank is its child); the master port and world size always"""
+    tag = os.environ.get("TDM_RCCL_TOKEN") or f"{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}|{os.getppid()}"
+    run = f"{tag}|{os.environ.get('MASTER_PORT', '')}|{world}".encode()
     return _MAGIC + struct.pack("<H", len(run)) + run
 
 
