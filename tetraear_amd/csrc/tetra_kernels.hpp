@@ -94,6 +94,16 @@ __device__ __forceinline__ float tau_at(const float2 *tau, int nb, double pos)
 }
 
 
+// clamp(x, LO, hi) for a small constant LO and a wave-uniform hi >= LO in ONE instruction (the compiler emits v_min + v_max:
+// it cannot know hi >= LO)
+template <int LO>
+__device__ __forceinline__ int clamp_med3(int x, int hi_uniform)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(LO), "s"(hi_uniform));
+    return r;
+}
+
 // atan2(y, x) / (2 pi), absolute error below 2e-6 turns (odd minimax polynomial on [0, 1] + octant folding): the timing
 // estimate it feeds is good to 1e-3 symbols at best
 __device__ __forceinline__ float atan2_turns(float y, float x)
@@ -512,7 +522,8 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         const int ring_lo = max(0, base + kRrcTile - kRing), ring_hi = base + kRrcTile;
         const int ring_off = ring_lo % kRing;
         const int span4 = ring_hi - ring_lo - 4;
-        const int b0_max = min(nb - 2, b_known - 1);
+        const int b0_max = __builtin_amdgcn_readfirstlane(max(min(nb - 2, b_known - 1), 0));   // (>= 0: clamp_med3's contract)
+        const int m_max = __builtin_amdgcn_readfirstlane(max(n - 3, 1));
         const float sps_f = (float)sps;
         constexpr int SU = PER / 4;   // symbols per thread in flight together
         // whole sample m and fraction mu of the instant t_k = (k + tau(k sps)) sps for the symbols kb + tid + u * 256; SU
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 // piecewise-linear timing estimate between sub-block centres (both estimates final: b0 + 1 <= b_known):
                 // u = (position - TB/2) / TB, b0 = floor(u) clamped, f = u - b0 clamped
                 const int t = mk[u] - kTimingBlock / 2;
-                const int b0 = max(min(t >> 8, b0_max), 0);
+                const int b0 = clamp_med3<0>(t >> 8, b0_max);
                 static_assert(kTimingBlock == 256, "shift");
                 ff[u] = __builtin_amdgcn_fmed3f(((float)(t - (b0 << 8)) + tk[u]) * (1.f / (float)kTimingBlock), 0.f, 1.f);
                 const float2 tp = tau[b0 & (kTauRing - 1)];   // (tau_b0, tau_{b0+1}: b0 + 1 <= b_known <= nb - 1, or nb == 1: its own)
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 const float ts = tk[u] + tauk * sps_f;      // t_k relative to the whole sample mk
                 const float fl = floorf(ts);
                 mu[u] = ts - fl;
-                mm[u] = min(max(mk[u] + (int)fl, 1), n - 3);
+                mm[u] = clamp_med3<1>(mk[u] + (int)fl, m_max);
             }
         };
         bool any_direct = false;
@@ -561,7 +572,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 // position of the symbol's first filter output in the ring's window; outside it -> direct path below
                 const int q = mm[u] - 1 - ring_lo;
                 any_direct |= (unsigned)q > (unsigned)span4 && kb + tid + u * kRrcThreads < k_end;
-                const int p = min(max(q, 0), span4) + ring_off;                    // < 2 kRing
+                const int p = clamp_med3<0>(q, span4) + ring_off;                  // < 2 kRing
                 const int p0 = (int)min((unsigned)p, (unsigned)(p - kRing));       // p >= kRing ? p - kRing : p
                 const float2 *yp = yring + rrc_slot(p0);
                 f[u].ym1 = yp[0];

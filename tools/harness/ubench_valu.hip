@@ -41,6 +41,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
                 if (MODE == 22) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(acc[i].x) : "v"(w[i].y), "v"(w[i].x));
                 if (MODE == 23) asm volatile("v_mul_f32 %0, %1, %2" : "+v"(acc[i].x) : "v"(w[i].y), "v"(w[i].x));
                 if (MODE == 24) asm volatile("v_lshl_or_b32 %0, %1, 8, %2" : "+v"(acc[i].x) : "v"(w[i].y), "v"(w[i].x));
+                if (MODE == 25) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(*(float __attribute__((ext_vector_type(4))) *)&acc[i & 2]) : "v"(*(float __attribute__((ext_vector_type(4))) *)&w[i & 6]));
+                if (MODE == 26) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(*(float __attribute__((ext_vector_type(4))) *)&acc[0]) : "v"(*(float __attribute__((ext_vector_type(4))) *)&w[i & 6]));
                 if (MODE == 14) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(*(float __attribute__((ext_vector_type(4))) *)&acc[i & 6]) : "v"(*(float __attribute__((ext_vector_type(4))) *)&w[i & 6]));
             }
         }
@@ -75,7 +77,7 @@ int main()
 #define R(M, N) if (w == 1) run<M>(N, 1); else run<M>(N, 4);
         R(0, "v_pk_fma_f32") R(1, "v_fma_f32") R(2, "v_fma_f64") R(3, "v_cndmask_b32") R(4, "v_mov_b32_dpp row_shr") R(5, "v_rcp_f32")
         R(6, "v_cvt_pk_bf16_f32") R(7, "v_add_u32") R(8, "v_lshl_add_u64") R(9, "v_pk_mul_f32") R(10, "v_mul_f64") R(11, "v_add_f64")
-        R(12, "v_cvt_f64_f32") R(13, "v_cvt_f32_ubyte0") R(14, "v_mfma_16x16x32_bf16") R(15, "v_mfma_16x16x16_bf16") R(16, "v_cndmask sgpr mask") R(17, "v_cmp+v_cndmask vcc (x2)") R(18, "v_max_f32") R(19, "v_floor_f32") R(20, "v_cvt_i32_f32") R(21, "v_alignbit_b32") R(22, "v_med3_f32") R(23, "v_mul_f32") R(24, "v_lshl_or_b32")
+        R(12, "v_cvt_f64_f32") R(13, "v_cvt_f32_ubyte0") R(14, "v_mfma_16x16x32_bf16") R(15, "v_mfma_16x16x16_bf16") R(16, "v_cndmask sgpr mask") R(17, "v_cmp+v_cndmask vcc (x2)") R(18, "v_max_f32") R(19, "v_floor_f32") R(20, "v_cvt_i32_f32") R(21, "v_alignbit_b32") R(22, "v_med3_f32") R(23, "v_mul_f32") R(24, "v_lshl_or_b32") R(25, "mfma 16x16x32, 2 accumulators alternating") R(26, "mfma 16x16x32, 1 accumulator (dependent)")
     }
     return 0;
 }
