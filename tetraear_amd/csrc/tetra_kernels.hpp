@@ -194,6 +194,12 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // front.  fetch() only issues loads (clamped addresses, nothing that consumes a loaded value: a use would wait for
     // the load on the spot); stage() masks what lies outside the chunk, splits into bf16 and writes LDS.
     typedef f32x4 __attribute__((aligned(8))) f32x4_a8;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the staged window is NP - 1 pairs for every thread and a few more (24 at 33 taps) that fall to the first lanes of
+    // wavefront 0: the other wavefronts skip the last pair altogether (load, split and all)
+    static_assert(NS / 2 - (NP - 1) * kRrcThreads <= 64, "the pairs of the last turn lie in wavefront 0");
+    const bool last_turn = wv == 0;
     const int gmaxp = n - 2;                              // last pair start inside the chunk
     const float2 x_first = xr[0], x_last = xr[n - 1];
     f32x4 pf[NP];
@@ -203,11 +209,13 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             // an inner tile: nothing to clamp, one scalar base and the thread's own offset (no vector address arithmetic)
             const f32x4_a8 *pb = (const f32x4_a8 *)(xr + g0);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) pf[j] = __builtin_nontemporal_load(pb + tid + j * kRrcThreads);
+            for (int j = 0; j < NP - 1; ++j) pf[j] = __builtin_nontemporal_load(pb + tid + j * kRrcThreads);
+            if (last_turn) pf[NP - 1] = __builtin_nontemporal_load(pb + tid + (NP - 1) * kRrcThreads);
             return;
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
+            if (j == NP - 1 && !last_turn) break;
             const int g = g0 + 2 * (tid + j * kRrcThreads);
             pf[j] = __builtin_nontemporal_load((const f32x4_a8 *)(xr + min(max(g, 0), gmaxp)));
         }
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         if (g0 >= 0 && g0 + NS <= gmaxp) {         // every pair of the tile lies inside the chunk: no masks
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
+                if (j == NP - 1 && !last_turn) break;
                 const f32x4 v = pf[j];
                 put(tid + j * kRrcThreads, j == NP - 1, v.x, v.y, v.z, v.w);
             }
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
+            if (j == NP - 1 && !last_turn) break;
             const int idx = tid + j * kRrcThreads;
             const int g = g0 + 2 * idx;               // chunk position of the pair's first sample
             const bool in = g >= 0 && g <= gmaxp;
@@ -256,8 +266,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // 48 instructions per wavefront and tile add their full 0.20 ms to the 0.37 ms of the rest of this kernel.)
     // Lane l supplies X[l & 15][32 s + 8 (l >> 4) .. + 7] (16 bytes per plane and step from LDS) and the constants
     // T[32 s + 8 (l >> 4) .. + 7][l & 15]; it receives Y[4 (l >> 4) + r][l & 15], r < 4.
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     u32x4 hB1[KS], hB2[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
