@@ -661,12 +661,15 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         if (a > 0.f && a < 3.0e38f) (void)frexpf(a, &ex);
         sc = ldexpf(1.f, -ex);
     }
-    auto products = [&](int c0, float2 (&d)[CH]) {
+    // (TAIL: the carrier's last chunk of CSYM symbols -- clamped addresses, nothing beyond symbol ns - 1; every other chunk
+    // lies inside [0, ns) and needs neither)
+    auto products = [&](int c0, float2 (&d)[CH], auto tail_c) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(tail_c)::value;
         const int i0 = c0 + CH * tid;
         f32x4 v[CH / 2];
 #pragma unroll
-        for (int j = 0; j < CH / 2; ++j) v[j] = *(const f32x4_a8 *)(sr + min(i0 + 2 * j, ms2));
-        float2 pm = sr[max(min(i0, ms2) - 1, 0)];   // (used by lane 0 of a wavefront)
+        for (int j = 0; j < CH / 2; ++j) v[j] = *(const f32x4_a8 *)(sr + (TAIL ? min(i0 + 2 * j, ms2) : i0 + 2 * j));
+        float2 pm = sr[max((TAIL ? min(i0, ms2) : i0) - 1, 0)];   // (used by lane 0 of a wavefront)
         pm.x *= sc;
         pm.y *= sc;
 #pragma unroll
@@ -686,39 +689,45 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             px = cx;
             py = cy;
         }
-        if (c0 + CSYM > ns) {   // the carrier's last chunk: nothing beyond symbol ns - 1
-            asm volatile("" : "+v"(d[0].x));
+        if (TAIL) {
 #pragma unroll
             for (int u = 0; u < CH; ++u)
                 if (i0 + u >= ns) d[u] = make_float2(0.f, 0.f);
         }
     };
-    float a4r = 0.f, a4i = 0.f;
-    auto power4 = [&](const float2 (&d)[CH]) {
+    auto products_chunk = [&](int c0, float2 (&d)[CH]) __attribute__((always_inline)) {
+        if (c0 + CSYM > ns) products(c0, d, std::true_type{});
+        else products(c0, d, std::false_type{});
+    };
+    // sum of d^4 = (p + 2 i q)^2 with p = Re d^2 = x^2 - y^2, q = Im d^2 / 2 = x y:  p^2 - 4 q^2 + 4 i p q, the three sums
+    // kept apart (one multiply-add each per symbol) and combined once per thread
+    float a_pp = 0.f, a_qq = 0.f, a_pq = 0.f;
+    auto power4 = [&](const float2 (&d)[CH]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const float2 d2 = cmulf(d[u], d[u]);
-            const float2 d4 = cmulf(d2, d2);
-            a4r += d4.x;
-            a4i += d4.y;
+            const float x = d[u].x, y = d[u].y;
+            const float p4 = fmaf(x, x, -(y * y)), q4 = x * y;
+            a_pp = fmaf(p4, p4, a_pp);
+            a_qq = fmaf(q4, q4, a_qq);
+            a_pq = fmaf(p4, q4, a_pq);
         }
     };
     float2 dk[KEEP][CH];
 #pragma unroll
     for (int c = 0; c < KEEP; ++c)
         if (c * CSYM < ns) {
-            products(c * CSYM, dk[c]);
+            products_chunk(c * CSYM, dk[c]);
             power4(dk[c]);
         }
     for (int c0 = KEEP * CSYM; c0 < ns; c0 += CSYM) {
         float2 d[CH];
-        products(c0, d);
+        products_chunk(c0, d);
         power4(d);
     }
     {
-        // both sums through one exchange (same order of additions as two block_sum calls)
-        a4r = wave_sum(a4r);
-        a4i = wave_sum(a4i);
+        // both sums through one exchange
+        float a4r = wave_sum(fmaf(-4.f, a_qq, a_pp));
+        float a4i = wave_sum(4.f * a_pq);
         constexpr int NW = kRrcThreads / 64;
         if (lane == 0) { sm[wv] = a4r; sm2[wv] = a4i; }
         __syncthreads();
@@ -731,13 +740,16 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     }
     float rs, rc;
     __sincosf(-delta_s, &rs, &rc);   // |delta| <= pi/4
-    // ---- quadrant decision of d_k exp(-i delta): +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3
-    // smallest min(|re|,|im|) / max(|re|,|im|) (the angular distance to the nearest boundary is its atan), kept as the pair
-    // (lo, hi) and compared by cross-multiplication: one reciprocal per thread at the end instead of one per symbol
-    float mlo = 1.f, mhi = 0.f;
-    bool mhave = false;           // (a NaN symbol never enters: hi >= lo fails for it)
+    // ---- quadrant decision of dd = d_k exp(-i delta): +pi/4 -> 0, +3pi/4 -> 1, -pi/4 -> 2, -3pi/4 -> 3, i.e. the dibit
+    // (Im dd < 0, Re dd < 0) = the two sign bits (three integer instructions per symbol).
+    // Margin: smallest min(|re|,|im|) / max(|re|,|im|) (the angular distance to the nearest boundary is its atan), kept as the
+    // pair (lo, hi) and compared by cross-multiplication -- one reciprocal per thread at the end instead of one per symbol.
+    // The pair starts at (3e38, 1) ("no symbol yet": any symbol with hi > 0 replaces it); a symbol that is exactly zero
+    // (margin 0 by the definition's atan2(0, 0)) never wins a strict comparison and is caught by the smallest hi instead;
+    // a NaN symbol fails every comparison.
+    float mlo = 3.0e38f, mhi = 1.f, hmin = 3.0e38f;
     uint8_t *hr = hard + (int64_t)row * P.max_soft;
-    auto decide = [&](int c0, float2 (&d)[CH], auto tail_c) {
+    auto decide = [&](int c0, float2 (&d)[CH], auto tail_c) __attribute__((always_inline)) {
         constexpr bool TAIL = decltype(tail_c)::value;
         const int i0 = c0 + CH * tid;
         // (symbol 0: its slot repeats symbol 1, which leaves the minimum margin alone; its decision is not stored)
@@ -745,14 +757,21 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         uint32_t w[2] = {0u, 0u};
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const float2 dd = make_float2(d[u].x * rc - d[u].y * rs, d[u].x * rs + d[u].y * rc);
-            const uint32_t h = dd.y >= 0.f ? (dd.x >= 0.f ? 0u : 1u) : (dd.x >= 0.f ? 2u : 3u);
+            const float ddx = d[u].x * rc - d[u].y * rs, ddy = d[u].x * rs + d[u].y * rc;
+            uint32_t h = __builtin_bit_cast(uint32_t, ddy) >> 31;
+            h = __builtin_amdgcn_alignbit(h, __builtin_bit_cast(uint32_t, ddx), 31);   // (h << 1) | sign of Re
             w[u >> 2] |= h << (8 * (u & 3));
-            const float ax = fabsf(dd.x), ay = fabsf(dd.y);
-            const float lo = fminf(ax, ay), hi = fmaxf(ax, ay);
-            // lo / hi < mlo / mhi  <=>  lo * mhi < mlo * hi (all non-negative); the first symbol (mhi = 0) always replaces
-            const bool take = (hi >= lo) && (!mhave || lo * mhi < mlo * hi);
-            if ((!TAIL || (i0 + u < ns && i0 + u >= 1)) && take) { mlo = lo; mhi = hi; mhave = true; }
+            float lo = fminf(fabsf(ddx), fabsf(ddy)), hi = fmaxf(fabsf(ddx), fabsf(ddy));
+            if (TAIL) {   // symbols outside [1, ns): the neutral pair (ratio 1)
+                const bool valid = i0 + u < ns && i0 + u >= 1;
+                lo = valid ? lo : 1.f;
+                hi = valid ? hi : 1.f;
+            }
+            hmin = fminf(hmin, hi);
+            // lo / hi < mlo / mhi  <=>  lo * mhi < mlo * hi (all non-negative)
+            const bool take = lo * mhi < mlo * hi;
+            mlo = take ? lo : mlo;
+            mhi = take ? hi : mhi;
         }
         if (!TAIL && i0 > 0) {
             *(u32x2_a1 *)(hr + i0 - 1) = u32x2{w[0], w[1]};
@@ -762,7 +781,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 if (i0 + u >= 1 && i0 + u < ns) hr[i0 + u - 1] = (uint8_t)(w[u >> 2] >> (8 * (u & 3)));
         }
     };
-    auto decide_chunk = [&](int c0, float2 (&d)[CH]) {
+    auto decide_chunk = [&](int c0, float2 (&d)[CH]) __attribute__((always_inline)) {
         if (c0 + CSYM > ns) decide(c0, d, std::true_type{});
         else decide(c0, d, std::false_type{});
     };
@@ -771,10 +790,10 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         if (c * CSYM < ns) decide_chunk(c * CSYM, dk[c]);
     for (int c0 = KEEP * CSYM; c0 < ns; c0 += CSYM) {
         float2 d[CH];
-        products(c0, d);
+        products_chunk(c0, d);
         decide_chunk(c0, d);
     }
-    const float mratio = !mhave ? 3.4e38f : (mhi > 0.f ? mlo * __builtin_amdgcn_rcpf(mhi) : 0.f);
+    const float mratio = hmin == 0.f ? 0.f : mlo * __builtin_amdgcn_rcpf(mhi);   // (no symbol: 3e38)
     float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;   // (a NaN ratio never replaces the running minimum)
     margin = block_min(margin, sm);
     TT_MARK(11)

@@ -51,6 +51,82 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
     for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y;
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// Do matrix and vector instructions overlap?  (a) in ONE wavefront: an MFMA followed by NV independent v_fma_f32 / 4-cycle
+// instructions; (b) in TWO wavefronts of a SIMD: 512-thread workgroups, wavefronts 0-3 issue MFMAs only, 4-7 vector only
+// (ROLE 1: only the matrix wavefronts work, 2: only the vector ones, 3: both)
+template <int NV, int KIND>
+__global__ __launch_bounds__(256) void k_mix(float *out, int iters, float a, float b)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[2] = {f32x4{a, b, a, b}, f32x4{b, a, b, a}};
+    f32x4 w = f32x4{a, b, b, a};
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = a + i + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(acc[r & 1]) : "v"(w));
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[i & 7]) : "v"(a), "v"(b));
+                if (KIND == 1) asm volatile("v_max_f32 %0, %1, %0" : "+v"(v[i & 7]) : "v"(a));
+            }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s + acc[0].x + acc[1].y;
+}
+template <int ROLE>
+__global__ __launch_bounds__(512) void k_two(float *out, int iters, float a, float b)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[2] = {f32x4{a, b, a, b}, f32x4{b, a, b, a}};
+    f32x4 w = f32x4{a, b, b, a};
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = a + i + threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 4) {
+        if (ROLE & 1)
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(acc[r & 1]) : "v"(w));
+            }
+    } else {
+        if (ROLE & 2)
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("v_max_f32 %0, %1, %0" : "+v"(v[i & 7]) : "v"(a));   // 4 x 4 cycles = one MFMA
+                }
+            }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * 512 + threadIdx.x] = s + acc[0].x + acc[1].y;
+}
+template <class K> void run_k(const char *name, K kern, int threads, int wgs_per_cu, double groups_per_iter)
+{
+    float *out;
+    hipMalloc(&out, 256 * 512 * 16 * 4);
+    const int iters = 2000, grid = 256 * wgs_per_cu;
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, 0, out, iters, 1.0001f, 0.9999f);
+    hipEventRecord(a);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, 0, out, iters, 1.0001f, 0.9999f);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    ms /= 5;
+    // cycles per group (one MFMA [+ its vector instructions]) per wavefront-slot of a SIMD
+    printf("%-44s %d WG/CU: %.3f ms, %.2f cycles per group per SIMD at 2.4 GHz\n", name, wgs_per_cu, ms,
+           ms * 1e-3 * 2.4e9 / ((double)wgs_per_cu * iters * groups_per_iter));
+    hipFree(out);
+}
 template <int MODE> void run(const char *name, int wgs_per_cu)
 {
     float *out;
@@ -71,8 +147,22 @@ template <int MODE> void run(const char *name, int wgs_per_cu)
     printf("%-22s %d WG/CU: %.3f ms, %.2f cycles per wave-instruction per SIMD at 2.4 GHz\n", name, wgs_per_cu, ms, ms * 1e-3 * 2.4e9 / per_simd);
     hipFree(out);
 }
-int main()
+int main(int argc, char **argv)
 {
+    for (int w : {1, 2, 4}) {
+        run_k("mfma alone (k_mix NV=0)", k_mix<0, 0>, 256, w, 16);
+        run_k("mfma + 2 v_fma_f32", k_mix<2, 0>, 256, w, 16);
+        run_k("mfma + 4 v_fma_f32", k_mix<4, 0>, 256, w, 16);
+        run_k("mfma + 6 v_fma_f32", k_mix<6, 0>, 256, w, 16);
+        run_k("mfma + 8 v_fma_f32", k_mix<8, 0>, 256, w, 16);
+        run_k("mfma + 2 v_max_f32", k_mix<2, 1>, 256, w, 16);
+        run_k("mfma + 3 v_max_f32", k_mix<3, 1>, 256, w, 16);
+        run_k("mfma + 4 v_max_f32", k_mix<4, 1>, 256, w, 16);
+        run_k("two waves/SIMD: matrix wave only", k_two<1>, 512, w, 16);
+        run_k("two waves/SIMD: vector wave only (4 v_max)", k_two<2>, 512, w, 16);
+        run_k("two waves/SIMD: both", k_two<3>, 512, w, 16);
+    }
+    if (argc > 1) return 0;
     for (int w : {1, 4}) {
 #define R(M, N) if (w == 1) run<M>(N, 1); else run<M>(N, 4);
         R(0, "v_pk_fma_f32") R(1, "v_fma_f32") R(2, "v_fma_f64") R(3, "v_cndmask_b32") R(4, "v_mov_b32_dpp row_shr") R(5, "v_rcp_f32")
