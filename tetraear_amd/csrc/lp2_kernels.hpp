@@ -51,14 +51,17 @@ namespace tdm {
 // neighbouring lanes hit sixteen different 16-byte bank groups) and the coalesced one (slot = base + lane with base a
 // multiple of 16: XOR with a constant).  (One pad slot per 32 -- the cascade engine's layout, made for 8-sample lanes --
 // left this kernel's 16-sample lanes with two-way conflicts: 37 % of its LDS cycles.)
-TDM_HD int lp2_slot(int s) { return s ^ ((s >> 4) & 15); }
-static_assert(kLp2La == 16, "lp2_slot swizzles inside runs of 16 slots = one lane's samples");
+// (8-sample lanes, -DTDM_LP2_LA=8: slot = 8 lane + i; the lane's low bit already selects the upper or lower eight bank
+// groups, lane bits 1..3 = slot bits 4..6 are XORed into i)
+TDM_HD int lp2_slot(int s) { return s ^ ((s >> 4) & (kLp2La - 1)); }
+static_assert(kLp2La == 16 || kLp2La == 8, "lp2_slot swizzles inside a lane's run of slots");
+static_assert(kLp2Lanes <= (1 << kLp2GBits), "item word layout");
 
 struct Lp2Lds {
     static constexpr int kSlots = kLp2Span;
     static constexpr int kStage = 2 * kSlots;
     // small area (doubles): [0,256) wave totals and the causal state at the end of the row, [256, 256 + 40*32) power partials of the groups
-    static constexpr int oTot = 0, oPow = 256, kPowGroups = 39;
+    static constexpr int oTot = 0, oPow = 2 * (kLp2Lanes / 16) * kLp2Pairs * 4, kPowGroups = 39;
     static constexpr int kSmall = oPow + (kPowGroups + 1) * kMaxSps;
 };
 
@@ -104,9 +107,9 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     TDM_HD void item_operands(const Lp2Params &P, int row, int w0, int w1, f64x2 (&sdv)[2 * PzLayout::kMaxPairs], f64x2 (&cyv)[2 * PzLayout::kMaxPairs]) const
     {
         constexpr int ND = PzLayout::kMaxPairs, D = 2 * ND;
-        const int dir = (w0 >> 8) & 1, b = w1 >> 8, t = w1 & 255;
+        const int dir = (w0 >> kLp2GBits) & 1, b = w1 >> 8, t = w1 & 255;
         const bool last = (b == dec.nb - 1);
-        // seed rows of the group: outputs 16t, 16t+1 (causal), 16t+14, 16t+15 (anticausal); the block's carries
+        // seed rows of the group: outputs La t, La t + 1 (causal), La t + La - 2, La t + La - 1 (anticausal); the block's carries
         const f64x2 *sd = (const f64x2 *)(P.seeds + ((size_t)(last ? P.seed_groups : 0) + t) * kLp2SeedDoubles) + (dir ? 2 * ND : 0);   // (rows 16t, 16t+1 or 16t+14, 16t+15)
 #pragma unroll
         for (int k = 0; k < 2 * ND; ++k) sdv[k] = sd[k];
@@ -156,8 +159,8 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
                          const f64x2 (&cyv)[2 * PzLayout::kMaxPairs]) const
     {
         constexpr int La = kLp2La, ND = PzLayout::kMaxPairs;
-        const int g = w0 & 255, dir = (w0 >> 8) & 1, mask = (w0 >> 9) & 15;
-        const int base = g * La, sw = g & 15;          // lp2_slot(16 g + i) = 16 g + (i ^ (g & 15))
+        const int g = w0 & ((1 << kLp2GBits) - 1), dir = (w0 >> kLp2GBits) & 1, mask = (w0 >> (kLp2GBits + 1)) & 15;
+        const int base = g * La, sw = ((g * La) >> 4) & (La - 1);   // lp2_slot(La g + i) = La g + (i ^ sw)
         const int flip = dir ? La - 1 : 0;             // (La is a power of two: La - 1 - i == i ^ (La - 1))
         double vr[La], vi[La];
 #pragma unroll

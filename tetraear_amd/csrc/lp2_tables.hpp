@@ -12,8 +12,16 @@
 
 namespace tdm {
 
-constexpr int kLp2La = 16;       // samples per lane
-constexpr int kLp2Waves = 4;     // wavefronts per workgroup
+// -DTDM_LP2_LA=8: eight-sample lanes in eight wavefronts (the same 4096-position span and 64 KB of staging, twice the
+// threads: 16 wavefronts per compute unit if the kernel fits 128 VGPRs).  Measured on MI355X (round 3): results equal
+// (CPU lock-step emulation, oracle-pinned bench digest), but 90 VGPRs spill at the 128 cap (304 B of scratch per lane) and
+// the per-lane fixed work -- scans, item operands -- doubles: 0.658 ms against 0.331 ms.  Kept as a build switch, off.
+#ifndef TDM_LP2_LA
+#define TDM_LP2_LA 16
+#endif
+constexpr int kLp2La = TDM_LP2_LA;            // samples per lane (16; 8: see above)
+constexpr int kLp2Waves = 64 / kLp2La;        // wavefronts per workgroup: the span is 4096 positions = 64 KB of staging
+constexpr int kLp2GBits = 9;                  // item word 0: group in the span (< 512) | direction << 9 | pair mask << 10
 constexpr int kLp2Lanes = kLp2Waves * kWave;
 constexpr int kLp2Span = kLp2Lanes * kLp2La;   // positions a workgroup covers (chunk + both halos)
 // -DTDM_LP2_INLINE_CARRY: the low-rate kernel's carry-response items form the decimator's block carries themselves
@@ -57,7 +65,7 @@ struct Lp2Params {
     // reach_s of its end (beyond, the response is below kLp2FixTol of the signal).  The (group, direction, pairs) items a
     // chunk needs are listed on the host, costliest first, so that the wavefronts of the workgroup that work them off
     // hold items of equal cost:  two words per item after a two-word header:
-    //   w0 = group in the workgroup's span | direction << 8 | pair mask << 9,   w1 = decimator block << 8 | group in block
+    //   w0 = group in the workgroup's span | direction << kLp2GBits | pair mask << (kLp2GBits + 1),   w1 = decimator block << 8 | group in block
     // with header items[chunk * items_stride + 0 / 1] = items of the first pass / of a second pass behind a barrier (used
     // only when some group has an item in both directions: then causal items first, anticausal second)
     const int32_t *items;
@@ -183,8 +191,8 @@ inline Lp2Host build_lp2(const double (*sos)[6], int64_t n, int edge, int sps, c
                 auto bits = [](int v) { int k = 0; for (; v; v &= v - 1) ++k; return k; };
                 if (mc && ma) both = true;
                 // sort key (filled in below): pass, then costliest first
-                if (mc) it.push_back({16 - bits(mc), {g | (0 << 8) | (mc << 9), (b << 8) | t}});
-                if (ma) it.push_back({16 - bits(ma) + 1000, {g | (1 << 8) | (ma << 9), (b << 8) | t}});
+                if (mc) it.push_back({16 - bits(mc), {g | (0 << kLp2GBits) | (mc << (kLp2GBits + 1)), (b << 8) | t}});
+                if (ma) it.push_back({16 - bits(ma) + 1000, {g | (1 << kLp2GBits) | (ma << (kLp2GBits + 1)), (b << 8) | t}});
             }
             // one pass when no group has an item in both directions (long decimator blocks: the usual case); otherwise the
             // causal items, a barrier, the anticausal items

@@ -396,6 +396,7 @@ struct tdm_plan {
     const RefPlanHost &h() const { return cur->h; }
     // TETRA mode
     TetraParams tp{};
+    uint32_t *d_tapops = nullptr;   // TetraParams::tap_ops
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -599,7 +600,7 @@ static void plan_free(tdm_plan *p)
     p->variants.clear();
     for (auto &kv : p->d_shared)
         if (kv.second.second) (void)hipFree(kv.second.second);
-    void *ptrs[] = {p->d_work, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp};
+    void *ptrs[] = {p->d_work, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp, p->d_tapops};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -682,6 +683,14 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         clock((double)kRrcTile, tp.tile_c, tp.tile_s);
         tp.max_soft = (int32_t)(n_samples / sps) + 4;
         for (size_t i = 0; i < h.size(); ++i) tp.taps[i] = (float)h[i];
+        {
+            // the matched filter's constant operands, lane by lane (every carrier of every launch reads the same 4-6 KB)
+            std::vector<uint32_t> ops(tetra_tap_operand_words(tp.ntaps));
+            tetra_tap_operands(tp.taps, tp.ntaps, ops.data());
+            HIP_TRY(hipMalloc((void **)&p->d_tapops, ops.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(p->d_tapops, ops.data(), ops.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            tp.tap_ops = p->d_tapops;
+        }
         {
             std::unique_ptr<Variant> v(new Variant);
             v->h.sample_rate = sample_rate;

@@ -29,7 +29,7 @@ void lp2_timing_dump()
 
 // low-rate stage in one kernel (lp2_kernels.hpp): grid = (chunks, rows), one workgroup of 8 wavefronts per chunk
 template <class Src>
-__global__ __launch_bounds__(kLp2Lanes, 2) void k_lp2(const Lp2Params P, const Src src)
+__global__ __launch_bounds__(kLp2Lanes, kLp2Waves / 2) void k_lp2(const Lp2Params P, const Src src)
 {
     __shared__ __attribute__((aligned(16))) double stg[Lp2Lds::kStage];
     __shared__ __attribute__((aligned(16))) double sml[Lp2Lds::kSmall];

@@ -246,6 +246,15 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             if (j == NP - 1 && !last_turn) break;
             const int idx = tid + j * kRrcThreads;
             const int g = g0 + 2 * idx;               // chunk position of the pair's first sample
+            if (g0 + 2 * (64 * wv + j * kRrcThreads) >= n) {
+                // the wavefront's 64 pairs of this turn all lie past the end of the chunk: zeros, nothing to split (the fifth
+                // tile of an 8389-sample chunk: 13 of its 17 wavefront-turns)
+                if (j < NP - 1 || idx < NS / 2) {
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl) xsb[pl * PLANE + idx] = 0u;
+                }
+                continue;
+            }
             const bool in = g >= 0 && g <= gmaxp;
             const f32x4 v = pf[j];
             const float2 e0 = in ? make_float2(v.x, v.y) : (g == n - 1 ? x_last : make_float2(0.f, 0.f));
@@ -267,6 +276,14 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // Lane l supplies X[l & 15][32 s + 8 (l >> 4) .. + 7] (16 bytes per plane and step from LDS) and the constants
     // T[32 s + 8 (l >> 4) .. + 7][l & 15]; it receives Y[4 (l >> 4) + r][l & 15], r < 4.
     u32x4 hB1[KS], hB2[KS];
+    if (P.tap_ops) {   // (the plan's table: two 16-byte loads per step instead of the split below)
+        const u32x4 *tp = (const u32x4 *)P.tap_ops + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            hB1[s] = tp[(2 * s) * 64];
+            hB2[s] = tp[(2 * s + 1) * 64];
+        }
+    } else
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         uint32_t w1[4], w2[4];

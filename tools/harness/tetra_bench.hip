@@ -51,6 +51,16 @@ int main(int argc, char **argv)
     tp.tile_c = (float)cos(-2 * M_PI * kRrcTile / sps);
     tp.tile_s = (float)sin(-2 * M_PI * kRrcTile / sps);
     for (size_t i = 0; i < h.size(); ++i) tp.taps[i] = (float)h[i];
+#ifndef TDM_HARNESS_NO_TAPOPS
+    {
+        std::vector<uint32_t> ops(tetra_tap_operand_words(tp.ntaps));
+        tetra_tap_operands(tp.taps, tp.ntaps, ops.data());
+        uint32_t *d_ops;
+        hipMalloc((void **)&d_ops, ops.size() * 4);
+        hipMemcpy(d_ops, ops.data(), ops.size() * 4, hipMemcpyHostToDevice);
+        tp.tap_ops = d_ops;
+    }
+#endif
     // pi/4-DQPSK-like rows: random symbols through the same RRC at 4 samples/symbol plus noise, 8 distinct rows
     std::vector<float2> x((size_t)n * 8);
     unsigned s = 12345;
