@@ -19,6 +19,7 @@
 #include "../../tetraear_amd/csrc/gate_kernels.hpp"
 #include "../../tetraear_amd/csrc/detect_kernels.hpp"
 #include "../../tetraear_amd/csrc/small_dft.hpp"
+#include "../../tetraear_amd/csrc/tetra_taps.hpp"
 
 using namespace tdm;
 
@@ -303,6 +304,13 @@ static void small_dft_host(const float *in, float *out)
 static bool g_allow_pz = true, g_allow_raw = true;
 
 extern "C" {
+
+// the TETRA-mode plan's matched-filter operand table (tetra_taps.hpp), as the library uploads it
+int64_t emu_tetra_tap_operands(const float *taps, int ntaps, uint32_t *out)
+{
+    if (out) tdm::tetra_tap_operands(taps, ntaps, out);
+    return (int64_t)tdm::tetra_tap_operand_words(ntaps);
+}
 
 // tests: 0 forces the cascade engine for every decimation factor (the generic fallback of the library)
 void emu_allow_parallel_form(int on) { g_allow_pz = on != 0; }
