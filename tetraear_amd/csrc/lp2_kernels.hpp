@@ -593,7 +593,12 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
 #endif   // TDM_LP2_MEMONLY
     LP2_T(4);
     // ---------------- output: through LDS; one thread per (timing phase, group) stores its phase's samples and sums their powers ----------------
-    cm.sync();   // (all lanes have taken their input out of the staging area)
+    // (No barrier here: a lane writes the slots only it has read since the carry responses were added; the one place
+    // where lanes read their neighbours' slots -- the odd extension in a chunk that holds an end of the row -- lies before
+    // the scans' barrier.  Round 2 and the first half of round 3 had one, "all lanes have taken their input out".)
+#ifdef TDM_LP2_MEMONLY
+    cm.sync();
+#endif
 #pragma unroll
     for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{or_[i], oi[i]};
     cm.sync();
