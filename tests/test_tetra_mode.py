@@ -87,6 +87,31 @@ def test_gpu_tetra_noise_and_silence_do_not_crash():
 
 
 @pytest.mark.gpu
+def test_gpu_tetra_final_passes_edge_cases():
+    """The final passes (differential products, 4th-power estimate, decisions, margin) work on chunks of 2048 symbols with
+    a separate path for a carrier's last chunk: symbol counts just below, at and above a multiple of 2048, and a silent
+    carrier (every product exactly zero: decisions 0 and margin 0 by the definition's atan2(0, 0)), against the definition."""
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    fs = 72000.0
+    seen = set()
+    for n in list(range(8186, 8214, 3)) + [16384, 16388, 24580]:
+        x, dib = make_signal(n, fs, 100 + n, 0.2, 30.0, 25.0)
+        bd = BatchDemodulator(fs, n, 2, "cf32", mode=MODE_TETRA)
+        hards, softs, timing, margin = bd.process(np.concatenate([x, np.zeros(n, np.complex64)]))
+        bd.close()
+        ref_hard, _, info = tetra_np.demod(x.astype(np.complex128), fs)
+        assert len(softs[0]) == info["n_sym"]
+        np.testing.assert_array_equal(hards[0], ref_hard)
+        assert abs(margin[0] - info["margin"]) < 1e-3
+        seen.add(info["n_sym"] % 2048)
+        zh, _, zinfo = tetra_np.demod(np.zeros(n, np.complex128), fs)
+        assert len(softs[1]) == zinfo["n_sym"] and not hards[1].any() and not zh.any()
+        assert margin[1] == 0.0 and zinfo["margin"] == 0.0
+    assert min(seen) <= 2 and max(seen) >= 2040   # (both sides of a chunk boundary were exercised)
+
+
+@pytest.mark.gpu
 def test_gpu_tetra_every_rate_in_the_contract_and_nonfinite_input():
     """Channel rates whose RRC length is not one the kernel is instantiated for (45 / 50 / 60 kHz: 21, 23, 27 taps) run
     with the taps centred in the next length up and still equal the fp64 definition; a NaN / Inf sample in one
