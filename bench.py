@@ -505,6 +505,11 @@ def main():
         print(json.dumps(out), flush=True)
     if group is not None:
         group.close()
+    if rank == 0:
+        bad = [k for k in ("tetra", "pfb", "wideband") if isinstance(out.get(k), dict)
+               and str(out[k].get("output_check", {}).get("status", "")).startswith("DIFFERS")]
+        if bad:   # (the line is printed for the record; the run does not count as a success)
+            raise SystemExit(f"bench: output check failed in leg(s) {bad}")
 
 
 def leg_single(carriers, steps, warmup):
@@ -588,7 +593,12 @@ def leg_pfb(carriers, steps, warmup):
     M, D, n_in = PFB_M, PFB_D, int(os.environ.get("TDM_BENCH_PFB_NIN", PFB_NIN))
     n_out = (n_in + D - 1) // D
     streams = max(1, carriers // 400)
-    u8 = pfb_stream()[:2 * n_in]
+    if n_in == PFB_NIN:
+        u8 = pfb_stream()
+    else:   # (experiment sizes: a stream of exactly the length the kernel reads, never a slice shorter than that)
+        from tetraear_amd import synth
+        u8 = synth.noise_cu8(n_in, 1)
+    assert len(u8) == 2 * n_in
     din = DeviceBuffer(0, streams * n_in * 2)
     pitch = (n_out + 15) // 16 * 16   # 128-byte aligned channel rows
     dout = DeviceBuffer(0, streams * M * pitch * 8)
@@ -634,8 +644,17 @@ def leg_pfb(carriers, steps, warmup):
                                      traffic_src=traffic_src, timing="HIP events on the kernel's stream, one kernel per step")}
 
 
+def _print_leg(out):
+    """a north-star leg run on its own: the JSON line, then -- as main() does for the headline -- a non-zero exit when the
+    leg's output differs from the pinned definition (a number from wrong output must not look like a result)"""
+    print(json.dumps(out), flush=True)
+    status = str(out.get("output_check", {}).get("status", ""))
+    if status.startswith("DIFFERS"):
+        raise SystemExit(f"bench: output check failed: {status}")
+
+
 def main_pfb(args):
-    print(json.dumps(leg_pfb(args.carriers, args.steps, args.warmup)))
+    _print_leg(leg_pfb(args.carriers, args.steps, args.warmup))
 
 
 def leg_wideband(carriers, steps, warmup):
@@ -700,11 +719,11 @@ def leg_wideband(carriers, steps, warmup):
 
 
 def main_wideband(args):
-    print(json.dumps(leg_wideband(args.carriers, args.steps, args.warmup)))
+    _print_leg(leg_wideband(args.carriers, args.steps, args.warmup))
 
 
 def main_tetra(args):
-    print(json.dumps(leg_tetra(args.carriers, args.steps, args.warmup)))
+    _print_leg(leg_tetra(args.carriers, args.steps, args.warmup))
 
 
 def leg_tetra(carriers, steps, warmup):

@@ -100,13 +100,14 @@ def test_fallback_decision_is_collective():
 
 @pytest.mark.timeout(120)
 def test_foreign_listener_on_the_first_candidate_port_is_skipped():
-    """something else listens on MASTER_PORT + 1 and never speaks the protocol: rank 0 binds the next port, the others
-    recognise the stranger by the missing acknowledgement and move on"""
+    """something else listens on the first rendezvous port and never speaks the protocol: rank 0 binds the next port, the
+    others recognise the stranger by the missing acknowledgement and move on"""
+    from tetraear_amd.rccl import _port_base
     port = _free_port()
     stranger = socket.socket()
     stranger.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     try:
-        stranger.bind(("127.0.0.1", port + 1))
+        stranger.bind(("127.0.0.1", _port_base(port)))
     except OSError:
         pytest.skip("port taken")
     stranger.listen(4)
@@ -115,3 +116,54 @@ def test_foreign_listener_on_the_first_candidate_port_is_skipped():
         assert [r[1] for r in res] == ["ok", "ok"]
     finally:
         stranger.close()
+
+
+def test_rendezvous_ports_keep_clear_of_the_launchers_range(monkeypatch):
+    """the ports rank 0 may bind lie >= 1000 above MASTER_PORT (a second launcher's MASTER_PORT + 1, + 2 ... stay free),
+    wrap below 65536, and TDM_RCCL_PORT overrides them"""
+    from tetraear_amd import rccl
+    assert rccl._port_base(29500) == 30500
+    for mp in (1024, 29500, 64000, 64500, 65535):
+        b = rccl._port_base(mp)
+        assert 1024 <= b and b + rccl._PORT_SPAN <= 65536
+        assert not (mp < b + rccl._PORT_SPAN and b <= mp + 64), (mp, b)
+
+
+@pytest.mark.timeout(60)
+def test_a_rank_that_connects_again_gets_the_decision_on_its_newer_socket():
+    """rank 1's first handshake breaks right after rank 0's acknowledgement (the socket is dropped); it connects again.
+    Rank 0 must deliver the decision on the newer connection instead of writing to the stale one and leaving the rank to
+    time out -- with world 2 (the stale socket was the last awaited one) and with world 3 (another rank still missing)."""
+    import struct
+    import threading
+    from tetraear_amd import rccl
+    for world in (2, 3):
+        port = _free_port()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="again")
+        res = {}
+
+        def run(rank):
+            res[rank] = rccl.rendezvous(rank, world, True, lambda: b"payload!", timeout_s=30.0)
+
+        t0 = threading.Thread(target=run, args=(0,))
+        t0.start()
+        # the broken first attempt of rank 1: token, rank, flag; read the acknowledgement; drop the connection
+        base, s = rccl._port_base(port), None
+        for _ in range(200):
+            try:
+                s = socket.create_connection(("127.0.0.1", base), timeout=1.0)
+                break
+            except OSError:
+                import time
+                time.sleep(0.02)
+        assert s is not None
+        s.sendall(rccl._token(world) + struct.pack("<iB", 1, 1))
+        assert rccl._recv_exact(s, len(rccl._MAGIC)) == rccl._MAGIC
+        s.close()
+        others = [threading.Thread(target=run, args=(r,)) for r in range(1, world)]
+        for t in others:
+            t.start()
+        for t in [t0] + others:
+            t.join(40)
+            assert not t.is_alive()
+        assert all(res[r] == (True, b"payload!") for r in range(world)), res

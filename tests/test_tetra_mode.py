@@ -111,6 +111,60 @@ def test_gpu_tetra_final_passes_edge_cases():
     assert min(seen) <= 2 and max(seen) >= 2040   # (both sides of a chunk boundary were exercised)
 
 
+def _end_of_chunk_contract(hard_dev, ns_dev, x, fs):
+    """The contract at a chunk's end: the device forms the symbol instants in fp32 from fp32 timing
+    estimates, the definition in fp64, so an instant within rounding of the bound t <= n - 3 may be kept by one and dropped
+    by the other.  Allowed: a symbol COUNT that differs by at most one, and then only with the deciding instant at the
+    bound; every decision both sides made must be equal.  Returns the count difference (device - definition)."""
+    n = len(x)
+    ref_hard, _, info = tetra_np.demod(x.astype(np.complex128), fs)
+    diff = int(ns_dev) - int(info["n_sym"])
+    assert abs(diff) <= 1, (fs, n, ns_dev, info["n_sym"])
+    m = min(len(hard_dev), len(ref_hard))
+    np.testing.assert_array_equal(hard_dev[:m], ref_hard[:m])
+    if diff:
+        t = info["t"]
+        # device dropped the definition's last symbol: that instant sits just under the bound; device kept one more: the
+        # definition's next instant (one symbol period on) sits just over it
+        t_edge = t[-1] if diff < 0 else t[-1] + (t[-1] - t[-2])
+        assert abs(t_edge - (n - 3.0)) < 5e-3, (fs, n, diff, t_edge)
+    return diff
+
+
+@pytest.mark.gpu
+def test_gpu_tetra_end_of_chunk_symbol_count_bound():
+    """(a) the carrier of the round-3 sweep whose last instant lies 1.3e-6 samples under the bound (fixture
+    tests/golden/tetra_edge.npz, made by tests/golden/make_golden_tetra_edge.py): the device returns the definition's
+    count or one fewer, all common decisions equal.  (b) a seeded slice built to land on the bound: timing offsets that
+    put the symbol instants on whole samples, chunk lengths through every residue of the symbol period."""
+    import os
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tetra_edge.npz"))
+    x, fs = g["x"], float(g["fs"])
+    bd = BatchDemodulator(fs, len(x), 1, "cf32", mode=MODE_TETRA)
+    hards, softs, _, _ = bd.process(x)
+    bd.close()
+    assert int(g["n_sym"]) == 2817 and abs(float(g["t_last"]) - (len(x) - 3.0)) < 1e-4
+    d = _end_of_chunk_contract(hards[0], len(softs[0]), x, fs)
+    assert d in (0, -1)
+    m = min(len(hards[0]), len(g["hard"]))
+    np.testing.assert_array_equal(hards[0][:m], g["hard"][:m])   # (the committed decisions, not only today's definition)
+    seen = {0: 0, 1: 0, -1: 0}
+    for fs, toffs in ((72000.0, (0.0, 0.25, 0.5)), (108000.0, (0.0, 1.0 / 6.0, 0.5)), (144000.0, (0.0, 0.125))):
+        sps = int(fs / 18000.0)
+        for ti, toff in enumerate(toffs):
+            n0 = 2900 + 37 * ti
+            xfull, _ = make_signal(n0 + 2 * sps + 1, fs, 900 + ti, toff, 15.0, 25.0)
+            for n in range(n0, n0 + 2 * sps + 1):
+                xr = np.ascontiguousarray(xfull[:n])
+                bd = BatchDemodulator(fs, n, 1, "cf32", mode=MODE_TETRA)
+                hards, softs, _, _ = bd.process(xr)
+                bd.close()
+                seen[_end_of_chunk_contract(hards[0], len(softs[0]), xr, fs)] += 1
+    assert sum(seen.values()) >= 80, seen
+
+
 @pytest.mark.gpu
 def test_gpu_tetra_every_rate_in_the_contract_and_nonfinite_input():
     """Channel rates whose RRC length is not one the kernel is instantiated for (45 / 50 / 60 kHz: 21, 23, 27 taps) run
@@ -134,10 +188,14 @@ def test_gpu_tetra_every_rate_in_the_contract_and_nonfinite_input():
     bad = good.copy()
     bad[1000] = np.nan
     bad[5000] = np.inf
-    bd = BatchDemodulator(fs, n, 3, "cf32", mode=MODE_TETRA)
-    hards, softs, timing, margin = bd.process(np.concatenate([bad, good, bad]))
+    bd = BatchDemodulator(fs, n, 4, "cf32", mode=MODE_TETRA)
+    hards, softs, timing, margin = bd.process(np.concatenate([bad, good, bad, np.full(n, np.nan, np.complex64)]))
     assert best_ber(hards[1], dib, edge=8)[0] == 0.0
     assert all(np.all(h <= 3) for h in hards)
+    # a carrier without a single comparable decision (every symbol NaN) reports the "no decision" margin, not the neutral
+    # ratio of the slots past its last symbol (atan(1) = 0.785 before round 4)
+    assert margin[3] > 3.0e38, margin[3]
+    assert 0.0 < margin[1] < 0.8
     bd.close()
 
 

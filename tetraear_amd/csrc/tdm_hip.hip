@@ -591,11 +591,14 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
 
 static size_t fmt_bytes(int fmt) { return fmt == TDM_CU8 || fmt == TDM_CS8 ? 2 : (fmt == TDM_CF32 ? 8 : 16); }
 
+static void sync_scratch_release(int device, hipStream_t st);   // (find_sync's per-stream scratch, below)
+
 static void plan_free(tdm_plan *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->stream) sync_scratch_release(p->device, p->stream);   // the stream goes away: so does the scratch keyed by it
     p->cur = nullptr;
     p->variants.clear();
     for (auto &kv : p->d_shared)
@@ -1579,11 +1582,15 @@ int tdm_detect(const double *x, int64_t n, int32_t rows, double sample_rate, dou
 
 // ---- burst sync: TetraDecoder.find_sync on the hard symbols, batched ---------------
 namespace {
+// Scratch of the device-pointer form, one buffer per (device, stream), process-wide: launches on one stream are ordered
+// whichever thread issues them, so they can share it.  The mutex is held from the look-up to the end of the enqueue, so a
+// buffer is never replaced between another caller's look-up and its launches; an entry goes away with its stream
+// (plan_free -> sync_scratch_release), so a long-lived thread that creates and destroys plans does not pile them up.
 struct SyncScratch { void *p = nullptr; size_t bytes = 0; };
 struct SyncScratchMap {
+    std::mutex mu;
     std::map<std::pair<int, hipStream_t>, SyncScratch> m;
-    SyncScratch &of(int device, hipStream_t st) { return m[std::make_pair(device, st)]; }
-    ~SyncScratchMap()   // thread exit: give the buffers back (errors ignored: the runtime may already be gone at process exit)
+    ~SyncScratchMap()   // process exit: give the buffers back (errors ignored: the runtime may already be gone)
     {
         int cur = 0;
         if (hipGetDevice(&cur) != hipSuccess) return;
@@ -1592,8 +1599,18 @@ struct SyncScratchMap {
         (void)hipSetDevice(cur);
     }
 };
-thread_local SyncScratchMap tl_sync_scratch;
+SyncScratchMap g_sync_scratch;
 }  // namespace
+
+// (the caller has made `device` current and synchronised `st`)
+static void sync_scratch_release(int device, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_sync_scratch.mu);
+    auto it = g_sync_scratch.m.find(std::make_pair(device, st));
+    if (it == g_sync_scratch.m.end()) return;
+    if (it->second.p) (void)hipFree(it->second.p);
+    g_sync_scratch.m.erase(it);
+}
 
 int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_units, int32_t rows, int32_t from_bits,
                   double threshold, int32_t max_pos, int32_t *positions, int32_t *n_pos, double *max_corr,
@@ -1629,12 +1646,14 @@ int tdm_find_sync(const uint8_t *units, int64_t row_stride, const int32_t *n_uni
         u = du.as<uint8_t>(); nu = dn.as<int32_t>(); pp = dp.as<int32_t>(); np_ = dnp.as<int32_t>(); mc = dmc.as<double>();
     }
     // scratch for the per-position counts: for the device-pointer form (asynchronous: it must outlive the call) one
-    // buffer per (calling thread, device, stream) -- launches on one stream are ordered, so they can share it; another
-    // device or another stream gets its own -- released with the call otherwise
+    // buffer per (device, stream) -- launches on one stream are ordered, so they can share it; another device or another
+    // stream gets its own; it goes away with the plan that owns the stream -- released with the call otherwise
     uint16_t *cnt = nullptr;
     const size_t cnt_bytes = (size_t)rows * max_bits * 2;
+    std::unique_lock<std::mutex> scratch_lock(g_sync_scratch.mu, std::defer_lock);
     if (device_pointers) {
-        SyncScratch &sc = tl_sync_scratch.of(device, st);
+        scratch_lock.lock();   // held until both launches are enqueued
+        SyncScratch &sc = g_sync_scratch.m[std::make_pair((int)device, st)];
         if (sc.bytes < cnt_bytes) {
             if (sc.p) {
                 HIP_TRY(hipStreamSynchronize(st));   // the only stream that ever used this buffer

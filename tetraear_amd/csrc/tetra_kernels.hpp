@@ -779,10 +779,11 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             h = __builtin_amdgcn_alignbit(h, __builtin_bit_cast(uint32_t, ddx), 31);   // (h << 1) | sign of Re
             w[u >> 2] |= h << (8 * (u & 3));
             float lo = fminf(fabsf(ddx), fabsf(ddy)), hi = fmaxf(fabsf(ddx), fabsf(ddy));
-            if (TAIL) {   // symbols outside [1, ns): the neutral pair (ratio 1)
+            if (TAIL) {   // symbols outside [1, ns) repeat the running pair: they never win the strict comparison, so a
+                          // carrier without a single decision (ns <= 1) keeps the "no symbol" sentinel
                 const bool valid = i0 + u < ns && i0 + u >= 1;
-                lo = valid ? lo : 1.f;
-                hi = valid ? hi : 1.f;
+                lo = valid ? lo : mlo;
+                hi = valid ? hi : mhi;
             }
             hmin = fminf(hmin, hi);
             // lo / hi < mlo / mhi  <=>  lo * mhi < mlo * hi (all non-negative)
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         products_chunk(c0, d);
         decide_chunk(c0, d);
     }
-    const float mratio = hmin == 0.f ? 0.f : mlo * __builtin_amdgcn_rcpf(mhi);   // (no symbol: 3e38)
+    const float mratio = hmin == 0.f ? 0.f : mlo * __builtin_amdgcn_rcpf(mhi);   // (no decision, ns <= 1 or all NaN: 3e38)
     float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;   // (a NaN ratio never replaces the running minimum)
     margin = block_min(margin, sm);
     TT_MARK(11)

@@ -11,7 +11,7 @@ reads in memory.  Two page-locked host buffers are filled in turn by a reader th
 one (rows of a batch = consecutive reads); ONE plan serves the whole recording -- the remainder batch runs on the
 same plan with its unused rows blank, the last, shorter read through tdm_plan_resize.
 """
-import io
+import os
 import threading
 
 import numpy as np
@@ -23,14 +23,21 @@ from tetraear_amd.batch import BatchDemodulator
 
 def _open(source):
     """-> (readinto(buffer) -> bytes read, close())"""
-    if isinstance(source, (str, bytes)):
-        f = open(source, "rb", buffering=0)
+    if isinstance(source, (str, bytes, os.PathLike)):
+        f = open(os.fspath(source), "rb", buffering=0)
         return f.readinto, f.close
     if hasattr(source, "readinto"):          # file object, pipe (sys.stdin.buffer), socket file
         return source.readinto, (lambda: None)
-    arr = np.ascontiguousarray(source, dtype=np.uint8).reshape(-1)
-    f = io.BytesIO(arr.data)                  # (no copy: a view of the caller's array)
-    return f.readinto, f.close
+    # an array of interleaved bytes: handed out through a view with an offset (io.BytesIO would copy the recording)
+    src = memoryview(np.ascontiguousarray(source, dtype=np.uint8).reshape(-1))
+    pos = [0]
+
+    def readinto(view):
+        k = min(len(view), len(src) - pos[0])
+        view[:k] = src[pos[0]:pos[0] + k]
+        pos[0] += k
+        return k
+    return readinto, (lambda: None)
 
 
 def _fill(readinto, view):
@@ -83,7 +90,7 @@ def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0,
                 break
             t = None
             if got == batch_bytes:               # (a short batch means the source has ended)
-                t = threading.Thread(target=read_into, args=(slot ^ 1,))
+                t = threading.Thread(target=read_into, args=(slot ^ 1,), daemon=True)
                 t.start()
             n_reads, tail = divmod(got // 2, chunk)
             if n_reads:
@@ -106,13 +113,19 @@ def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0,
             t = None
             slot ^= 1
     finally:
+        # the consumer stopped early (or an error): the reader thread may sit in a pipe read that never returns.  It is a
+        # daemon; it gets a moment to finish, and if it does not, the buffer it writes into is left registered and alive
+        # (held by the thread's closure) rather than unpinned under it.
+        stuck = False
         if t is not None:
-            t.join()
+            t.join(2.0)
+            stuck = t.is_alive()
         if bd is not None:
             bd.close()
-        for b in pinned:
-            lib.tdm_host_unregister(device, ptr(b))
-        close()
+        if not stuck:
+            for b in pinned:
+                lib.tdm_host_unregister(device, ptr(b))
+            close()
 
 
 def demodulate_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0, rows_per_batch=64, device=0):

@@ -30,7 +30,14 @@ NCCL_UNIQUE_ID_BYTES = 128
 ncclFloat64, ncclInt64 = 8, 4
 ncclSum, ncclMax = 0, 2
 _PORT_SPAN = 64
-_MAGIC = b"TDMRCCL2"
+_MAGIC = b"TDMRCCL3"
+
+
+def _port_base(master_port):
+    """first rendezvous port for a launch whose store listens on `master_port`: 1000 + above it, folded back under 65536 - span"""
+    hi = 65536 - _PORT_SPAN
+    p = master_port + 1000
+    return p if p < hi else 1024 + (p - hi) % (hi - 1024)
 
 
 class RcclUnavailable(RuntimeError):
@@ -101,7 +108,13 @@ def rendezvous(rank, world, usable, make_payload, timeout_s=120.0, addr=None, ba
     """Collective decision + payload hand-off.  Every rank passes `usable`; rank 0 also passes make_payload() -> bytes
     (called only when every rank is usable).  Returns (all_usable, payload or b"")."""
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-    base = int(base_port if base_port is not None else os.environ.get("MASTER_PORT", "29500")) + 1
+    # the rendezvous ports lie well away from the launcher's own range: a second launcher on the node normally takes
+    # MASTER_PORT + 1, + 2, ... as ITS master port, and a rank 0 of ours squatting there would stop that job from starting
+    # (TDM_RCCL_PORT overrides the base)
+    if base_port is None:
+        env = os.environ.get("TDM_RCCL_PORT")
+        base_port = int(env) if env else _port_base(int(os.environ.get("MASTER_PORT", "29500")))
+    base = int(base_port)
     token = _token(world)
     deadline = time.time() + timeout_s
     if world == 1:
@@ -120,32 +133,50 @@ def rendezvous(rank, world, usable, make_payload, timeout_s=120.0, addr=None, ba
                 s.close()
         if srv is None:
             raise RuntimeError(f"rccl rendezvous: no free port in {base}..{base + _PORT_SPAN - 1} on {addr}")
-        peers, flags = {}, {0: bool(usable)}
+        # peers[r]: the NEWEST connection of rank r; confirmed: the ranks that acknowledged the decision.  A rank whose
+        # handshake broke (before or after our acknowledgement) simply connects again: the newer socket replaces the stale
+        # one, and a decision that could not be delivered (send error, no acknowledgement) puts the rank back among the
+        # awaited ones instead of leaving it to time out.
+        peers, flags, confirmed = {}, {0: bool(usable)}, set()
+        decision, payload = None, b""
         try:
-            while len(peers) < world - 1:
-                srv.settimeout(max(0.1, deadline - time.time()))
-                try:
-                    conn, _ = srv.accept()
-                except socket.timeout:
-                    raise TimeoutError(f"rccl rendezvous: {world - 1 - len(peers)} rank(s) never arrived") from None
-                try:
-                    conn.settimeout(10.0)
-                    if _recv_exact(conn, len(token)) != token:
-                        conn.close()          # not one of this launch's ranks
+            while len(confirmed) < world - 1:
+                while len(peers) + len(confirmed) < world - 1:
+                    srv.settimeout(max(0.1, deadline - time.time()))
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        raise TimeoutError(f"rccl rendezvous: {world - 1 - len(peers) - len(confirmed)} rank(s) never arrived") from None
+                    try:
+                        conn.settimeout(10.0)
+                        if _recv_exact(conn, len(token)) != token:
+                            conn.close()          # not one of this launch's ranks
+                            continue
+                        r, ok = struct.unpack("<iB", _recv_exact(conn, 5))
+                        conn.sendall(_MAGIC)      # immediate acknowledgement: the peer knows it found this launch's rank 0
+                    except (OSError, ConnectionError, struct.error):
+                        conn.close()
                         continue
-                    r, ok = struct.unpack("<iB", _recv_exact(conn, 5))
-                    conn.sendall(_MAGIC)      # immediate acknowledgement: the peer knows it found this launch's rank 0
-                except (OSError, ConnectionError, struct.error):
+                    if 0 < r < world and r not in confirmed:
+                        if r in peers:
+                            peers[r].close()
+                        peers[r] = conn
+                        flags.setdefault(r, bool(ok))
+                    else:
+                        conn.close()
+                if decision is None:
+                    decision = all(flags.values())
+                    payload = make_payload() if decision else b""
+                for r, conn in list(peers.items()):
+                    try:
+                        conn.sendall(struct.pack("<BI", 1 if decision else 0, len(payload)) + payload)
+                        if _recv_exact(conn, 1) != b"K":
+                            raise ConnectionError("no acknowledgement")
+                        confirmed.add(r)
+                    except (OSError, ConnectionError):
+                        pass                      # the rank connects again (or the deadline passes)
                     conn.close()
-                    continue
-                if 0 < r < world and r not in peers:
-                    peers[r], flags[r] = conn, bool(ok)
-                else:
-                    conn.close()
-            decision = all(flags.values())
-            payload = make_payload() if decision else b""
-            for conn in peers.values():
-                conn.sendall(struct.pack("<BI", 1 if decision else 0, len(payload)) + payload)
+                    del peers[r]
         finally:
             for conn in peers.values():
                 conn.close()
@@ -169,6 +200,7 @@ def rendezvous(rank, world, usable, make_payload, timeout_s=120.0, addr=None, ba
                 head = _recv_exact(s, 5)
                 decision, n = struct.unpack("<BI", head)
                 payload = _recv_exact(s, n) if n else b""
+                s.sendall(b"K")               # delivered: rank 0 stops waiting for this rank
                 return bool(decision), payload
             except (OSError, ConnectionError, struct.error) as e:
                 last = e
