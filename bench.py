@@ -158,14 +158,23 @@ def wideband_stream():
     return synth.quantise_cu8(x, scale=1.0 / (4.0 * np.sqrt(len(WIDEBAND_CHANNELS) + 1.0))), dibs
 
 
-def make_batch(carriers, chunk, fmt, rank):
-    """Synthetic batch: a few distinct pi/4-DQPSK carriers (own symbol seed each), tiled."""
+STREAM_SEED0 = 1000   # stream g of the job has seed 1000 + g
+
+
+def carrier_offsets(first, carriers):
+    """post-decimation frequency offset of the job's carriers first .. first + carriers - 1 (21 values on the gate's AFC grid)"""
+    g = np.arange(first, first + carriers)
+    return (((g * 5) % 21) - 10) * 117.1875
+
+
+def make_batch(carriers, chunk, fmt, first=0, workers=None):
+    """Synthetic batch: `carriers` DISTINCT pi/4-DQPSK streams -- the job's carriers first .. first + carriers - 1, stream
+    g with symbol / noise seed 1000 + g ("1024 separate cu8 streams (seeds 1000 + i)") and its own
+    frequency offset.  Weak scaling: rank r holds the carriers r * C .. r * C + C - 1; strong scaling: its slice of the
+    one job.  (Up to round 3 a batch tiled 8 distinct streams.)"""
     from tetraear_amd import synth
-    distinct = min(carriers, 8)
-    base = [synth.dqpsk_cu8(chunk, SAMPLE_RATE, seed=1000 * (rank + 1) + i, carrier_offset=0.0)[0]
-            for i in range(distinct)]
-    u8 = np.concatenate([base[i % distinct] for i in range(carriers)])
-    foffs = np.array([((i * 5) % 21 - 10) * 117.1875 for i in range(carriers)], dtype=np.float64)
+    u8 = synth.dqpsk_cu8_streams(chunk, SAMPLE_RATE, [STREAM_SEED0 + first + i for i in range(carriers)], workers).reshape(-1)
+    foffs = carrier_offsets(first, carriers).astype(np.float64)
     if fmt == "cu8":
         return u8, foffs
     x = synth.cu8_to_c128(u8)
@@ -333,18 +342,16 @@ def main():
     bd.sync()
     plan_create_ms = (time.perf_counter() - t_plan) * 1e3
     bd.alloc_device_io(shared_input=args.shared)
+    gen_workers = max(1, min(64, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     if args.shared:
         iq, foffs = make_batch(1, args.chunk, args.fmt, rank)
         foffs = np.zeros(carriers)
         pre = shared_offsets(carriers)
         bd.upload(iq, freq_offsets=None, pre_shifts=pre)
-    elif strong:
-        iq, foffs = make_batch(args.total_carriers, args.chunk, args.fmt, 0)
-        per = len(iq) // args.total_carriers
-        iq, foffs = iq[lo * per: hi * per], foffs[lo:hi]
-        bd.upload(iq, freq_offsets=foffs)
     else:
-        iq, foffs = make_batch(carriers, args.chunk, args.fmt, rank)
+        # every carrier of the job is its own stream: this rank's are first .. first + carriers - 1
+        first = lo if strong else rank * carriers
+        iq, foffs = make_batch(carriers, args.chunk, args.fmt, first, gen_workers)
         if args.zero_foff:
             foffs = foffs * 0.0
         bd.upload(iq, freq_offsets=foffs)
@@ -438,7 +445,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"{carriers} carriers shifted out of ONE shared {args.chunk}-sample {args.fmt} stream "
                                     f"@{args.rate / 1e6:g} MS/s (SURVEY 8(d) C3)") if args.shared else
-                                   (f"{total} independent 25 kHz carriers over {world} GPU(s) ({carriers} on rank 0), "
+                                   (f"{total} independent 25 kHz carriers, every one its own stream (seeds 1000 + g), over {world} GPU(s) ({carriers} on rank 0), "
                                     f"{args.chunk}-sample {args.fmt} chunks @{args.rate / 1e6:g} MS/s (SURVEY 8(d) C4"
                                     f"{'' if strong else ' per-GPU share x ' + str(world)})"),
                        "carriers_per_gpu": carriers, "chunk_samples": args.chunk, "in_fmt": args.fmt,

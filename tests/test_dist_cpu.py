@@ -81,18 +81,24 @@ def test_two_rank_job_matches_single_process():
 
 
 def test_strong_scaling_partition_covers_the_batch_once():
-    """bench.py --total-carriers: the ranks' slices of the one global batch are disjoint, in order and complete."""
+    """bench.py --total-carriers: every rank generates ITS slice of the one job (carriers lo .. hi - 1, seeds 1000 + g); the
+    slices are disjoint, in order, complete, and equal to the job generated in one piece.  Weak scaling: rank r's batch is
+    the job's carriers r * C .. r * C + C - 1, so the ranks' streams never repeat."""
     import bench
     from tetraear_amd.shard import carrier_range
     total, chunk = 21, 512
     iq, foffs = bench.make_batch(total, chunk, "cu8", 0)
-    per = len(iq) // total
+    assert len(np.unique(iq.reshape(total, -1), axis=0)) == total      # every carrier its own stream
     for world in (1, 2, 4, 8):
         parts, offs = [], []
         for r in range(world):
             lo, hi = carrier_range(total, r, world)
-            parts.append(iq[lo * per: hi * per])
-            offs.append(foffs[lo:hi])
+            p, o = bench.make_batch(hi - lo, chunk, "cu8", lo)
+            parts.append(p)
+            offs.append(o)
         assert np.array_equal(np.concatenate(parts), iq) and np.array_equal(np.concatenate(offs), foffs)
         sizes = [len(o) for o in offs]
         assert max(sizes) - min(sizes) <= 1
+    a, _ = bench.make_batch(4, chunk, "cu8", 0)
+    b, _ = bench.make_batch(4, chunk, "cu8", 4)
+    assert np.array_equal(np.concatenate([a, b]), bench.make_batch(8, chunk, "cu8", 0)[0])

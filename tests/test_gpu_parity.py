@@ -399,14 +399,21 @@ def test_random_lengths_and_rates_vs_oracle(cu8_engine):
 
 def test_c4_full_batch_every_carrier_vs_oracle():
     """BASELINE config 4 at its full size, the very batch bench.py times: 1024 carriers x 262144 cu8 samples through
-    BatchDemodulator.enqueue; every carrier's hard symbols and timing phase equal the C oracle's (8 signals x 21
-    offsets = 168 oracle runs), soft <= 1e-10, and the digest bench.py asserts after its timed region is this one."""
+    BatchDemodulator.enqueue -- 1024 DISTINCT streams (seeds 1000 + i); every carrier's hard symbols and
+    timing phase equal the C oracle's (1024 oracle runs), soft <= 1e-10, the digest bench.py asserts after its timed
+    region is this one, and the strong-scaling slices of the batch (8 GPUs x 128) have the digests pinned for them."""
     import bench
+    from tetraear_amd.shard import carrier_range
     from tools.make_bench_digest import check_batch
-    digest, n_oracle, worst = check_batch(1024, 262144, 0)
-    assert n_oracle == 168 and worst <= SOFT_TOL
+    digest, n_oracle, worst, (hard, n_soft, bp) = check_batch(1024, 262144, 0, want_rows=True)
+    assert n_oracle == 1024 and worst <= SOFT_TOL
     want = bench.expected_digest(bench.digest_key(1024, 262144, "cu8", bench.SAMPLE_RATE, 0, False))
     assert want is not None and digest == want
+    for world in (2, 4, 8):
+        for r in range(world):
+            lo, hi = carrier_range(1024, r, world)
+            key = bench.digest_key(hi - lo, 262144, "cu8", bench.SAMPLE_RATE, r, False) + f":strong{lo}-{hi}of1024"
+            assert bench.expected_digest(key) == bench.output_digest(hard[lo:hi], n_soft[lo:hi], bp[lo:hi]), key
 
 
 def test_decimate_entry_vs_goldens(gold_stages):

@@ -101,6 +101,35 @@ def dqpsk_cu8(n_samples, sample_rate=2.4e6, seed=1, esn0_db=20.0, carrier_offset
     return quantise_cu8(y, scale=1.0 / peak), dibits
 
 
+def _dqpsk_cu8_job(job):
+    n_samples, sample_rate, seed = job
+    return dqpsk_cu8(n_samples, sample_rate, seed=seed)[0]
+
+
+def dqpsk_cu8_streams(n_samples, sample_rate, seeds, workers=None):
+    """`dqpsk_cu8` for many seeds -> uint8 [len(seeds)][2 * n_samples], every stream its own symbols and noise (SURVEY 8(d)
+    C4: "1024 separate cu8 streams, seeds 1000 + i").  One stream costs ~0.3 s of numpy on arrays long enough for numpy to
+    drop the interpreter lock, so more than a few of them are made by a pool of THREADS (no fork or spawn beside a HIP /
+    RCCL context, no re-import of the caller's main module); the bytes are the ones
+    `dqpsk_cu8(n_samples, sample_rate, seed)` returns, in the order of `seeds`."""
+    import os
+    seeds = [int(s) for s in seeds]
+    out = np.empty((len(seeds), 2 * n_samples), dtype=np.uint8)
+    jobs = [(int(n_samples), float(sample_rate), s) for s in seeds]
+    if workers is None:
+        workers = min(64, os.cpu_count() or 1)
+    workers = max(1, min(int(workers), len(seeds) // 2))
+    if workers == 1:
+        for i, j in enumerate(jobs):
+            out[i] = _dqpsk_cu8_job(j)
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as pool:
+        for i, u8 in enumerate(pool.map(_dqpsk_cu8_job, jobs)):
+            out[i] = u8
+    return out
+
+
 def multicarrier_cu8(n_samples, sample_rate, offsets_hz, seed0=100, esn0_db=20.0):
     """Sum of carriers at the given offsets in one wideband stream."""
     acc = np.zeros(n_samples, dtype=np.complex128)
