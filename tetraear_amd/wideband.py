@@ -21,10 +21,16 @@ class WidebandReceiver:
     """`streams` wideband streams of `n_in` samples at `sample_rate` -> M channels each, spaced
     sample_rate/M and decimated by D (channel rate sample_rate/D), all demodulated per call."""
 
-    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0, slots=1):
+    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0, slots=1, group=None):
         """slots = 2: two independent (channel buffer, demodulator plan) pairs, each with its own stream.  Consecutive
         batches go to alternating slots (enqueue(slot=k % 2)), so the channeliser of batch k+1 -- bound by its output
-        stores -- runs beside the demodulation of batch k -- bound by instruction issue -- instead of behind it."""
+        stores -- runs beside the demodulation of batch k -- bound by instruction issue -- instead of behind it.
+
+        group = G (a divisor of `streams`): the batch is worked off in sub-batches of G streams (enqueue_grouped): the
+        channel rows of a sub-batch (G x M x pitch x 8 bytes: 27 MB per 10 MS/s stream) are written into a buffer small
+        enough to stay in the 256 MB Infinity Cache and read back from there by the sub-batch's demodulation, instead of
+        860 MB per 32-stream batch going out to HBM and coming back; sub-batches alternate between the slots, outputs of
+        all sub-batches land in ONE set of output buffers (`out`)."""
         self.lib = _lib.load()
         self.fmt = _FMT_OF[fmt]
         self.device = device
@@ -32,14 +38,24 @@ class WidebandReceiver:
         self.n_out = (self.n_in + self.D - 1) // self.D
         self.pitch = aligned_pitch(self.n_out)
         self.d_in = DeviceBuffer(device, self.streams * self.n_in * FMT_BYTES[self.fmt])
+        self.group = int(group) if group else self.streams
+        if self.streams % self.group:
+            raise ValueError("group must divide streams")
         self.slots = []
         for _ in range(int(slots)):
-            d_ch = DeviceBuffer(device, self.streams * self.M * self.pitch * 8)
-            demod = BatchDemodulator(self.sample_rate / self.D, self.n_out, self.streams * self.M, "cf32",
+            d_ch = DeviceBuffer(device, self.group * self.M * self.pitch * 8)
+            demod = BatchDemodulator(self.sample_rate / self.D, self.n_out, self.group * self.M, "cf32",
                                      device=device, mode=MODE_TETRA)
-            demod.alloc_device_io()
+            if self.group == self.streams:
+                demod.alloc_device_io()
             self.slots.append((d_ch, demod))
         self.d_ch, self.demod = self.slots[0]
+        self.out = None
+        if self.group != self.streams:
+            rows, ms = self.streams * self.M, self.demod.info.max_soft
+            self.out = {"hard": DeviceBuffer(device, rows * ms), "soft": DeviceBuffer(device, rows * ms * 8),
+                        "n_soft": DeviceBuffer(device, rows * 4), "bp": DeviceBuffer(device, rows * 4),
+                        "mm": DeviceBuffer(device, rows * 8)}
 
     def process(self, iq):
         """iq: the streams back to back in the plan's wire format.  Returns (hard, n_sym, timing, margin):
@@ -68,6 +84,37 @@ class WidebandReceiver:
         finally:
             demod.release_stream()
 
+    def enqueue_grouped(self, d_in=None):
+        """the whole batch as streams / group sub-batches, alternating between the slots (see __init__)"""
+        no = C.c_int64()
+        rows_g, ms = self.group * self.M, self.demod.info.max_soft
+        in_bytes = self.group * self.n_in * FMT_BYTES[self.fmt]
+        base = (d_in or self.d_in).ptr.value
+        o = self.out
+        for g in range(self.streams // self.group):
+            d_ch, demod = self.slots[g % len(self.slots)]
+            demod.make_stream_current()
+            try:
+                check(self.lib.tdm_channelise_batch(C.c_void_p(base + g * in_bytes), self.fmt, self.n_in, self.group, self.M,
+                                                    self.D, d_ch.ptr, self.pitch, C.byref(no), 1, self.device))
+                r0 = g * rows_g
+                check(self.lib.tdm_process_device(demod.handle, d_ch.ptr, self.pitch, None, None,
+                                                  C.c_void_p(o["hard"].ptr.value + r0 * ms),
+                                                  C.c_void_p(o["soft"].ptr.value + r0 * ms * 8),
+                                                  C.c_void_p(o["n_soft"].ptr.value + r0 * 4),
+                                                  C.c_void_p(o["bp"].ptr.value + r0 * 4),
+                                                  C.c_void_p(o["mm"].ptr.value + r0 * 8), None))
+            finally:
+                demod.release_stream()
+
+    def download_grouped(self):
+        rows, ms = self.streams * self.M, self.demod.info.max_soft
+        o = self.out
+        n_soft = o["n_soft"].download(np.int32, rows)
+        hard = o["hard"].download(np.uint8, rows * ms).reshape(rows, ms)
+        soft = o["soft"].download(np.complex64, rows * ms).reshape(rows, ms)
+        return hard, soft, n_soft, o["bp"].download(np.int32, rows), o["mm"].download(np.float64, rows)
+
     def sync(self):
         for _, demod in self.slots:
             demod.sync()
@@ -81,4 +128,8 @@ class WidebandReceiver:
             demod.close()
             d_ch.free()
         self.slots = []
+        if self.out:
+            for b in self.out.values():
+                b.free()
+            self.out = None
         self.d_in.free()
