@@ -36,12 +36,15 @@ EXECUTED_FLOP_PER_INPUT_SAMPLE = 5080 * 2 / 120.0
 IRREDUCIBLE_FLOP_PER_INPUT_SAMPLE = 3840 * 2 / 120.0
 
 _CEILING = None
+PMC_CHILD = "--pmc-child" in sys.argv   # this process is the short run a parent bench counts HBM traffic on
 
 
 def hbm_ceiling(device=0):
     """Measured HBM ceilings of THIS box (the roofline denominator is an on-box copy-kernel figure): the
     library's own copy / read / write kernels over 2 x 1 GiB, once per bench process (~0.3 s)."""
     global _CEILING
+    if PMC_CHILD:
+        return {"skipped": "pmc child"}
     if _CEILING is None:
         import ctypes as C
         from tetraear_amd import _lib
@@ -64,6 +67,8 @@ def hbm_roofline(kernel, bytes_alg, ms, read_bytes=None, traffic=None, traffic_s
            "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": ms}
     if traffic_src:
         out["traffic_source"] = traffic_src
+    if traffic:
+        out["traffic_over_algorithmic"] = traffic / bytes_alg
     c = hbm_ceiling(device)
     if "copy" in c:
         out["peak_measured"] = c["copy"]
@@ -232,6 +237,64 @@ def measured_traffic(samples_per_launch, fmt, key="k1"):
     return prof[key]["hbm_bytes_per_input_sample"] * samples_per_launch, os.path.basename(files[-1])
 
 
+def live_traffic(child_args, kernel_match, timeout_s=240):
+    """HBM bytes per launch of the kernel whose name contains `kernel_match`, measured NOW on this box: two rocprofv3
+    counter passes (FETCH_SIZE, WRITE_SIZE -- separate passes, with --kernel-trace only, as MI355X_MICROARCH.md's HBM
+    section prescribes; FETCH_SIZE doubled on gfx950, counter unit KB) over a short child run of this script
+    (`child_args` + 2 steps; the child skips its own measurements of this kind).  None when rocprofv3 is not there, the
+    process is itself being profiled, TDM_BENCH_LIVE_PMC=0, or a pass fails / times out -- the caller then falls back to
+    the last committed profile and says so in `traffic_source`."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("TDM_BENCH_LIVE_PMC", "1") == "0" or shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):   # nested profilers do not mix
+        return None
+    env = dict(os.environ, TDM_BENCH_LIVE_PMC="0", TMPDIR="/tmp")
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory(prefix="tdm_pmc_", dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "c", "--",
+                       sys.executable, os.path.abspath(__file__)] + list(child_args) + ["--steps", "2", "--warmup", "1", "--pmc-child"]
+                r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+                if r.returncode != 0:
+                    return None
+                vals = collections.defaultdict(list)
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            if row["Counter_Name"] == counter and kernel_match in row["Kernel_Name"]:
+                                vals[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+                if len(vals) != 1:
+                    return None
+                name, v = next(iter(vals.items()))
+                out["kernel"] = name
+                out[counter] = sum(v) / len(v) * 1024.0
+                out["launches_" + counter] = len(v)
+    except Exception:  # noqa: BLE001 -- a side measurement never breaks the bench line
+        return None
+    return {"kernel": out["kernel"], "fetch_bytes_raw": out["FETCH_SIZE"], "fetch_bytes_corrected_x2": 2 * out["FETCH_SIZE"],
+            "write_bytes": out["WRITE_SIZE"], "hbm_bytes_per_launch": 2 * out["FETCH_SIZE"] + out["WRITE_SIZE"],
+            "launches_averaged": [out["launches_FETCH_SIZE"], out["launches_WRITE_SIZE"]],
+            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a 2-step child run of "
+                   "this command on this box, inside this bench run; FETCH_SIZE x 2 (gfx950), unit KB"}
+
+
+def traffic_now(child_args, kernel_match, samples_per_launch, fmt, key):
+    """(traffic bytes per launch, source, detail): measured live if possible, else the last committed profile's figure"""
+    live = live_traffic(child_args, kernel_match)
+    if live is not None:
+        return live["hbm_bytes_per_launch"], "live: rocprofv3 PMC passes inside this bench run", live
+    t, src = measured_traffic(samples_per_launch, fmt, key)
+    return t, (src + " (committed profile: live PMC passes unavailable)") if src else None, None
+
+
 def cpu_baseline(chunk, budget_s=10.0):
     """The CPU oracle (C restatement of the reference chain, single thread) on the same workload,
     bounded to ~budget_s of CPU work.  Reported next to the GPU number; never the thing shipped."""
@@ -296,6 +359,8 @@ def main():
     ap.add_argument("--total-carriers", type=int, default=0,
                     help="strong scaling: this many carriers in total, block-partitioned over the ranks (BASELINE config 4: 1024)")
     ap.add_argument("--no-extra", action="store_true", help="skip the tetra / pfb / wideband / single-carrier legs appended at N = 1")
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="(internal) the short run rocprofv3 counts HBM traffic on: noise input, no output check, no side measurements")
     args = ap.parse_args()
 
     if args.mode == "tetra":
@@ -343,7 +408,17 @@ def main():
     plan_create_ms = (time.perf_counter() - t_plan) * 1e3
     bd.alloc_device_io(shared_input=args.shared)
     gen_workers = max(1, min(64, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
-    if args.shared:
+    if args.pmc_child:
+        # (the counters do not care what the bytes say: uniform noise, made in a second instead of the job's 1024 streams)
+        from tetraear_amd import synth
+        iq = synth.noise_cu8((1 if args.shared else carriers) * args.chunk, 7)
+        if args.fmt != "cu8":
+            iq = synth.cu8_to_c128(iq).astype(np.complex64 if args.fmt == "cf32" else np.complex128)
+        if args.shared:
+            bd.upload(iq, freq_offsets=None, pre_shifts=shared_offsets(carriers))
+        else:
+            bd.upload(iq, freq_offsets=carrier_offsets(0, carriers).astype(np.float64))
+    elif args.shared:
         iq, foffs = make_batch(1, args.chunk, args.fmt, rank)
         foffs = np.zeros(carriers)
         pre = shared_offsets(carriers)
@@ -365,7 +440,7 @@ def main():
     # 0.56 -> 0.68 -> 0.50 ms for the decimator, profiles/*_kernel_timed.json), so a short --warmup would put the timed
     # region inside the ramp.  Untimed passes of the same hot path are added in front of the warm-up until at least
     # SETTLE_STEPS passes have run; the W warm-up steps and the K timed steps follow unchanged.
-    settle_steps = max(0, SETTLE_STEPS - args.warmup)
+    settle_steps = 0 if args.pmc_child else max(0, SETTLE_STEPS - args.warmup)
     for _ in range(settle_steps):
         bd.enqueue()
     for _ in range(args.warmup):
@@ -396,11 +471,13 @@ def main():
     # the output of the last timed step is checked, not just counted: its digest must equal the one pinned to the oracle
     dkey = digest_key(carriers, args.chunk, args.fmt, args.rate, rank, args.shared) + (f":strong{lo}-{hi}of{args.total_carriers}" if strong and world > 1 else "")
     digest, want = output_digest(hard, n_soft, bp), expected_digest(dkey)
-    mismatch = want is not None and digest != want and not args.zero_foff
+    if args.zero_foff or args.pmc_child:
+        want = None
+    mismatch = want is not None and digest != want
     output_check = {"key": dkey, "sha256": digest,
                     "status": "matches oracle-pinned digest" if want == digest else
-                              ("no pinned digest for this workload" if want is None else
-                               ("DIFFERS from the oracle-pinned digest" if mismatch else "not compared"))}
+                              ("not compared" if (args.zero_foff or args.pmc_child) else
+                               ("no pinned digest for this workload" if want is None else "DIFFERS from the oracle-pinned digest"))}
 
     # (a rank whose check failed still takes part in the reductions: the failure count is reduced with the job and ALL
     # ranks stop together below; leaving early would strand the others inside ncclAllReduce)
@@ -424,11 +501,21 @@ def main():
         contract_tf = samples_per_launch * FLOP_PER_INPUT_SAMPLE / (k1_ms * 1e-3) / 1e12
         # executed flops: exact for the raw-byte kernel (dec_engine 3, the bench's case); the double-based kernel executes
         # 52.5 FMAs per sample and the cascade engine 133 issue slots: other engines report the same field from their counts
-        exec_flop = {3: EXECUTED_FLOP_PER_INPUT_SAMPLE, 2: 105.0, 1: 266.0}.get(bd.info.dec_engine, EXECUTED_FLOP_PER_INPUT_SAMPLE)
+        # (a call with an input-rate pre-shift -- --shared -- runs the double-based kernel whatever the batch size: the raw-byte
+        # kernel works on integers, and a rotated sample is none; tdm_plan_info cannot know the call's arguments)
+        engine = 2 if (args.shared and bd.info.dec_engine == 3) else bd.info.dec_engine
+        # --shared adds, per input sample, the conversion (4 flop) and the input-rate NCO that reproduces the reference's own
+        # rounding of its phase (NcoRunT: Markstein quotient 10, phase 1, phasor advance 6, correction 7, rotation 6: ~35 flop)
+        exec_flop = {3: EXECUTED_FLOP_PER_INPUT_SAMPLE, 2: 105.0, 1: 266.0}.get(engine, EXECUTED_FLOP_PER_INPUT_SAMPLE) + (39.0 if args.shared else 0.0)
         executed_tf = samples_per_launch * exec_flop / (k1_ms * 1e-3) / 1e12
         irreducible_tf = samples_per_launch * IRREDUCIBLE_FLOP_PER_INPUT_SAMPLE / (k1_ms * 1e-3) / 1e12
-        ceil = hbm_ceiling(local_rank) if world == 1 else {}
-        traffic, traffic_src = measured_traffic(samples_per_launch, args.fmt)
+        ceil = hbm_ceiling(local_rank) if (world == 1 and not args.pmc_child) else {}
+        traffic, traffic_src, traffic_detail = None, None, None
+        if world == 1 and not args.pmc_child:
+            child = ["--carriers", str(carriers), "--chunk", str(args.chunk), "--fmt", args.fmt, "--rate", repr(args.rate),
+                     "--no-cpu-baseline", "--no-extra"] + (["--shared"] if args.shared else [])
+            traffic, traffic_src, traffic_detail = traffic_now(child, "k_pz_raw<" if engine == 3 else ("k_pz_block<" if engine == 2 else "k_zp_block<"),
+                                                               samples_per_launch, args.fmt, "k1")
         total = args.total_carriers if strong else carriers * world
         out = {
             "metric": "Msymbols/s demodulated (reference-parity mode, hard symbols written)",
@@ -461,9 +548,11 @@ def main():
             "stage_ms_per_launch": stage_ms,
             "roofline": {
                 "kernel": ("k_pz_raw<10,12,27> (zero-phase Chebyshev-8 decimator in parallel form: causal + anticausal all-pole banks on the raw samples)"
-                           if bd.info.dec_engine == 3 else
-                           "k_pz_block (the same decimator with the samples held as doubles: few carriers, or a wire format other than cu8)"
-                           if bd.info.dec_engine == 2 else "k_zp_block (cascade engine)"),
+                           if engine == 3 else
+                           ("k_pz_block<shift> (the same decimator on doubles, every sample first rotated by its carrier's input-rate NCO: frequency_shift(x, f_k) of the shared stream)"
+                            if args.shared else
+                            "k_pz_block (the same decimator with the samples held as doubles: few carriers, or a wire format other than cu8)")
+                           if engine == 2 else "k_zp_block (cascade engine)"),
                 "bound": "valu_fp64",
                 # frac = what the fp64 vector ALUs execute over their peak (never > 1); round 2 reported SURVEY 8(d)'s
                 # operation count over the measured time here, which the parallel form undercuts (1.02 "of peak")
@@ -482,6 +571,7 @@ def main():
                                                "rate can exceed the ALU peak and is NOT a fraction of anything the kernel does"},
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_detail": traffic_detail,
                 "hbm": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                         "peak_measured": ceil.get("copy"),
@@ -492,7 +582,7 @@ def main():
             },
             "hbm_ceiling_measured": ceil or None,
         }
-        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not args.pmc_child:   # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.chunk)
             try:
                 out["cpu_baseline_allcore"] = cpu_baseline_allcore(args.chunk)
@@ -617,7 +707,7 @@ def leg_pfb(carriers, steps, warmup):
         def step():
             # one launch for all streams (grid.y = stream)
             _lib.check(L.tdm_channelise_batch(din.ptr, 0, n_in, streams, M, D, dout.ptr, pitch, C.byref(no), 1, 0))
-        for _ in range(max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
+        for _ in range(warmup if PMC_CHILD else max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
             step()
         clock.sync()
         clock.time_begin()
@@ -640,7 +730,8 @@ def leg_pfb(carriers, steps, warmup):
     din.free()
     dout.free()
     bytes_alg = streams * (n_in * 2 + M * n_out * 8)
-    traffic, traffic_src = measured_traffic(streams * n_in, "tetra-cf32", key="pfb")
+    traffic, traffic_src, traffic_detail = (None, None, None) if PMC_CHILD else traffic_now(
+        ["--mode", "pfb", "--carriers", str(carriers)], "k_pfb_fft<", streams * n_in, "tetra-cf32", "pfb")
     return {"metric": "channeliser throughput (tetra mode, polyphase DFT filter bank)", "value": streams * n_in / (ms * 1e-3) / 1e6,
             "unit": "Msamples/s in", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": ms,
             "higher_is_better": True, "dtype": "f32", "data": "synthetic",
@@ -648,7 +739,8 @@ def leg_pfb(carriers, steps, warmup):
             "realtime_10MSps_streams": streams * n_in / (ms * 1e-3) / 10e6,
             "output_check": check,
             "roofline": hbm_roofline("k_pfb_fft<20,20,3,32>", bytes_alg, ms, read_bytes=streams * n_in * 2, traffic=traffic,
-                                     traffic_src=traffic_src, timing="HIP events on the kernel's stream, one kernel per step")}
+                                     traffic_src=traffic_src, traffic_detail=traffic_detail,
+                                     timing="HIP events on the kernel's stream, one kernel per step")}
 
 
 def _print_leg(out):
@@ -681,7 +773,7 @@ def leg_wideband(carriers, steps, warmup):
     rx = WidebandReceiver(fs, n_in, M, D, streams=streams, fmt="cu8", slots=2)
     rx.d_in.upload(np.tile(u8, streams))
     bd = rx.demod
-    for _ in range(max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
+    for _ in range(warmup if PMC_CHILD else max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
         rx.enqueue()
     bd.sync()
     bd.time_begin()
@@ -747,7 +839,7 @@ def leg_tetra(carriers, steps, warmup):
     bd.alloc_device_io()
     base = tetra_rows()
     bd.upload(np.concatenate([base[i % TETRA_DISTINCT] for i in range(rows)]))
-    for _ in range(max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
+    for _ in range(warmup if PMC_CHILD else max(warmup, SETTLE_STEPS)):   # (clock settling: see main())
         bd.enqueue()
     bd.sync()
     bd.time_begin()
@@ -762,7 +854,8 @@ def leg_tetra(carriers, steps, warmup):
     nsym = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
     rrc_ms = st.get("tetra_fused", float("nan"))
     bytes_alg = rows * n * 8 + int(np.sum(n_soft.astype(np.int64))) * 9
-    traffic, traffic_src = measured_traffic(rows * n, "tetra-cf32", key="tetra_fused")
+    traffic, traffic_src, traffic_detail = (None, None, None) if PMC_CHILD else traffic_now(
+        ["--mode", "tetra", "--carriers", str(rows)], "k_tetra_fused<", rows * n, "tetra-cf32", "tetra_fused")
     # ---- output check against the definition's pinned results
     d8 = [rows_digest(hard, n_soft, [r]) for r in range(min(rows, TETRA_DISTINCT))]
     same = all(rows_digest(hard, n_soft, [r]) == d8[r % TETRA_DISTINCT] for r in range(TETRA_DISTINCT, rows))
@@ -787,7 +880,7 @@ def leg_tetra(carriers, steps, warmup):
            "output_check": check,
            "roofline": hbm_roofline("k_tetra_fused<33> (RRC matched filter on the matrix cores (split-bf16 products, fp32 accumulate) -> timing -> Farrow -> slicer, one pass over the input)",
                                     bytes_alg, rrc_ms, read_bytes=rows * n * 8, traffic=traffic, traffic_src=traffic_src,
-                                    bytes_per_symbol=bytes_alg / max(nsym, 1))}
+                                    traffic_detail=traffic_detail, bytes_per_symbol=bytes_alg / max(nsym, 1))}
     bd.close()
     return out
 

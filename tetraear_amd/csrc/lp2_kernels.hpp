@@ -627,7 +627,11 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
             f64x2 *po = zt + (int64_t)p2 * P.zt_k + (k0 + g2);
             for (; j < jhi; j += step, po += ngrp) {
                 const f64x2 v = stage[lp2_slot(j - jc32)];
+#ifdef TDM_LP2_ONEPHASE   // experiment: only one timing phase's samples are stored (results are wrong, timing only)
+                if (p2 == 3) *po = v;
+#else
                 *po = v;
+#endif
                 if (j < lim) acc += fma(v.x, v.x, v.y * v.y);
             }
             small[Lp2Lds::oPow + g2 * kMaxSps + p2] = acc;
