@@ -1776,26 +1776,63 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
     const bool force_direct = std::getenv("TDM_PFB_DIRECT") != nullptr;
     if (!force_direct && D <= 4 * M) {
         const int64_t rounds = (n_out + TB - 1) / TB;
-        {
-            // rounds per workgroup: one workgroup per compute unit is resident (146 KB of LDS at M = 400), so the launch runs
-            // in ceil(workgroups / CUs) waves of G rounds each plus a start-up of about a third of a round per workgroup;
-            // the G that minimises that (32 streams x 263 rounds: G = 3 -> 2816 workgroups = exactly 11 waves, 0.235 ms;
-            // round 2's G = 4 -> 8.25 waves, 0.244 ms)
-            static int cu_count[64] = {0};   // (per device, asked once)
-            int &cus = cu_count[device & 63];
-            if (cus == 0) {
-                hipDeviceProp_t prop;
-                cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-            }
+        // rounds per workgroup: `per_cu` workgroups per compute unit are resident (one of k_pfb_fft's 146 KB at M = 400, two of
+        // k_pfb_h2's 80 KB), so the launch runs in ceil(workgroups / slots) waves of G rounds each plus a start-up of about
+        // a third of a round per workgroup; the G that minimises that (32 streams x 263 rounds, one per CU: G = 3 -> 2816
+        // workgroups = exactly 11 waves, 0.235 ms; round 2's G = 4 -> 8.25 waves, 0.244 ms)
+        static int cu_count[64] = {0};   // (per device, asked once)
+        int &cus = cu_count[device & 63];
+        if (cus == 0) {
+            hipDeviceProp_t prop;
+            cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        auto pick_rounds = [&](int per_cu) {
             double best = 1e300;
-            Q.G = 1;
+            int G = 1;
+            const int64_t slots = (int64_t)cus * per_cu;
             for (int g = 1; g <= 8; ++g) {
                 const int64_t wgs = ((rounds + g - 1) / g) * n_streams;
-                const double cost = (double)((wgs + cus - 1) / cus) * (g + 0.3);
-                if (cost < best - 1e-9) { best = cost; Q.G = g; }
+                const double cost = (double)((wgs + slots - 1) / slots) * (g + 0.3);
+                if (cost < best - 1e-9) { best = cost; G = g; }
+            }
+            if (const char *e = std::getenv("TDM_PFB_G")) G = std::max(1, std::atoi(e));   // experiments
+            return G;
+        };
+        if constexpr (M1 == M2 && M1 % 2 == 0 && TB % 2 == 0 && WGS == 1) {
+            // 8-bit wire formats, TDM_PFB_HALFTILE=1: the half-tile kernel, two workgroups per compute unit (pfb_kernels.hpp:
+            // correct, measured slower than the full-tile kernel -- 0.335 against 0.237 ms per 32 x 1 Mi samples -- and off)
+            const size_t lds2 = pfb_h2_lds_bytes<M1, M2, P, TB>(D);
+            if ((fmt == TDM_CU8 || fmt == TDM_CS8) && lds2 <= 80 * 1024 && std::getenv("TDM_PFB_HALFTILE")) {
+                void (*kern)(const void *, cf32v *, int64_t, const PfbParams) =
+                    fmt == TDM_CU8 ? k_pfb_h2<M1, M2, P, TB, 0> : k_pfb_h2<M1, M2, P, TB, 1>;
+                Q.G = pick_rounds(2);
+                HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                const unsigned blocks = (unsigned)((rounds + Q.G - 1) / Q.G);
+#ifdef TDM_PFB_TIMING
+                static unsigned long long *dbg2 = nullptr;
+                if (!dbg2) HIP_TRY(hipMalloc(&dbg2, 128));
+                HIP_TRY(hipMemset(dbg2, 0, 128));
+                Q.dbg = dbg2;
+#endif
+                hipLaunchKernelGGL(kern, dim3(blocks, n_streams), dim3(TB * M2 / 2), lds2, st, iq, (cf32v *)out, pitch, Q);
+                HIP_TRY(hipGetLastError());
+#ifdef TDM_PFB_TIMING
+                {
+                    unsigned long long hd[16];
+                    HIP_TRY(hipMemcpy(hd, dbg2, 128, hipMemcpyDeviceToHost));
+                    const double rt = (double)rounds * n_streams;
+                    int occ = -1;
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, TB * M2 / 2, lds2);
+                    fprintf(stderr, "pfb_h2: %d workgroups per CU by the occupancy query, %zu B of LDS each, G = %d, %u x %d workgroups\n", occ, lds2, Q.G, blocks, n_streams);
+                    fprintf(stderr, "pfb_h2 phases (memtime ticks/round, thread 0): land0 %.0f bar1 %.0f fused %.0f bar2 %.0f land %.0f pass2e %.0f bar3 %.0f odd %.0f bar4 %.0f pass2o %.0f\n",
+                            hd[0] / rt, hd[1] / rt, hd[2] / rt, hd[3] / rt, hd[4] / rt, hd[5] / rt, hd[6] / rt, hd[7] / rt, hd[8] / rt, hd[9] / rt);
+                }
+#endif
+                if (sync) HIP_TRY(hipStreamSynchronize(st));
+                return TDM_OK;
             }
         }
-        if (const char *e = std::getenv("TDM_PFB_G")) Q.G = std::max(1, std::atoi(e));   // experiments
+        Q.G = pick_rounds(1);
         const size_t lds = pfb_fft_lds<M1, M2, P, TB>(D) * sizeof(float2);
         if (lds <= 160 * 1024) {
             void (*kern)(const void *, cf32v *, int64_t, const PfbParams) = nullptr;

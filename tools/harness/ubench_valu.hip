@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
                 if (MODE == 24) asm volatile("v_lshl_or_b32 %0, %1, 8, %2" : "+v"(acc[i].x) : "v"(w[i].y), "v"(w[i].x));
                 if (MODE == 25) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(*(float __attribute__((ext_vector_type(4))) *)&acc[i & 2]) : "v"(*(float __attribute__((ext_vector_type(4))) *)&w[i & 6]));
                 if (MODE == 26) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(*(float __attribute__((ext_vector_type(4))) *)&acc[0]) : "v"(*(float __attribute__((ext_vector_type(4))) *)&w[i & 6]));
+                if (MODE == 27) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[i].x) : "v"(w[i].y), "v"(w[i].x));
+                if (MODE == 28) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[i].x) : "v"(w[i].y), "v"(w[i].x));
+                if (MODE == 29) asm volatile("v_cvt_f32_f16 %0, %1" : "+v"(acc[i].x) : "v"(w[i].y));
                 if (MODE == 14) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(*(float __attribute__((ext_vector_type(4))) *)&acc[i & 6]) : "v"(*(float __attribute__((ext_vector_type(4))) *)&w[i & 6]));
             }
         }
@@ -162,7 +165,11 @@ int main(int argc, char **argv)
         run_k("two waves/SIMD: vector wave only (4 v_max)", k_two<2>, 512, w, 16);
         run_k("two waves/SIMD: both", k_two<3>, 512, w, 16);
     }
-    if (argc > 1) return 0;
+    if (argc > 1 && argv[1][0] == 'm') return 0;
+    if (argc > 1 && argv[1][0] == 'x') {   // fp16-mix forms only
+        run<27>("v_fma_mix_f32 lo", 4); run<28>("v_fma_mix_f32 hi", 4); run<29>("v_cvt_f32_f16", 4); run<1>("v_fma_f32", 4); run<0>("v_pk_fma_f32", 4);
+        return 0;
+    }
     for (int w : {1, 4}) {
 #define R(M, N) if (w == 1) run<M>(N, 1); else run<M>(N, 4);
         R(0, "v_pk_fma_f32") R(1, "v_fma_f32") R(2, "v_fma_f64") R(3, "v_cndmask_b32") R(4, "v_mov_b32_dpp row_shr") R(5, "v_rcp_f32")
