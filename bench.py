@@ -542,7 +542,7 @@ def main():
             "output_check": output_check,
             "rccl_ranks": world if group is not None else 0,
             "plan_create_ms": plan_create_ms,
-            "settle_steps": settle_steps,   # untimed passes before the warm-up (clock ramp after idle; see DESIGN 6)
+            "settle_steps": settle_steps,   # untimed passes before the warm-up (clock ramp after idle; see DESIGN 5)
             "event_ms_per_step_rank0": ev_ms / args.steps,
             "ms_per_step_per_kernel_pass_rank0": dt_staged / args.steps * 1e3,   # same steps with events around every launch
             "stage_ms_per_launch": stage_ms,

@@ -112,7 +112,7 @@ def test_gpu_tetra_final_passes_edge_cases():
 
 
 def _end_of_chunk_contract(hard_dev, ns_dev, x, fs):
-    """The contract at a chunk's end (DESIGN section 8): the device forms the symbol instants in fp32 from fp32 timing
+    """The contract at a chunk's end (DESIGN section 7): the device forms the symbol instants in fp32 from fp32 timing
     estimates, the definition in fp64, so an instant within rounding of the bound t <= n - 3 may be kept by one and dropped
     by the other.  Allowed: a symbol COUNT that differs by at most one, and then only with the deciding instant at the
     bound; every decision both sides made must be equal.  Returns the count difference (device - definition)."""
