@@ -590,6 +590,12 @@ def main():
                 out["cpu_baseline_allcore"] = {"error": str(e)}
     bd.close()
     if rank == 0:
+        if (world == 1 and not args.no_extra and not strong and not args.shared and not args.pmc_child and args.fmt == "cu8"
+                and carriers >= 2 and carriers % 2 == 0):
+            try:
+                out["two_plans"] = leg_two_plans(iq, foffs, carriers, args.chunk, args.rate, args.steps, want)
+            except Exception as e:  # noqa: BLE001
+                out["two_plans"] = {"error": str(e)}
         if world == 1 and not args.no_extra and not strong and not args.shared:
             # the north-star stages beside the headline (own workloads, HIP-event timing; none of them is `value`)
             for key, leg, c in (("single_carrier", leg_single, 1), ("tetra", leg_tetra, 4096), ("pfb", leg_pfb, 12800),
@@ -603,10 +609,48 @@ def main():
     if group is not None:
         group.close()
     if rank == 0:
-        bad = [k for k in ("tetra", "pfb", "wideband") if isinstance(out.get(k), dict)
+        bad = [k for k in ("tetra", "pfb", "wideband", "two_plans") if isinstance(out.get(k), dict)
                and str(out[k].get("output_check", {}).get("status", "")).startswith("DIFFERS")]
         if bad:   # (the line is printed for the record; the run does not count as a success)
             raise SystemExit(f"bench: output check failed in leg(s) {bad}")
+
+
+def leg_two_plans(iq, foffs, carriers, chunk, rate, steps, want):
+    """The same batch as TWO plans of half the carriers each, every plan on its own stream (a caller-side choice: plans are
+    independent).  One plan's small launches and low-rate stage overlap the other plan's decimator across steps.  Side
+    figure, never `value`: the headline keeps the one-plan configuration, whose kernels are timed one by one."""
+    from tetraear_amd.batch import BatchDemodulator
+    per = carriers // 2
+    bds = []
+    for i in range(2):
+        bd = BatchDemodulator(rate, chunk, per, "cu8")
+        bd.alloc_device_io()
+        bd.upload(iq[2 * chunk * per * i: 2 * chunk * per * (i + 1)], freq_offsets=foffs[per * i: per * (i + 1)])
+        bds.append(bd)
+    for _ in range(SETTLE_STEPS):
+        for bd in bds:
+            bd.enqueue()
+    for bd in bds:
+        bd.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for bd in bds:
+            bd.enqueue()
+    for bd in bds:
+        bd.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    outs = [bd.download() for bd in bds]
+    for bd in bds:
+        bd.close()
+    hard = np.concatenate([o[0] for o in outs])
+    n_soft = np.concatenate([o[2] for o in outs])
+    bp = np.concatenate([o[3] for o in outs])
+    nsym = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
+    digest = output_digest(hard, n_soft, bp)
+    return {"workload": f"2 plans x {per} carriers, two streams, wall clock between device synchronisations", "ms_per_step": ms,
+            "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s",
+            "output_check": {"sha256": digest, "status": ("matches oracle-pinned digest" if digest == want else
+                                                           ("no pinned digest for this workload" if want is None else "DIFFERS from the oracle-pinned digest"))}}
 
 
 def leg_single(carriers, steps, warmup):
