@@ -225,8 +225,13 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // a loaded pair of consecutive samples (pair idx = staged samples 2 idx, 2 idx + 1) into the four planes
     auto put = [&](int idx, bool last_pair, float re0, float im0, float re1, float im1) __attribute__((always_inline)) {
         uint32_t w[4];
+#ifdef TDM_TETRA_NOSPLIT   // experiment: the input taken as if it arrived split already (results are wrong, timing only)
+        w[0] = __builtin_bit_cast(uint32_t, re0); w[1] = __builtin_bit_cast(uint32_t, im0);
+        w[2] = __builtin_bit_cast(uint32_t, re1); w[3] = __builtin_bit_cast(uint32_t, im1);
+#else
         split_bf16(re0, re1, w[0], w[1]);
         split_bf16(im0, im1, w[2], w[3]);
+#endif
         if (!last_pair || idx < NS / 2) {
 #pragma unroll
             for (int pl = 0; pl < 4; ++pl) xsb[pl * PLANE + idx] = w[pl];
