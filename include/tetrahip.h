@@ -55,12 +55,16 @@ typedef enum tdm_fmt {
 
 typedef enum tdm_mode {
     TDM_MODE_REFERENCE = 0, /* reproduces processor.py:221-273 (parity mode) */
-    TDM_MODE_TETRA = 1      /* RRC matched filter + feed-forward timing + Farrow + quadrant slicer on cf32
+    TDM_MODE_TETRA = 1,     /* RRC matched filter + feed-forward timing + Farrow + quadrant slicer on cf32
                                channelised baseband (no reference oracle; defined by oracle/tetra_np.py).
                                Arithmetic: fp32; the matched filter (16-bit coefficients) multiplies samples as sums
                                of two bf16 on the matrix cores with fp32 accumulation: soft symbols within 1e-5 of the
                                largest symbol of the fp64 definition (measured: median 3e-6, max 6e-6), independent of
                                the input's scale and of the alignment of its rows */
+    TDM_MODE_TETRA_GARDNER = 2 /* the same receiver with the timing recovery BASELINE.json's north_star names: Gardner
+                               timing-error detector -> proportional-integral loop -> period-controlled Farrow
+                               interpolation (oracle/tetra_np.py demod_gardner), one lane per carrier.  Same I/O as
+                               TDM_MODE_TETRA; slower by construction (a recurrence over a carrier's symbols) */
 } tdm_mode;
 
 typedef struct tdm_plan tdm_plan;

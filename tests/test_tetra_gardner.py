@@ -68,3 +68,68 @@ def test_feed_forward_matches_or_beats_gardner(snr_db):
     print(f"Es/N0 {snr_db} dB: (timing offset, CFO Hz, SER feed-forward, SER Gardner, RMS timing error ff, Gardner [symbols])")
     for r in rows:
         print("   %.2f %6.0f  %.5f %.5f  %.4f %.4f" % r)
+
+
+# ---- the device's Gardner receiver (TDM_MODE_TETRA_GARDNER) against the same definition ------------------------------
+def _gardner_case(n, fs, seed, toff, coff, snr_db, rate_ppm=0.0):
+    """a carrier whose symbol clock runs rate_ppm fast (the loop has to track a ramp, and the carriers of a wavefront drift
+    apart)"""
+    x, dib = synth.dqpsk_baseband(n, fs / (1.0 + rate_ppm * 1e-6), seed, timing_offset=toff)
+    rng = np.random.default_rng(seed + 100)
+    sps = fs / 18000.0
+    sigma2 = sps / 10 ** (snr_db / 10)
+    x = x + np.sqrt(sigma2 / 2) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return (x * np.exp(2j * np.pi * coff * np.arange(n) / fs)).astype(np.complex64), dib
+
+
+def _check_against_definition(x, fs, hard, soft, dib, skip=300):
+    ref_hard, _, info = tetra_np.demod_gardner(x.astype(np.complex128), fs)
+    # the loop runs in fp32 on the device (instants in fp64): symbol count within one of the definition's at the end of
+    # the chunk, decisions equal wherever the definition itself is not within rounding of a boundary
+    assert abs(len(soft) - len(info["t"])) <= 1, (len(soft), len(info["t"]))
+    m = min(len(hard), len(ref_hard))
+    assert m > 0.9 * len(x) / (fs / 18000.0) - 20
+    assert np.mean(hard[:m] != ref_hard[:m]) <= 1e-3, float(np.mean(hard[:m] != ref_hard[:m]))
+    best = min(int(np.sum(hard[skip:m - 8] != dib[lag + skip:lag + m - 8])) for lag in range(40) if len(dib) - lag >= m)
+    return best
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_receiver_matches_definition_and_transmitted():
+    """Gardner TED + PI loop + Farrow on the device, one lane per carrier: against oracle/tetra_np.demod_gardner (decisions)
+    and against the transmitted dibits (error-free after the loop's acquisition at 20 dB), at 3..8 samples per symbol,
+    with timing and carrier offsets and a symbol clock 200 ppm off"""
+    from tetraear_amd._lib import MODE_TETRA_GARDNER
+    from tetraear_amd.batch import BatchDemodulator
+    for fs, n, ppm in ((72000.0, 16384, 0.0), (72000.0, 32768, 200.0), (80000.0, 12000, -150.0), (54000.0, 6000, 0.0), (144000.0, 20000, 100.0)):
+        rows = 3
+        sig = [_gardner_case(n, fs, 40 + 7 * r, 0.13 * r - 0.2, (-120.0, 0.0, 90.0)[r], 20.0, ppm) for r in range(rows)]
+        bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+        hards, softs, timing, margin = bd.process(np.concatenate([s[0] for s in sig]))
+        bd.close()
+        for r in range(rows):
+            errs = _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1])
+            assert errs == 0, (fs, n, r, errs)
+            assert 0.0 < margin[r] < 0.8
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_receiver_many_carriers_share_a_wavefront():
+    """130 carriers (two full wavefronts of 64 and a partial one) with different symbol-clock offsets: the carriers of a
+    wavefront drift apart by several samples over the chunk while sharing one ring of matched-filter samples; every one
+    equals the definition"""
+    from tetraear_amd._lib import MODE_TETRA_GARDNER
+    from tetraear_amd.batch import BatchDemodulator
+    fs, n, rows = 72000.0, 24576, 130
+    sig = [_gardner_case(n, fs, 500 + r, ((r * 37) % 100) / 100.0 - 0.5, float((r * 53) % 240 - 120), 18.0, float((r % 9) - 4) * 100.0)
+           for r in range(rows)]
+    bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+    hards, softs, timing, margin = bd.process(np.concatenate([s[0] for s in sig]))
+    bd.close()
+    for r in range(0, rows, 3):
+        _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1])
+    # every carrier (also the ones not compared with the slow fp64 loop): error-free against what was sent, after acquisition
+    for r in range(rows):
+        m = len(hards[r])
+        dib = sig[r][1]
+        assert min(int(np.sum(hards[r][300:m - 8] != dib[lag + 300:lag + m - 8])) for lag in range(40) if len(dib) - lag >= m) == 0, r

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TETRAHIP_LIB", os.path.join(_HERE, "libtetrahip.so"))  # override: experiments only
 
 FMT_CU8, FMT_CS8, FMT_CF32, FMT_CF64 = 0, 1, 2, 3
-MODE_REFERENCE, MODE_TETRA = 0, 1
+MODE_REFERENCE, MODE_TETRA, MODE_TETRA_GARDNER = 0, 1, 2
 FMT_BYTES = {FMT_CU8: 2, FMT_CS8: 2, FMT_CF32: 8, FMT_CF64: 16}
 
 

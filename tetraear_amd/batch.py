@@ -62,7 +62,7 @@ class BatchDemodulator:
         self.n_carriers = int(n_carriers)
         self.n_samples = int(n_samples)
         self.mode = mode
-        self.soft_dtype = np.complex64 if mode == _lib.MODE_TETRA else np.complex128
+        self.soft_dtype = np.complex64 if mode in (_lib.MODE_TETRA, _lib.MODE_TETRA_GARDNER) else np.complex128
 
     def resize(self, n_samples):
         """Serve another chunk length with this plan (tdm_plan_resize): tables of a new length are built once (a fraction of

@@ -200,10 +200,10 @@ __global__ __launch_bounds__(256) void k_shift(const double *x, double *y, int64
 // ------------------------------------------------------------------------------------------
 // stage timing (HIP events around each launch, on the stream the kernels run on)
 // ------------------------------------------------------------------------------------------
-enum Stage { ST_DEC_BLOCK = 0, ST_DEC_CARRY, ST_DEC_FIXUP, ST_CONVERT, ST_LPF_BLOCK, ST_LPF_CARRY, ST_LPF_FIXUP, ST_FINISH, ST_TETRA, ST_COUNT };
+enum Stage { ST_DEC_BLOCK = 0, ST_DEC_CARRY, ST_DEC_FIXUP, ST_CONVERT, ST_LPF_BLOCK, ST_LPF_CARRY, ST_LPF_FIXUP, ST_FINISH, ST_TETRA, ST_TETRA_MF, ST_TETRA_LOOP, ST_TETRA_DECIDE, ST_COUNT };
 static const char *kStageNames[ST_COUNT] = {"dec_block", "dec_carry", "dec_fixup", "convert",
                                             "lpf_block", "lpf_carry", "lpf_fixup", "finish",
-                                            "tetra_fused"};
+                                            "tetra_fused", "tetra_mf", "tetra_gardner_loop", "tetra_decide"};
 
 struct StageTimer {
     bool on = false;
@@ -397,6 +397,8 @@ struct tdm_plan {
     // TETRA mode
     TetraParams tp{};
     uint32_t *d_tapops = nullptr;   // TetraParams::tap_ops
+    float2 *d_gy = nullptr;         // TDM_MODE_TETRA_GARDNER: matched-filter output
+    int64_t gy_pitch = 0;
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -603,7 +605,7 @@ static void plan_free(tdm_plan *p)
     p->variants.clear();
     for (auto &kv : p->d_shared)
         if (kv.second.second) (void)hipFree(kv.second.second);
-    void *ptrs[] = {p->d_work, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp, p->d_tapops};
+    void *ptrs[] = {p->d_work, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp, p->d_tapops, p->d_gy};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -640,7 +642,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     if (!(sample_rate > 0) || n_samples < 1 || n_samples > (int64_t(1) << 31) || n_carriers < 1 || n_carriers > 65535 ||
         in_fmt < 0 || in_fmt > 3)
         return fail(TDM_ERR_INVALID, "bad sample_rate / n_samples / n_carriers (1..65535) / in_fmt");
-    if (mode != TDM_MODE_REFERENCE && mode != TDM_MODE_TETRA) return fail(TDM_ERR_INVALID, "bad mode");
+    if (mode != TDM_MODE_REFERENCE && mode != TDM_MODE_TETRA && mode != TDM_MODE_TETRA_GARDNER) return fail(TDM_ERR_INVALID, "bad mode");
     int rc = use_device(device);
     if (rc) return rc;
     std::unique_ptr<tdm_plan, void (*)(tdm_plan *)> p(new tdm_plan, plan_free);
@@ -648,7 +650,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     p->rows = n_carriers;
     p->fmt = in_fmt;
     p->mode = mode;
-    if (mode == TDM_MODE_TETRA) {
+    if (mode == TDM_MODE_TETRA || mode == TDM_MODE_TETRA_GARDNER) {
         // channelised baseband in: sample_rate is the per-carrier rate, >= 2 samples per symbol
         if (in_fmt != TDM_CF32) return fail(TDM_ERR_UNSUPPORTED, "TETRA mode takes cf32 channelised baseband");
         const double sps = sample_rate / kSymbolRate;
@@ -705,6 +707,11 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             v->h.lpf = true;
             p->cur = v.get();
             p->variants[n_samples] = std::move(v);
+        }
+        if (mode == TDM_MODE_TETRA_GARDNER) {
+            // the matched-filter output goes through HBM in this mode: [rows][pitch] cf32, rows 16-byte aligned
+            p->gy_pitch = (n_samples + 1) & ~(int64_t)1;
+            HIP_TRY(hipMalloc((void **)&p->d_gy, (size_t)n_carriers * p->gy_pitch * sizeof(float2)));
         }
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&p->ev0));
@@ -798,12 +805,30 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     HipBackend be;
     be.stream = stream ? (hipStream_t)stream : plan->stream;
     be.timer = &plan->timer;
-    if (plan->mode == TDM_MODE_TETRA) {
+    if (plan->mode == TDM_MODE_TETRA || plan->mode == TDM_MODE_TETRA_GARDNER) {
         if (pre_shift_hz || freq_offset_hz)
             return fail(TDM_ERR_UNSUPPORTED, "TETRA mode: carrier offsets are estimated, not supplied");
         if (carrier_stride_samples < plan->tp.n)
             return fail(TDM_ERR_INVALID, "TETRA mode: carrier stride shorter than the chunk");
         const TetraParams &tp = plan->tp;
+        if (plan->mode == TDM_MODE_TETRA_GARDNER) {
+            // matched filter -> HBM -> Gardner loop, one lane per carrier -> decisions (tetra_gardner_kernels.hpp)
+            {
+                HipBackend::Scope s(be, ST_TETRA_MF);
+                if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))
+                    return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
+            }
+            {
+                HipBackend::Scope s(be, ST_TETRA_LOOP);
+                tetra_gardner_loop_launch(tp, plan->rows, plan->d_gy, plan->gy_pitch, (float2 *)soft, n_soft, best_phase, be.stream);
+            }
+            {
+                HipBackend::Scope s(be, ST_TETRA_DECIDE);
+                tetra_decide_launch(tp, plan->rows, (const float2 *)soft, n_soft, hard, min_margin, be.stream);
+            }
+            if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
+            return TDM_OK;
+        }
         {
             // one kernel: matched filter, timing, Farrow, carrier-offset estimate and decisions; one workgroup per carrier
             HipBackend::Scope s(be, ST_TETRA);
@@ -898,7 +923,7 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
                                 plan->d_bp, plan->d_margin, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(hard, plan->d_hard, (size_t)rows * h.max_soft, hipMemcpyDeviceToHost, st));
-    const size_t soft_elem = plan->mode == TDM_MODE_TETRA ? 2 * sizeof(float) : 2 * sizeof(double);
+    const size_t soft_elem = plan->mode != TDM_MODE_REFERENCE ? 2 * sizeof(float) : 2 * sizeof(double);
     HIP_TRY(hipMemcpyAsync(soft, plan->d_soft, (size_t)rows * h.max_soft * soft_elem, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(n_soft, plan->d_nsoft, rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (best_phase) HIP_TRY(hipMemcpyAsync(best_phase, plan->d_bp, rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -917,7 +942,7 @@ int tdm_process_pipelined(tdm_plan *plan, const void *iq, int64_t n_batches, con
     const RefPlanHost &h = plan->h();
     const int rows = plan->rows;
     const size_t in_bytes = (size_t)rows * h.n * fmt_bytes(plan->fmt);
-    const size_t soft_elem = plan->mode == TDM_MODE_TETRA ? 2 * sizeof(float) : 2 * sizeof(double);
+    const size_t soft_elem = plan->mode != TDM_MODE_REFERENCE ? 2 * sizeof(float) : 2 * sizeof(double);
     const size_t hard_bytes = (size_t)rows * h.max_soft, soft_bytes = (size_t)rows * h.max_soft * soft_elem;
     // pin the caller's buffers in place so the copies are truly asynchronous (best effort)
     const bool pin_in = hipHostRegister((void *)iq, in_bytes * n_batches, hipHostRegisterDefault) == hipSuccess;

@@ -2,6 +2,7 @@
 #include <cstdio>
 
 #include "tetra_kernels.hpp"
+#include "tetra_gardner_kernels.hpp"
 
 namespace tdm {
 
@@ -26,6 +27,42 @@ bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_s
 #undef TDM_RRC_CASE
     default: return false;
     }
+}
+
+bool tetra_mf_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *y, int64_t y_pitch, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((tp.n + kMfTile - 1) / kMfTile), (unsigned)rows);
+    switch (tp.ntaps) {
+#define TDM_MF_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_mf<NT>), grid, dim3(kMfThreads), 0, stream, x, in_stride, tp, y, y_pitch); return true;
+        TDM_MF_CASE(17) TDM_MF_CASE(25) TDM_MF_CASE(33) TDM_MF_CASE(35) TDM_MF_CASE(41) TDM_MF_CASE(49) TDM_MF_CASE(57) TDM_MF_CASE(65)
+#undef TDM_MF_CASE
+    default: return false;
+    }
+}
+
+void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y, int64_t y_pitch, float2 *soft, int32_t *n_soft,
+                               int32_t *timing_milli, hipStream_t stream)
+{
+    // loop filter gains of the definition (oracle/tetra_np.py demod_gardner: noise bandwidth 1 % of the symbol rate,
+    // damping 0.7071, detector gain 2.7 per symbol; Rice, Digital Communications, eq. C.61)
+    const double bn_t = 0.01, zeta = 0.7071, kp = 2.7;
+    const double th = bn_t / (zeta + 0.25 / zeta);
+    const double den = 1.0 + 2.0 * zeta * th + th * th;
+    GardnerConsts G{(float)(4.0 * zeta * th / den / kp), (float)(4.0 * th * th / den / kp)};
+    const size_t lds = (size_t)64 * kGPitch * sizeof(float2);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)k_tetra_gardner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_tetra_gardner, dim3((unsigned)((rows + 63) / 64)), dim3(64), lds, stream, y, y_pitch, tp, G, rows, soft, n_soft,
+                       timing_milli);
+}
+
+void tetra_decide_launch(const TetraParams &tp, int rows, const float2 *soft, const int32_t *n_soft, uint8_t *hard, double *min_margin,
+                         hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_tetra_decide, dim3((unsigned)rows), dim3(256), 0, stream, soft, (int)tp.max_soft, n_soft, hard, min_margin);
 }
 
 }  // namespace tdm

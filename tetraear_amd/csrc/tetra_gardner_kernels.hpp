@@ -1,0 +1,255 @@
+// TETRA mode, Gardner variant (TDM_MODE_TETRA_GARDNER): the textbook receiver BASELINE.json's north_star names --
+// RRC matched filter -> Gardner timing-error detector -> proportional-integral loop filter -> period-controlled cubic
+// Farrow interpolator -> differential quadrant decisions -- on the device, defined by oracle/tetra_np.py demod_gardner.
+//
+// The loop is a nonlinear recurrence over a carrier's symbols (every symbol instant depends on the errors of all symbols
+// before it), so it cannot be tiled over time like the feed-forward receiver of tetra_kernels.hpp: the parallel axis is
+// the CARRIER.  Three kernels:
+//   k_tetra_mf       matched filter, LDS-tiled sliding window, fp32, output to HBM (one workgroup per 2048 outputs)
+//   k_tetra_gardner  ONE LANE PER CARRIER walks its carrier's symbols; a wavefront's 64 carriers share an LDS ring of
+//                    matched-filter samples (three 64-sample chunks per carrier, refilled cooperatively with coalesced
+//                    loads one chunk ahead), so that the loop's dependent chain sees LDS latency, not HBM latency
+//   k_tetra_decide   differential products, 4th-power carrier-offset estimate, quadrant decisions, margin (one workgroup
+//                    per carrier)
+// It is the slower receiver by construction (8192 dependent loop turns per 32 768-sample chunk) and exists because the
+// north-star names it: tests compare it with the fp64 definition, bench.py times it beside the feed-forward receiver.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tetra_params.hpp"
+
+namespace tdm {
+
+constexpr int kMfThreads = 256, kMfPer = 8, kMfTile = kMfThreads * kMfPer;
+
+// y[n] = sum_t h[t] x[n + t - (NT-1)/2], zero outside the chunk (oracle/tetra_np.py matched_filter); y rows have pitch y_pitch
+template <int NT>
+__global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restrict__ x, int64_t in_stride, const TetraParams P,
+                                                         float2 *__restrict__ y, int64_t y_pitch)
+{
+    constexpr int H = (NT - 1) / 2, W = kMfTile + NT - 1;
+    __shared__ float2 xs[W + 1];
+    const int row = blockIdx.y, tid = threadIdx.x, n = P.n;
+    const int base = blockIdx.x * kMfTile;
+    const float2 *xr = x + (int64_t)row * in_stride;
+    for (int i = tid; i < W; i += kMfThreads) {
+        const int g = base - H + i;
+        xs[i] = (g >= 0 && g < n) ? xr[g] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    // thread t: outputs t + 256 j -- consecutive lanes read consecutive LDS slots for every tap
+    float ar[kMfPer], ai[kMfPer];
+#pragma unroll
+    for (int j = 0; j < kMfPer; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
+#pragma unroll 3   // (a few taps' loads in flight: fully unrolled, the 8 x NT LDS reads are all hoisted and spill)
+    for (int t = 0; t < NT; ++t) {
+        const float h = P.taps[t];
+#pragma unroll
+        for (int j = 0; j < kMfPer; ++j) {
+            const float2 v = xs[tid + kMfThreads * j + t];
+            ar[j] = fmaf(h, v.x, ar[j]);
+            ai[j] = fmaf(h, v.y, ai[j]);
+        }
+    }
+    float2 *yr = y + (int64_t)row * y_pitch;
+#pragma unroll
+    for (int j = 0; j < kMfPer; ++j) {
+        const int g = base + tid + kMfThreads * j;
+        if (g < n) yr[g] = make_float2(ar[j], ai[j]);
+    }
+}
+
+// ---- the loop ---------------------------------------------------------------------------------------------------------
+constexpr int kGChunk = 64, kGRing = 3 * kGChunk, kGPitch = kGRing + 1;   // LDS slots per carrier (+1: rows on different banks)
+
+struct GardnerConsts {
+    float k1, k2;      // loop filter gains (oracle/tetra_np.py demod_gardner: Rice eq. C.61, detector gain 2.7, bn_t 0.01, zeta 0.7071)
+};
+
+// cubic Lagrange interpolation (the definition's _farrow1: samples at -1, 0, 1, 2 around the whole part of t).  Sample g of
+// a carrier lives in slot g mod 192 of its ring row (a chunk is 64 slots, three chunks are resident), so any index --
+// also that of a carrier whose loop has run away -- stays inside the row.
+__device__ __forceinline__ float2 gardner_farrow(const float2 *ring_row, double t)
+{
+    const double fl = floor(t);
+    const int m = (int)fl;
+    const float mu = (float)(t - fl);
+    auto at = [&](int g) { return ring_row[(unsigned)g % (unsigned)kGRing]; };
+    const float2 ym1 = at(m - 1), y0 = at(m), y1 = at(m + 1), y2 = at(m + 2);
+    const float c1x = y1.x - ym1.x * (1.f / 3.f) - y0.x * 0.5f - y2.x * (1.f / 6.f), c1y = y1.y - ym1.y * (1.f / 3.f) - y0.y * 0.5f - y2.y * (1.f / 6.f);
+    const float c2x = (ym1.x + y1.x) * 0.5f - y0.x, c2y = (ym1.y + y1.y) * 0.5f - y0.y;
+    const float c3x = (y2.x - ym1.x) * (1.f / 6.f) + (y0.x - y1.x) * 0.5f, c3y = (y2.y - ym1.y) * (1.f / 6.f) + (y0.y - y1.y) * 0.5f;
+    return make_float2(((c3x * mu + c2x) * mu + c1x) * mu + y0.x, ((c3y * mu + c2y) * mu + c1y) * mu + y0.y);
+}
+
+__global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__ y, int64_t y_pitch, const TetraParams P,
+                                                      const GardnerConsts G, int rows, float2 *__restrict__ soft,
+                                                      int32_t *__restrict__ n_soft, int32_t *__restrict__ timing_milli)
+{
+    extern __shared__ float2 ring[];               // [64 carriers][kGPitch]
+    const int lane = threadIdx.x;
+    const int row = min((int)blockIdx.x * 64 + lane, rows - 1);
+    const bool mine = (int)blockIdx.x * 64 + lane < rows;
+    const int n = P.n;
+    const double sps = P.sps;
+    const int back = (int)sps + 4;                 // samples behind floor(t) a strobe may need (mid-symbol strobe + interpolator)
+    float2 *my = ring + lane * kGPitch;
+    float2 *sr = soft + (int64_t)row * P.max_soft;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (a clamped pair at the end of an odd-length row starts on an odd sample)
+    // ---- cooperative chunk moves: chunk c = samples [64 c, 64 c + 64) of every carrier of the wavefront.  One 16-byte load
+    // fetches two samples; lanes 0..31 serve carrier 2 q, lanes 32..63 carrier 2 q + 1 (rows are 16-byte aligned: even pitch)
+    f32x4 pf[32];
+    const int half = lane >> 5, l32 = lane & 31;
+    auto request = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int r = min((int)blockIdx.x * 64 + 2 * q + half, rows - 1);
+            const int g = kGChunk * c + 2 * l32;
+            const int gg = min(g, max(n - 2, 0));                      // (clamped address; masked when it lands)
+            pf[q] = *(const f32x4_a8 *)(y + (int64_t)r * y_pitch + gg);
+        }
+    };
+    auto land = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int g = kGChunk * c + 2 * l32;
+            float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
+            if (g >= n) a = make_float2(0.f, 0.f);
+            if (g + 1 >= n) b = make_float2(0.f, 0.f);
+            if (g == n - 1 && n >= 2) a = make_float2(pf[q].z, pf[q].w);   // (the clamped pair ends at n - 1: its second half is sample n - 1)
+            float2 *dst = ring + (2 * q + half) * kGPitch + (unsigned)g % (unsigned)kGRing;
+            dst[0] = a;
+            dst[1] = b;
+        }
+    };
+    request(0); land(0);
+    request(1); land(1);
+    request(2); land(2);
+    int c0 = 0;                                     // oldest resident chunk: chunks c0, c0 + 1, c0 + 2 are in the ring
+    request(3);                                     // in flight while the first symbols are formed
+    __syncthreads();
+    // ---- per-carrier loop state (oracle/tetra_np.py demod_gardner)
+    double t = 1.0 + sps;
+    float integ = 0.f, pw = 1.f;
+    float2 prev = make_float2(0.f, 0.f);
+    bool have_prev = false;
+    int k = 0;
+    double t_mid_sym = 0.0;
+    const double t_end = (double)n - 3.0;
+    const int k_mid = (int)(0.5 * (double)n / sps);
+    bool active = mine && t <= t_end;
+    const int max_turns = 4 * P.max_soft + 64;      // (bounded whatever the input: every turn advances the slowest active carrier)
+    for (int turn = 0; turn < max_turns; ++turn) {
+        if (!__any(active)) break;
+        // a carrier takes its strobes when the samples both of them can touch lie in the resident chunks; one that has run
+        // ahead of the wavefront's slowest carrier by more than two chunks waits for the ring to move on
+        const int mlo = max((int)t - back, 0), mhi = (int)t + 2;
+        const bool ok = active && mlo >= kGChunk * c0 && mhi < kGChunk * (c0 + 3);
+        if (ok) {
+            const float2 sk = gardner_farrow(my, t);
+            float v = 0.f;
+            if (have_prev) {
+                const float2 mid = gardner_farrow(my, t - 0.5 * sps * (1.0 - (double)integ));
+                pw = 0.99f * pw + 0.01f * (sk.x * sk.x + sk.y * sk.y);
+                const float dx = sk.x - prev.x, dy = sk.y - prev.y;
+                const float e = (dx * mid.x + dy * mid.y) / fmaxf(pw, 1e-12f);
+                integ += G.k2 * e;
+                v = G.k1 * e + integ;
+            }
+            sr[k] = sk;
+            if (k == k_mid) t_mid_sym = t;
+            prev = sk;
+            have_prev = true;
+            ++k;
+            t += sps * (1.0 - (double)v);          // (a late strobe makes e positive: shorten the period)
+            active = t <= t_end && k < P.max_soft;
+        }
+        // the ring moves on when no active carrier needs its oldest chunk any more (a wavefront-uniform decision)
+        int lo = active ? ((int)t - back) : 0x7fffffff;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) lo = min(lo, __shfl_xor(lo, d, 64));
+        if (lo != 0x7fffffff && lo >= kGChunk * (c0 + 1)) {
+            __syncthreads();                         // (one wavefront: orders the ring reads above against the writes below)
+            land(c0 + 3);                            // into the slots chunk c0 held
+            ++c0;
+            request(c0 + 3);
+            __syncthreads();
+        }
+    }
+    if (mine) {
+        n_soft[row] = k;
+        if (timing_milli) {
+            const double u = t_mid_sym / sps;
+            timing_milli[row] = (int32_t)rint((u - rint(u)) * 1000.0);
+        }
+    }
+}
+
+// ---- decisions (the same detection as demod(): d_k = s_k conj(s_{k-1}), delta = arg(-sum d^4) / 4, quadrant of d e^{-i delta})
+__global__ __launch_bounds__(256) void k_tetra_decide(const float2 *__restrict__ soft, int max_soft, const int32_t *__restrict__ n_soft,
+                                                      uint8_t *__restrict__ hard, double *__restrict__ min_margin)
+{
+    __shared__ float sm[3][4];
+    __shared__ float delta_s;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float2 *sr = soft + (int64_t)row * max_soft;
+    uint8_t *hr = hard + (int64_t)row * max_soft;
+    const int ns = n_soft[row];
+    // scale: a power of two that brings the carrier's middle symbol to [0.5, 1) (exact; see tetra_kernels.hpp)
+    float sc = 1.f;
+    if (ns > 0) {
+        const float2 smid = sr[ns >> 1];
+        const float a = fmaxf(fabsf(smid.x), fabsf(smid.y));
+        int ex = 0;
+        if (a > 0.f && a < 3.0e38f) (void)frexpf(a, &ex);
+        sc = ldexpf(1.f, -ex);
+    }
+    auto product = [&](int i) {
+        const float2 p = sr[i - 1], c = sr[i];
+        const float px = p.x * sc, py = p.y * sc, cx = c.x * sc, cy = c.y * sc;
+        return make_float2(cx * px + cy * py, cy * px - cx * py);
+    };
+    float a_pp = 0.f, a_qq = 0.f, a_pq = 0.f;
+    for (int i = 1 + tid; i < ns; i += 256) {
+        const float2 d = product(i);
+        const float p4 = fmaf(d.x, d.x, -(d.y * d.y)), q4 = d.x * d.y;
+        a_pp = fmaf(p4, p4, a_pp);
+        a_qq = fmaf(q4, q4, a_qq);
+        a_pq = fmaf(p4, q4, a_pq);
+    }
+    float r = fmaf(-4.f, a_qq, a_pp), q = 4.f * a_pq;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { r += __shfl_xor(r, d, 64); q += __shfl_xor(q, d, 64); }
+    if (lane == 0) { sm[0][wv] = r; sm[1][wv] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        float rr = 0.f, qq = 0.f;
+        for (int w = 0; w < 4; ++w) { rr += sm[0][w]; qq += sm[1][w]; }
+        delta_s = (rr == 0.f && qq == 0.f) ? 0.f : atan2f(-qq, -rr) * 0.25f;
+    }
+    __syncthreads();
+    float rs, rc;
+    __sincosf(-delta_s, &rs, &rc);
+    float mlo = 3.0e38f, mhi = 1.f, hmin = 3.0e38f;
+    for (int i = 1 + tid; i < ns; i += 256) {
+        const float2 d = product(i);
+        const float ddx = d.x * rc - d.y * rs, ddy = d.x * rs + d.y * rc;
+        hr[i - 1] = (uint8_t)(((ddy < 0.f) ? 2u : 0u) | ((ddx < 0.f) ? 1u : 0u));
+        const float lo = fminf(fabsf(ddx), fabsf(ddy)), hi = fmaxf(fabsf(ddx), fabsf(ddy));
+        hmin = fminf(hmin, hi);
+        const bool take = lo * mhi < mlo * hi;
+        mlo = take ? lo : mlo;
+        mhi = take ? hi : mhi;
+    }
+    const float mratio = hmin == 0.f ? 0.f : mlo / mhi;
+    float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) margin = fminf(margin, __shfl_xor(margin, d, 64));
+    if (lane == 0) sm[2][wv] = margin;
+    __syncthreads();
+    if (tid == 0 && min_margin) min_margin[row] = (double)fminf(fminf(sm[2][0], sm[2][1]), fminf(sm[2][2], sm[2][3]));
+}
+
+}  // namespace tdm

@@ -55,4 +55,12 @@ void tetra_timing_dump();
 bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, uint8_t *hard,
                   int32_t *n_soft, int32_t *timing_milli, double *min_margin, hipStream_t stream);
 
+// TDM_MODE_TETRA_GARDNER (tetra_gardner_kernels.hpp): the three launches, each on its own so that the caller can time them.
+// y: [rows][y_pitch] cf32 matched-filter output (y_pitch even, >= tp.n); false when no kernel is instantiated for tp.ntaps
+bool tetra_mf_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *y, int64_t y_pitch, hipStream_t stream);
+void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y, int64_t y_pitch, float2 *soft, int32_t *n_soft,
+                               int32_t *timing_milli, hipStream_t stream);
+void tetra_decide_launch(const TetraParams &tp, int rows, const float2 *soft, const int32_t *n_soft, uint8_t *hard, double *min_margin,
+                         hipStream_t stream);
+
 }  // namespace tdm
