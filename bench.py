@@ -792,8 +792,9 @@ def _print_leg(out):
     leg's output differs from the pinned definition (a number from wrong output must not look like a result)"""
     print(json.dumps(out), flush=True)
     status = str(out.get("output_check", {}).get("status", ""))
-    if status.startswith("DIFFERS"):
-        raise SystemExit(f"bench: output check failed: {status}")
+    side = str(((out.get("gardner_mode") or {}).get("output_check") or {}).get("status", ""))
+    if status.startswith("DIFFERS") or side.startswith("DIFFERS"):
+        raise SystemExit(f"bench: output check failed: {status} {side}")
 
 
 def main_pfb(args):
@@ -869,6 +870,48 @@ def main_tetra(args):
     _print_leg(leg_tetra(args.carriers, args.steps, args.warmup))
 
 
+def leg_gardner(rows, base, chk, steps):
+    """The same carriers through TDM_MODE_TETRA_GARDNER -- the timing recovery `north_star` names (Gardner TED + PI loop +
+    period-controlled Farrow), a recurrence over a carrier's symbols run with one lane per carrier -- timed beside the
+    feed-forward receiver that is the leg's headline.  Output check: every prototype row against the decisions of the fp64
+    definition's loop (oracle/tetra_np.demod_gardner via the fixture): the device's loop runs in fp32, so the count may
+    differ by one symbol at the chunk's end and at most 1e-3 of the decisions (symbols the definition itself puts within
+    rounding of a boundary)."""
+    from tetraear_amd._lib import MODE_TETRA_GARDNER
+    from tetraear_amd.batch import BatchDemodulator
+    bd = BatchDemodulator(TETRA_FS, TETRA_N, rows, "cf32", mode=MODE_TETRA_GARDNER)
+    bd.alloc_device_io()
+    bd.upload(np.concatenate([base[i % TETRA_DISTINCT] for i in range(rows)]))
+    for _ in range(3):
+        bd.enqueue()
+    bd.sync()
+    bd.time_begin()
+    for _ in range(steps):
+        bd.enqueue()
+    ms = bd.time_end() / steps
+    st = bd.stage_times()
+    hard, soft, n_soft, tm, mm = bd.download()
+    bd.close()
+    nsym = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
+    check = {"status": "no pinned decisions for this workload"}
+    if chk is not None and "gardner_hard" in chk.files and rows >= TETRA_DISTINCT:
+        ref_n, ref_h = chk["gardner_n_sym"], chk["gardner_hard"]
+        worst, ok = 0.0, True
+        for r in range(TETRA_DISTINCT):
+            ns = int(n_soft[r])
+            m = min(ns, int(ref_n[r])) - 1
+            frac = float(np.mean(hard[r, :m] != ref_h[r, :m]))
+            worst = max(worst, frac)
+            ok = ok and abs(ns - int(ref_n[r])) <= 1 and frac <= 1e-3
+        same = all(rows_digest(hard, n_soft, [r]) == rows_digest(hard, n_soft, [r % TETRA_DISTINCT]) for r in range(TETRA_DISTINCT, rows))
+        check = {"against": "oracle/tetra_np.py demod_gardner (fp64 loop), pinned by tests/golden/make_bench_checks.py",
+                 "worst_fraction_of_differing_decisions": worst, "rows_equal_their_prototype": bool(same),
+                 "status": "decisions match the definition's loop (<= 1e-3 differing, count within one)" if (ok and same) else "DIFFERS from the definition"}
+    return {"what": "TDM_MODE_TETRA_GARDNER: matched filter -> HBM -> Gardner TED + PI loop + Farrow, one lane per carrier -> decisions (3 launches)",
+            "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s", "steps": steps, "stage_ms_per_launch": st,
+            "output_check": check}
+
+
 def leg_tetra(carriers, steps, warmup):
     """TETRA-mode leg (no reference oracle; SURVEY 8(d) 'tetra mode'): `carriers` channelised carriers,
     cf32 at 72 kS/s (4 samples/symbol), chunks of 32768 samples.  ONE kernel (matched filter -> timing ->
@@ -914,6 +957,12 @@ def leg_tetra(carriers, steps, warmup):
                  "hard_sha256_row0": d8[0], "rows_equal_their_prototype": bool(same), "soft_probes": int(idx.size),
                  "soft_max_err_rel": err, "soft_tolerance": 1e-5,
                  "status": "hard decisions match the definition-pinned digests, soft within 1e-5" if ok else "DIFFERS from the definition"}
+    gardner = None
+    if not PMC_CHILD:
+        try:
+            gardner = leg_gardner(rows, base, chk, max(5, steps // 5))
+        except Exception as e:  # noqa: BLE001 -- a side leg never breaks the line
+            gardner = {"error": str(e)}
     out = {"metric": "Msymbols/s demodulated (TETRA mode: RRC + feed-forward timing + Farrow + quadrant slicer)",
            "value": nsym * steps / dt / 1e6, "unit": "Msym/s", "n_gpus": 1, "steps": steps,
            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -922,6 +971,7 @@ def leg_tetra(carriers, steps, warmup):
            "realtime_carriers": nsym * steps / dt / 18000.0, "event_ms_per_step": ev_ms / steps,
            "stage_ms_per_launch": st,
            "output_check": check,
+           "gardner_mode": gardner,
            "roofline": hbm_roofline("k_tetra_fused<33> (RRC matched filter on the matrix cores (split-bf16 products, fp32 accumulate) -> timing -> Farrow -> slicer, one pass over the input)",
                                     bytes_alg, rrc_ms, read_bytes=rows * n * 8, traffic=traffic, traffic_src=traffic_src,
                                     traffic_detail=traffic_detail, bytes_per_symbol=bytes_alg / max(nsym, 1))}

@@ -48,6 +48,18 @@ def main():
         idxs.append(idx)
         refs.append(info_e["sym"][idx])
         print(f"tetra row {r}: {info['n_sym']} symbols, sha256 {digests[-1][:16]}")
+    # ---- the same carriers through the Gardner receiver of the definition (TDM_MODE_TETRA_GARDNER's side leg): its decisions,
+    # as arrays -- the device runs the loop in fp32, so the leg compares decision by decision (<= 1e-3 may differ, the
+    # symbol count by one at the chunk's end) instead of by digest
+    g_n, g_hard = [], []
+    for r, x in enumerate(bench.tetra_rows()):
+        hard, _, info = tetra_np.demod_gardner(x.astype(np.complex128), bench.TETRA_FS)
+        g_n.append(len(info["t"]))
+        g_hard.append(hard)
+        print(f"tetra row {r} (Gardner): {len(info['t'])} symbols")
+    width = max(len(h) for h in g_hard)
+    out["gardner_n_sym"] = np.array(g_n, dtype=np.int32)
+    out["gardner_hard"] = np.stack([np.pad(h, (0, width - len(h))) for h in g_hard]).astype(np.uint8)
     out["tetra_digests"] = np.array(digests)
     out["tetra_soft_idx"] = np.stack(idxs)
     out["tetra_soft_ref"] = np.stack(refs)

@@ -7,12 +7,16 @@
 // the CARRIER.  Three kernels:
 //   k_tetra_mf       matched filter, LDS-tiled sliding window, fp32, output to HBM (one workgroup per 2048 outputs)
 //   k_tetra_gardner  ONE LANE PER CARRIER walks its carrier's symbols; a wavefront's 64 carriers share an LDS ring of
-//                    matched-filter samples (three 64-sample chunks per carrier, refilled cooperatively with coalesced
+//                    matched-filter samples (four 64-sample chunks per carrier, refilled cooperatively with coalesced
 //                    loads one chunk ahead), so that the loop's dependent chain sees LDS latency, not HBM latency
 //   k_tetra_decide   differential products, 4th-power carrier-offset estimate, quadrant decisions, margin (one workgroup
 //                    per carrier)
-// It is the slower receiver by construction (8192 dependent loop turns per 32 768-sample chunk) and exists because the
-// north-star names it: tests compare it with the fp64 definition, bench.py times it beside the feed-forward receiver.
+// It is the slower receiver by construction and exists because the north-star names it: tests compare it with the fp64
+// definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768): matched filter 0.60 ms
+// (3.6 TB/s), loop 3.66 ms, decisions 0.10 ms.  The loop's time does not depend on the number of carriers up to 16 384 (64
+// per wavefront, one wavefront per SIMD): it is 8190 turns x ~1070 cycles, and a turn is its ~150 vector instructions at one
+// issue per four cycles plus two LDS round trips -- without the mid-symbol strobe 3.03 ms, without the per-symbol store
+// 3.72 ms, with the instant in fp64 instead of (int, fp32) 3.66 ms: no single piece dominates.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,12 +34,26 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
 {
     constexpr int H = (NT - 1) / 2, W = kMfTile + NT - 1;
     __shared__ float2 xs[W + 1];
+    __shared__ float hs[NT];
     const int row = blockIdx.y, tid = threadIdx.x, n = P.n;
+    if (tid < NT) hs[tid] = P.taps[tid];
     const int base = blockIdx.x * kMfTile;
     const float2 *xr = x + (int64_t)row * in_stride;
-    for (int i = tid; i < W; i += kMfThreads) {
-        const int g = base - H + i;
-        xs[i] = (g >= 0 && g < n) ? xr[g] : make_float2(0.f, 0.f);
+    {
+        // the window's loads all in flight at once (unconditional, clamped addresses; masked as they land): under a branch
+        // every load would be waited for on its own -- nine serial HBM round trips per workgroup
+        constexpr int NLD = (W + kMfThreads - 1) / kMfThreads;
+        float2 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int g = base - H + tid + k * kMfThreads;
+            v[k] = xr[min(max(g, 0), n - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * kMfThreads, g = base - H + i;
+            if (i < W) xs[i] = (g >= 0 && g < n) ? v[k] : make_float2(0.f, 0.f);
+        }
     }
     __syncthreads();
     // thread t: outputs t + 256 j -- consecutive lanes read consecutive LDS slots for every tap
@@ -44,7 +62,7 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
     for (int j = 0; j < kMfPer; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
 #pragma unroll 3   // (a few taps' loads in flight: fully unrolled, the 8 x NT LDS reads are all hoisted and spill)
     for (int t = 0; t < NT; ++t) {
-        const float h = P.taps[t];
+        const float h = hs[t];                      // (one broadcast LDS read per tap; a scalar load per turn would be waited for)
 #pragma unroll
         for (int j = 0; j < kMfPer; ++j) {
             const float2 v = xs[tid + kMfThreads * j + t];
@@ -61,22 +79,29 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
 }
 
 // ---- the loop ---------------------------------------------------------------------------------------------------------
-constexpr int kGChunk = 64, kGRing = 3 * kGChunk, kGPitch = kGRing + 1;   // LDS slots per carrier (+1: rows on different banks)
+constexpr int kGChunk = 64, kGChunks = 4, kGRing = kGChunks * kGChunk, kGPitch = kGRing + 1;   // LDS slots per carrier (+1: rows on different banks)
+static_assert((kGRing & (kGRing - 1)) == 0, "ring index by mask");
 
 struct GardnerConsts {
     float k1, k2;      // loop filter gains (oracle/tetra_np.py demod_gardner: Rice eq. C.61, detector gain 2.7, bn_t 0.01, zeta 0.7071)
 };
 
-// cubic Lagrange interpolation (the definition's _farrow1: samples at -1, 0, 1, 2 around the whole part of t).  Sample g of
-// a carrier lives in slot g mod 192 of its ring row (a chunk is 64 slots, three chunks are resident), so any index --
+// cubic Lagrange interpolation (the definition's _farrow1: samples at -1, 0, 1, 2 around the whole part m of t).  Sample g of
+// a carrier lives in slot g mod 256 of its ring row (a chunk is 64 slots, four chunks are resident), so any index --
 // also that of a carrier whose loop has run away -- stays inside the row.
-__device__ __forceinline__ float2 gardner_farrow(const float2 *ring_row, double t)
+struct GardnerTaps { float2 ym1, y0, y1, y2; };
+__device__ __forceinline__ GardnerTaps gardner_taps(const float2 *ring_row, int m)
 {
-    const double fl = floor(t);
-    const int m = (int)fl;
-    const float mu = (float)(t - fl);
-    auto at = [&](int g) { return ring_row[(unsigned)g % (unsigned)kGRing]; };
-    const float2 ym1 = at(m - 1), y0 = at(m), y1 = at(m + 1), y2 = at(m + 2);
+    GardnerTaps g;
+    g.ym1 = ring_row[(m - 1) & (kGRing - 1)];
+    g.y0 = ring_row[m & (kGRing - 1)];
+    g.y1 = ring_row[(m + 1) & (kGRing - 1)];
+    g.y2 = ring_row[(m + 2) & (kGRing - 1)];
+    return g;
+}
+__device__ __forceinline__ float2 gardner_eval(const GardnerTaps &g, float mu)
+{
+    const float2 ym1 = g.ym1, y0 = g.y0, y1 = g.y1, y2 = g.y2;
     const float c1x = y1.x - ym1.x * (1.f / 3.f) - y0.x * 0.5f - y2.x * (1.f / 6.f), c1y = y1.y - ym1.y * (1.f / 3.f) - y0.y * 0.5f - y2.y * (1.f / 6.f);
     const float c2x = (ym1.x + y1.x) * 0.5f - y0.x, c2y = (ym1.y + y1.y) * 0.5f - y0.y;
     const float c3x = (y2.x - ym1.x) * (1.f / 6.f) + (y0.x - y1.x) * 0.5f, c3y = (y2.y - ym1.y) * (1.f / 6.f) + (y0.y - y1.y) * 0.5f;
@@ -119,62 +144,78 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
             if (g >= n) a = make_float2(0.f, 0.f);
             if (g + 1 >= n) b = make_float2(0.f, 0.f);
             if (g == n - 1 && n >= 2) a = make_float2(pf[q].z, pf[q].w);   // (the clamped pair ends at n - 1: its second half is sample n - 1)
-            float2 *dst = ring + (2 * q + half) * kGPitch + (unsigned)g % (unsigned)kGRing;
+            float2 *dst = ring + (2 * q + half) * kGPitch + (g & (kGRing - 1));
             dst[0] = a;
             dst[1] = b;
         }
     };
-    request(0); land(0);
-    request(1); land(1);
-    request(2); land(2);
-    int c0 = 0;                                     // oldest resident chunk: chunks c0, c0 + 1, c0 + 2 are in the ring
-    request(3);                                     // in flight while the first symbols are formed
+#pragma unroll 1
+    for (int c = 0; c < kGChunks; ++c) { request(c); land(c); }
+    int c0 = 0;                                     // oldest resident chunk: chunks c0 .. c0 + kGChunks - 1 are in the ring
+    request(kGChunks);                              // in flight while the first symbols are formed
     __syncthreads();
     // ---- per-carrier loop state (oracle/tetra_np.py demod_gardner)
-    double t = 1.0 + sps;
+    // the symbol instant t = m + mu, whole samples and a fraction in [0, 1): integer and fp32 arithmetic only in the loop's
+    // dependent chain (an fp32 t would be good to 4e-3 samples at the end of a 32 768-sample chunk, an fp64 t puts a dozen
+    // long-latency instructions into every turn)
+    const float sps_f = (float)sps;
+    int m = 1 + (int)floor(sps);
+    float mu = (float)(sps - floor(sps));
     float integ = 0.f, pw = 1.f;
     float2 prev = make_float2(0.f, 0.f);
     bool have_prev = false;
     int k = 0;
     double t_mid_sym = 0.0;
-    const double t_end = (double)n - 3.0;
+    const int m_end = n - 3;                        // t <= n - 3  <=>  m < n - 3 or (m == n - 3 and mu == 0)
     const int k_mid = (int)(0.5 * (double)n / sps);
-    bool active = mine && t <= t_end;
+    auto in_chunk = [&](int mm, float uu) { return mm < m_end || (mm == m_end && uu == 0.f); };
+    bool active = mine && in_chunk(m, mu);
     const int max_turns = 4 * P.max_soft + 64;      // (bounded whatever the input: every turn advances the slowest active carrier)
     for (int turn = 0; turn < max_turns; ++turn) {
         if (!__any(active)) break;
         // a carrier takes its strobes when the samples both of them can touch lie in the resident chunks; one that has run
-        // ahead of the wavefront's slowest carrier by more than two chunks waits for the ring to move on
-        const int mlo = max((int)t - back, 0), mhi = (int)t + 2;
-        const bool ok = active && mlo >= kGChunk * c0 && mhi < kGChunk * (c0 + 3);
+        // ahead of the wavefront's slowest carrier by more than three chunks waits for the ring to move on
+        const int mlo = max(m - back, 0), mhi = m + 2;
+        const bool ok = active && mlo >= kGChunk * c0 && mhi < kGChunk * (c0 + kGChunks);
         if (ok) {
-            const float2 sk = gardner_farrow(my, t);
+            // both strobes in one basic block (the mid-symbol one is formed for the first symbol too and not used): two
+            // independent chains of LDS reads and multiply-adds that the scheduler interleaves -- with one wavefront per
+            // SIMD every dependent instruction's latency is exposed, and the turn's length is its longest chain
+            // mid-symbol strobe at t - 0.5 sps (1 - integ), not before sample 1.  All eight ring reads are issued before
+            // either interpolation starts
+            const float um = mu - 0.5f * sps_f * (1.f - integ), fm = floorf(um);
+            const int m2 = m + (int)fm;
+            const GardnerTaps ta = gardner_taps(my, m), tb = gardner_taps(my, max(m2, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            const float2 sk = gardner_eval(ta, mu);
+            const float2 mid = gardner_eval(tb, m2 >= 1 ? um - fm : 0.f);
             float v = 0.f;
-            if (have_prev) {
-                const float2 mid = gardner_farrow(my, t - 0.5 * sps * (1.0 - (double)integ));
-                pw = 0.99f * pw + 0.01f * (sk.x * sk.x + sk.y * sk.y);
+            {
+                const float pw_n = 0.99f * pw + 0.01f * (sk.x * sk.x + sk.y * sk.y);
                 const float dx = sk.x - prev.x, dy = sk.y - prev.y;
-                const float e = (dx * mid.x + dy * mid.y) / fmaxf(pw, 1e-12f);
-                integ += G.k2 * e;
-                v = G.k1 * e + integ;
+                const float e = (dx * mid.x + dy * mid.y) * __builtin_amdgcn_rcpf(fmaxf(pw_n, 1e-12f));
+                const float integ_n = integ + G.k2 * e;
+                pw = have_prev ? pw_n : pw;
+                integ = have_prev ? integ_n : integ;
+                v = have_prev ? G.k1 * e + integ_n : 0.f;
             }
             sr[k] = sk;
-            if (k == k_mid) t_mid_sym = t;
+            if (k == k_mid) t_mid_sym = (double)m + (double)mu;
             prev = sk;
             have_prev = true;
             ++k;
-            t += sps * (1.0 - (double)v);          // (a late strobe makes e positive: shorten the period)
-            active = t <= t_end && k < P.max_soft;
+            const float un = mu + sps_f * (1.f - v), fn = floorf(un);   // (a late strobe makes e positive: shorten the period)
+            m += (int)fn;
+            mu = un - fn;
+            active = in_chunk(m, mu) && k < P.max_soft;
         }
-        // the ring moves on when no active carrier needs its oldest chunk any more (a wavefront-uniform decision)
-        int lo = active ? ((int)t - back) : 0x7fffffff;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) lo = min(lo, __shfl_xor(lo, d, 64));
-        if (lo != 0x7fffffff && lo >= kGChunk * (c0 + 1)) {
+        // the ring moves on when no active carrier needs its oldest chunk any more (a wavefront-uniform vote)
+        const bool can_drop = !active || (m - back) >= kGChunk * (c0 + 1);
+        if (__all(can_drop) && __any(active)) {
             __syncthreads();                         // (one wavefront: orders the ring reads above against the writes below)
-            land(c0 + 3);                            // into the slots chunk c0 held
+            land(c0 + kGChunks);                     // into the slots chunk c0 held
             ++c0;
-            request(c0 + 3);
+            request(c0 + kGChunks);
             __syncthreads();
         }
     }
