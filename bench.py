@@ -870,6 +870,32 @@ def main_tetra(args):
     _print_leg(leg_tetra(args.carriers, args.steps, args.warmup))
 
 
+def leg_rrc(bd, rows, n, steps):
+    """The RRC stage alone (tdm_plan_rrc_filter: LDS-tiled sliding-window matched filter, cf32 in, cf32 out at the sample rate),
+    the stage `north_star`'s ">= 70 % of the HBM roofline for the RRC stage" names: launches back to back on the resident
+    batch of the tetra leg, HIP events on the plan's stream; algorithmic bytes 16 per sample (SURVEY 8(d) "unfused": 8 in +
+    8 out).  Its output is checked by tests/test_tetra_mode.py (every tap count, against the fp64 definition)."""
+    from tetraear_amd.batch import DeviceBuffer
+    pitch = (n + 1) & ~1
+    ybuf = DeviceBuffer(0, rows * pitch * 8)
+    try:
+        for _ in range(20 if PMC_CHILD else SETTLE_STEPS):
+            bd.enqueue_rrc_filter(ybuf, pitch)
+        bd.sync()
+        bd.time_begin()
+        for _ in range(steps):
+            bd.enqueue_rrc_filter(ybuf, pitch)
+        ms = bd.time_end() / steps
+    finally:
+        ybuf.free()
+    traffic, traffic_src, traffic_detail = (None, None, None) if PMC_CHILD else traffic_now(
+        ["--mode", "tetra", "--carriers", str(rows)], "k_tetra_mf<", rows * n, "tetra-cf32", "tetra_mf")
+    return hbm_roofline("k_tetra_mf<33> (RRC matched filter alone: LDS-tiled sliding window, 8 consecutive outputs per thread, taps in scalar registers, "
+                        "next tile's window in flight during the arithmetic; cf32 in and out)",
+                        rows * n * 16, ms, read_bytes=rows * n * 8, traffic=traffic, traffic_src=traffic_src, traffic_detail=traffic_detail,
+                        bytes_per_sample=16, steps=steps, timing="HIP events on the plan's stream, launches back to back")
+
+
 def leg_gardner(rows, base, chk, steps):
     """The same carriers through TDM_MODE_TETRA_GARDNER -- the timing recovery `north_star` names (Gardner TED + PI loop +
     period-controlled Farrow), a recurrence over a carrier's symbols run with one lane per carrier -- timed beside the
@@ -908,6 +934,7 @@ def leg_gardner(rows, base, chk, steps):
                  "worst_fraction_of_differing_decisions": worst, "rows_equal_their_prototype": bool(same),
                  "status": "decisions match the definition's loop (<= 1e-3 differing, count within one)" if (ok and same) else "DIFFERS from the definition"}
     return {"what": "TDM_MODE_TETRA_GARDNER: matched filter -> HBM -> Gardner TED + PI loop + Farrow, one lane per carrier -> decisions (3 launches)",
+
             "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s", "steps": steps, "stage_ms_per_launch": st,
             "output_check": check}
 
@@ -957,6 +984,10 @@ def leg_tetra(carriers, steps, warmup):
                  "hard_sha256_row0": d8[0], "rows_equal_their_prototype": bool(same), "soft_probes": int(idx.size),
                  "soft_max_err_rel": err, "soft_tolerance": 1e-5,
                  "status": "hard decisions match the definition-pinned digests, soft within 1e-5" if ok else "DIFFERS from the definition"}
+    try:
+        rrc_stage = leg_rrc(bd, rows, n, 3 if PMC_CHILD else steps)
+    except Exception as e:  # noqa: BLE001
+        rrc_stage = {"error": str(e)}
     gardner = None
     if not PMC_CHILD:
         try:
@@ -971,6 +1002,7 @@ def leg_tetra(carriers, steps, warmup):
            "realtime_carriers": nsym * steps / dt / 18000.0, "event_ms_per_step": ev_ms / steps,
            "stage_ms_per_launch": st,
            "output_check": check,
+           "rrc_stage": rrc_stage,
            "gardner_mode": gardner,
            "roofline": hbm_roofline("k_tetra_fused<33> (RRC matched filter on the matrix cores (split-bf16 products, fp32 accumulate) -> timing -> Farrow -> slicer, one pass over the input)",
                                     bytes_alg, rrc_ms, read_bytes=rows * n * 8, traffic=traffic, traffic_src=traffic_src,

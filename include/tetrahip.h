@@ -136,6 +136,13 @@ TDM_API int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_s
                        double *soft, int32_t *n_soft, int32_t *best_phase, double *min_margin,
                        void *stream);
 TDM_API int tdm_plan_sync(tdm_plan *plan);
+/* The RRC matched filter of a TDM_MODE_TETRA / TDM_MODE_TETRA_GARDNER plan on its own (the receiver's first stage as a
+ * stand-alone operator: LDS-tiled sliding window, cf32 in, cf32 out at the sample rate; oracle/tetra_np.py matched_filter
+ * with the plan's taps): iq [n_carriers] rows of the plan's chunk length, carrier_stride_samples apart; y [n_carriers]
+ * rows, y_pitch samples apart (even, >= the chunk length).  DEVICE pointers; enqueues on `stream` (NULL = the plan's) and
+ * returns.  No counterpart in the reference (it has no matched filter). */
+TDM_API int tdm_plan_rrc_filter(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, float *y, int64_t y_pitch,
+                                void *stream);
 /* Stream ordering of the stand-alone entry points.  Plans run on their own (non-blocking) stream, which has no implicit
  * ordering with the null stream.  The device-pointer forms of tdm_spectrum_gate, tdm_channelise(_batch) and
  * tdm_find_sync enqueue on the calling thread's CURRENT stream: the null stream until tdm_set_stream names another.

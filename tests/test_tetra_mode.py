@@ -507,3 +507,23 @@ def test_gpu_c5_full_size_wideband_chain():
     p_ch = np.mean(np.abs(y) ** 2, axis=1)
     assert np.max(p_ch[~near]) < 5e-2 * np.min(p_ch[ks])
     rx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_rrc_matched_filter_alone_equals_definition():
+    """tdm_plan_rrc_filter (the receiver's first stage as a stand-alone operator, the kernel the Gardner mode runs): against
+    oracle/tetra_np.matched_filter with the plan's 16-bit taps, every tap count the kernel is instantiated for, chunk lengths
+    that end inside a tile and inside a workgroup's run of tiles, rows at odd alignments"""
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    rng = np.random.default_rng(3)
+    for fs, n in ((72000.0, 8192), (72000.0, 8193), (36000.0, 2047), (54000.0, 6001), (90000.0, 10240), (144000.0, 20000), (108000.0, 64)):
+        rows = 3
+        x = (rng.standard_normal((rows, n)) + 1j * rng.standard_normal((rows, n))).astype(np.complex64)
+        bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA)
+        y = bd.rrc_filter(x)
+        bd.close()
+        h = tetra_np.rrc_taps(fs / 18000.0)
+        for r in range(rows):
+            ref = tetra_np.matched_filter(x[r].astype(np.complex128), h)
+            assert np.max(np.abs(y[r] - ref)) < 2e-6 * np.max(np.abs(ref)), (fs, n, r)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tdm_demodulate_dqpsk": (C.c_int, [_vp, _i64, _vp, _P(_i64), _P(_f64), _i32]),
     "tdm_set_stream": (C.c_int, [_vp]),
     "tdm_plan_stream": (C.c_int, [_vp, _P(_vp)]),
+    "tdm_plan_rrc_filter": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "tdm_decimate": (C.c_int, [_vp, _i64, _i32, _vp, _P(_i64), _i32]),
     "tdm_resample": (C.c_int, [_vp, _i64, _i64, _vp, _i32]),
     "tdm_spectrum_gate": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _f64, _vp, _vp, _i32, _i32]),

@@ -154,6 +154,27 @@ class BatchDemodulator:
                                           d["foff"].ptr if d["use_foff"] else None, d["hard"].ptr, d["soft"].ptr,
                                           d["n_soft"].ptr, d["bp"].ptr, d["mm"].ptr, None))
 
+    def enqueue_rrc_filter(self, y_buf, y_pitch, iq_ptr=None, stride=None):
+        """TETRA-mode plans: the RRC matched filter alone over the resident batch (tdm_plan_rrc_filter; asynchronous):
+        y_buf = DeviceBuffer of n_carriers x y_pitch complex64"""
+        d = self._dev
+        check(self.lib.tdm_plan_rrc_filter(self.handle, iq_ptr if iq_ptr is not None else d["iq"].ptr,
+                                           self.n_samples if stride is None else int(stride), y_buf.ptr, int(y_pitch), None))
+
+    def rrc_filter(self, iq):
+        """host in, host out: complex64 [n_carriers][n_samples] -> the matched filter's output, same shape"""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(self.n_carriers, self.n_samples)
+        pitch = (self.n_samples + 1) & ~1
+        din, dout = DeviceBuffer(self.device, iq.nbytes), DeviceBuffer(self.device, self.n_carriers * pitch * 8)
+        try:
+            din.upload(iq)
+            check(self.lib.tdm_plan_rrc_filter(self.handle, din.ptr, self.n_samples, dout.ptr, pitch, None))
+            self.sync()
+            return dout.download(np.complex64, self.n_carriers * pitch).reshape(self.n_carriers, pitch)[:, :self.n_samples].copy()
+        finally:
+            din.free()
+            dout.free()
+
     def sync(self):
         check(self.lib.tdm_plan_sync(self.handle))
 

@@ -813,16 +813,18 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
         const TetraParams &tp = plan->tp;
         if (plan->mode == TDM_MODE_TETRA_GARDNER) {
             // matched filter -> HBM -> Gardner loop, one lane per carrier -> decisions (tetra_gardner_kernels.hpp)
-            {
+            // (TDM_GARDNER_STAGES: bit mask of the launches to make -- 1 matched filter, 2 loop, 4 decisions; profiling only)
+            static const int stages = [] { const char *e = std::getenv("TDM_GARDNER_STAGES"); return e ? std::atoi(e) : 7; }();
+            if (stages & 1) {
                 HipBackend::Scope s(be, ST_TETRA_MF);
                 if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))
                     return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
             }
-            {
+            if (stages & 2) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 tetra_gardner_loop_launch(tp, plan->rows, plan->d_gy, plan->gy_pitch, (float2 *)soft, n_soft, best_phase, be.stream);
             }
-            {
+            if (stages & 4) {
                 HipBackend::Scope s(be, ST_TETRA_DECIDE);
                 tetra_decide_launch(tp, plan->rows, (const float2 *)soft, n_soft, hard, min_margin, be.stream);
             }
@@ -852,6 +854,24 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     B.lp2_raw = v.lp2_raw;
     RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin};
     run_ref(be, v.h, plan->rows, plan->fmt, B, io);
+    if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
+    return TDM_OK;
+}
+
+int tdm_plan_rrc_filter(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, float *y, int64_t y_pitch, void *stream)
+{
+    if (!plan || !iq || !y) return fail(TDM_ERR_INVALID, "null argument");
+    if (plan->mode != TDM_MODE_TETRA && plan->mode != TDM_MODE_TETRA_GARDNER) return fail(TDM_ERR_UNSUPPORTED, "a TETRA-mode plan holds the RRC taps");
+    if (carrier_stride_samples < plan->tp.n || y_pitch < plan->tp.n || (y_pitch & 1)) return fail(TDM_ERR_INVALID, "stride / pitch (even, >= chunk length)");
+    HIP_TRY(hipSetDevice(plan->device));
+    HipBackend be;
+    be.stream = stream ? (hipStream_t)stream : plan->stream;
+    be.timer = &plan->timer;
+    {
+        HipBackend::Scope s(be, ST_TETRA_MF);
+        if (!tetra_mf_launch(plan->tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)y, y_pitch, be.stream))
+            return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
+    }
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
     return TDM_OK;
 }

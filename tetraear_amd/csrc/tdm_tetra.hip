@@ -31,7 +31,8 @@ bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_s
 
 bool tetra_mf_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *y, int64_t y_pitch, hipStream_t stream)
 {
-    const dim3 grid((unsigned)((tp.n + kMfTile - 1) / kMfTile), (unsigned)rows);
+    const int tiles = (tp.n + kMfTile - 1) / kMfTile;
+    const dim3 grid((unsigned)((tiles + kMfTilesPerWg - 1) / kMfTilesPerWg), (unsigned)rows);
     switch (tp.ntaps) {
 #define TDM_MF_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_mf<NT>), grid, dim3(kMfThreads), 0, stream, x, in_stride, tp, y, y_pitch); return true;
         TDM_MF_CASE(17) TDM_MF_CASE(25) TDM_MF_CASE(33) TDM_MF_CASE(35) TDM_MF_CASE(41) TDM_MF_CASE(49) TDM_MF_CASE(57) TDM_MF_CASE(65)

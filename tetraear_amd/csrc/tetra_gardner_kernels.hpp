@@ -25,56 +25,130 @@
 
 namespace tdm {
 
-constexpr int kMfThreads = 256, kMfPer = 8, kMfTile = kMfThreads * kMfPer;
+constexpr int kMfThreads = 256, kMfPer = 8, kMfTile = kMfThreads * kMfPer, kMfTilesPerWg = 4;
 
-// y[n] = sum_t h[t] x[n + t - (NT-1)/2], zero outside the chunk (oracle/tetra_np.py matched_filter); y rows have pitch y_pitch
+// The RRC stage on its own: y[n] = sum_t h[t] x[n + t - (NT-1)/2], zero outside the chunk (oracle/tetra_np.py
+// matched_filter); y rows have pitch y_pitch.  HBM-bound by design (SURVEY 8(d) "unfused": 16 B per sample, 8 in + 8 out,
+// for 2 NT multiply-adds):
+//   * a workgroup's window (2048 + NT - 1 samples) travels HBM -> registers -> LDS with all of a thread's loads in flight
+//     at once (under a branch each would be waited for on its own: 2.25 ms instead of 0.60 for 4096 x 32 768), and a
+//     workgroup walks four tiles with the next window requested before the current one is worked on;
+//   * a thread forms EIGHT CONSECUTIVE outputs from the 8 + NT - 1 samples under them, read from LDS once (40 bytes of
+//     LDS traffic per output instead of the 8 NT of one-output-per-tap-read), taps in scalar registers, multiply-adds
+//     packed over (re, im);
+//   * the outputs leave through LDS, transposed, so that consecutive lanes store consecutive 16-byte pairs;
+//   * the LDS layout has two pad slots per eight samples: a lane's window starts 80 bytes after its neighbour's, so the
+//     lanes of a 16-byte read fall on different banks and every pair stays 16-byte aligned.
 template <int NT>
 __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restrict__ x, int64_t in_stride, const TetraParams P,
                                                          float2 *__restrict__ y, int64_t y_pitch)
 {
-    constexpr int H = (NT - 1) / 2, W = kMfTile + NT - 1;
-    __shared__ float2 xs[W + 1];
-    __shared__ float hs[NT];
+    constexpr int H = (NT - 1) / 2, W = kMfTile + NT - 1, WIN = kMfPer + NT - 1;   // WIN: samples under a thread's outputs
+    constexpr int NLD = (W + kMfThreads - 1) / kMfThreads;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float2 xs[W + 2 * (W / 8) + 4];
+    auto slot = [](int s) { return s + 2 * (s >> 3); };
     const int row = blockIdx.y, tid = threadIdx.x, n = P.n;
-    if (tid < NT) hs[tid] = P.taps[tid];
-    const int base = blockIdx.x * kMfTile;
     const float2 *xr = x + (int64_t)row * in_stride;
-    {
-        // the window's loads all in flight at once (unconditional, clamped addresses; masked as they land): under a branch
-        // every load would be waited for on its own -- nine serial HBM round trips per workgroup
-        constexpr int NLD = (W + kMfThreads - 1) / kMfThreads;
-        float2 v[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int g = base - H + tid + k * kMfThreads;
-            v[k] = xr[min(max(g, 0), n - 1)];
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = tid + k * kMfThreads, g = base - H + i;
-            if (i < W) xs[i] = (g >= 0 && g < n) ? v[k] : make_float2(0.f, 0.f);
-        }
-    }
-    __syncthreads();
-    // thread t: outputs t + 256 j -- consecutive lanes read consecutive LDS slots for every tap
-    float ar[kMfPer], ai[kMfPer];
-#pragma unroll
-    for (int j = 0; j < kMfPer; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
-#pragma unroll 3   // (a few taps' loads in flight: fully unrolled, the 8 x NT LDS reads are all hoisted and spill)
-    for (int t = 0; t < NT; ++t) {
-        const float h = hs[t];                      // (one broadcast LDS read per tap; a scalar load per turn would be waited for)
-#pragma unroll
-        for (int j = 0; j < kMfPer; ++j) {
-            const float2 v = xs[tid + kMfThreads * j + t];
-            ar[j] = fmaf(h, v.x, ar[j]);
-            ai[j] = fmaf(h, v.y, ai[j]);
-        }
-    }
     float2 *yr = y + (int64_t)row * y_pitch;
+    // a workgroup walks kMfTilesPerWg consecutive tiles with the NEXT tile's window already on its way from HBM while it
+    // works on the current one: the memory pipes never wait for a workgroup's arithmetic phase
+    // interior tiles (the whole window inside the chunk) travel as 16-byte pairs, NLP per thread, lanes past the window
+    // masked (they would fetch the next tile's first samples: +11 % of read traffic when they were not); the first and the
+    // last tile of a row take 8-byte loads with clamped addresses and zeros outside the chunk
+    constexpr int NLP = (W / 2 + kMfThreads - 1) / kMfThreads;
+    static_assert(W % 2 == 0 && NLP * 4 >= NLD * 2, "pairs; the registers of the pair path hold the single-sample path too");
+    typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (rows are 8-byte aligned: pitched channeliser rows)
+    f32x4 vp[NLP];
+    auto interior = [&](int base) { return base - H >= 0 && base - H + W <= n; };
+    auto fetch = [&](int base) {
+        if (interior(base)) {
+            const f32x4_a8 *pb = (const f32x4_a8 *)(xr + (base - H));
 #pragma unroll
-    for (int j = 0; j < kMfPer; ++j) {
-        const int g = base + tid + kMfThreads * j;
-        if (g < n) yr[g] = make_float2(ar[j], ai[j]);
+            for (int k = 0; k < NLP; ++k) {
+                const int pi = tid + k * kMfThreads;
+                if (k < NLP - 1 || pi < W / 2) vp[k] = __builtin_nontemporal_load(pb + pi);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int g = base - H + tid + k * kMfThreads;
+                const f32x2 q = __builtin_nontemporal_load((const f32x2 *)xr + min(max(g, 0), n - 1));
+                if (k & 1) { vp[k >> 1].z = q.x; vp[k >> 1].w = q.y; }
+                else { vp[k >> 1].x = q.x; vp[k >> 1].y = q.y; }
+            }
+        }
+    };
+    auto stage = [&](int base) {
+        if (interior(base)) {
+#pragma unroll
+            for (int k = 0; k < NLP; ++k) {
+                const int pi = tid + k * kMfThreads;
+                if (k < NLP - 1 || pi < W / 2) *(f32x4 *)(xs + slot(2 * pi)) = vp[k];   // (an even sample and its successor: adjacent slots)
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + k * kMfThreads, g = base - H + i;
+                const float2 q = (k & 1) ? make_float2(vp[k >> 1].z, vp[k >> 1].w) : make_float2(vp[k >> 1].x, vp[k >> 1].y);
+                if (i < W) xs[slot(i)] = (g >= 0 && g < n) ? q : make_float2(0.f, 0.f);
+            }
+        }
+    };
+    const int tile0 = blockIdx.x * kMfTilesPerWg, ntiles = (n + kMfTile - 1) / kMfTile;
+    // Order of a tile's memory operations: its stores are issued right AFTER the next tile's window has been taken out of
+    // the load registers, never before -- loads and stores count on one counter (vmcnt), so a wait for loads with younger
+    // stores in flight would be a wait for those stores' acknowledgements as well.
+    fetch(tile0 * kMfTile);
+    stage(tile0 * kMfTile);
+    for (int ti = 0; ti < kMfTilesPerWg; ++ti) {
+        const int tile = tile0 + ti;
+        if (tile >= ntiles) break;
+        const int base = tile * kMfTile;
+        const bool more = ti + 1 < kMfTilesPerWg && tile + 1 < ntiles;
+        __syncthreads();                                  // the tile's window is in LDS
+        if (more) fetch(base + kMfTile);
+        // the thread's window: samples 8 tid .. 8 tid + WIN - 1 of the staged tile
+        f32x2 w[WIN + 1];
+        {
+            const float2 *p = xs + slot(kMfPer * tid);       // (8 tid is a multiple of 8: the window starts a padded group)
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                f32x2 q = *(const f32x2 *)(p + i + 2 * (i >> 3));
+                asm volatile("" : "+v"(q));   // (opaque: read once, kept in registers)
+                w[i] = q;
+            }
+        }
+        f32x2 acc[kMfPer];
+#pragma unroll
+        for (int j = 0; j < kMfPer; ++j) acc[j] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float h = P.taps[t];
+#pragma unroll
+            for (int j = 0; j < kMfPer; ++j) acc[j] += w[j + t] * h;
+        }
+        // out through LDS: a thread's eight outputs are 64 contiguous bytes, so stored from registers every store
+        // instruction would touch 64 lines with 16 bytes each; transposed, consecutive lanes store consecutive 16-byte pairs
+        __syncthreads();
+        {
+            float2 *p = xs + slot(kMfPer * tid);
+#pragma unroll
+            for (int j = 0; j < kMfPer; j += 2) *(f32x4 *)(p + j) = f32x4{acc[j].x, acc[j].y, acc[j + 1].x, acc[j + 1].y};
+        }
+        __syncthreads();
+        f32x4 q[kMfPer / 2];
+#pragma unroll
+        for (int k = 0; k < kMfPer / 2; ++k) q[k] = *(const f32x4 *)(xs + slot(2 * (tid + k * kMfThreads)));
+        __syncthreads();                                  // the LDS is free for the next window
+        if (more) stage(base + kMfTile);
+#pragma unroll
+        for (int k = 0; k < kMfPer / 2; ++k) {
+            const int g = base + 2 * (tid + k * kMfThreads);   // chunk position of the pair
+            if (g + 1 < n) __builtin_nontemporal_store(q[k], (f32x4 *)(yr + g));
+            else if (g < n) yr[g] = make_float2(q[k].x, q[k].y);
+        }
     }
 }
 
