@@ -890,8 +890,8 @@ def leg_rrc(bd, rows, n, steps):
         ybuf.free()
     traffic, traffic_src, traffic_detail = (None, None, None) if PMC_CHILD else traffic_now(
         ["--mode", "tetra", "--carriers", str(rows)], "k_tetra_mf<", rows * n, "tetra-cf32", "tetra_mf")
-    return hbm_roofline("k_tetra_mf<33> (RRC matched filter alone: LDS-tiled sliding window, 8 consecutive outputs per thread, taps in scalar registers, "
-                        "next tile's window in flight during the arithmetic; cf32 in and out)",
+    return hbm_roofline("k_tetra_mf<33> (RRC matched filter alone: LDS-tiled sliding window, 8 consecutive outputs per thread from one LDS read per sample, "
+                        "taps in scalar registers, outputs transposed through LDS; cf32 in and out)",
                         rows * n * 16, ms, read_bytes=rows * n * 8, traffic=traffic, traffic_src=traffic_src, traffic_detail=traffic_detail,
                         bytes_per_sample=16, steps=steps, timing="HIP events on the plan's stream, launches back to back")
 

@@ -12,33 +12,39 @@
 //   k_tetra_decide   differential products, 4th-power carrier-offset estimate, quadrant decisions, margin (one workgroup
 //                    per carrier)
 // It is the slower receiver by construction and exists because the north-star names it: tests compare it with the fp64
-// definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768): matched filter 0.60 ms
-// (3.6 TB/s), loop 3.66 ms, decisions 0.10 ms.  The loop's time does not depend on the number of carriers up to 16 384 (64
-// per wavefront, one wavefront per SIMD): it is 8190 turns x ~1070 cycles, and a turn is its ~150 vector instructions at one
-// issue per four cycles plus two LDS round trips -- without the mid-symbol strobe 3.03 ms, without the per-symbol store
-// 3.72 ms, with the instant in fp64 instead of (int, fp32) 3.66 ms: no single piece dominates.
+// definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768): matched filter 0.37 ms
+// (5.8 TB/s), loop 2.92 ms, decisions 0.10 ms.  The loop's time does not depend on the number of carriers up to 16 384 (64
+// per wavefront, one wavefront per SIMD): 8190 turns x ~860 cycles, a turn being its ~100 vector instructions at one issue
+// per four cycles plus the LDS round trip and the loop filter's dependent chain.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "tetra_params.hpp"
 
+
 namespace tdm {
 
-constexpr int kMfThreads = 256, kMfPer = 8, kMfTile = kMfThreads * kMfPer, kMfTilesPerWg = 4;
+#ifndef TDM_MF_TPW
+#define TDM_MF_TPW 1   // tiles a workgroup walks, the next one's window in flight (measured: 1 -> 0.371 ms, 2 -> 0.377, 4 -> 0.390, 8 -> 0.424)
+#endif
+constexpr int kMfThreads = 256, kMfPer = 8, kMfTile = kMfThreads * kMfPer, kMfTilesPerWg = TDM_MF_TPW;
 
 // The RRC stage on its own: y[n] = sum_t h[t] x[n + t - (NT-1)/2], zero outside the chunk (oracle/tetra_np.py
 // matched_filter); y rows have pitch y_pitch.  HBM-bound by design (SURVEY 8(d) "unfused": 16 B per sample, 8 in + 8 out,
-// for 2 NT multiply-adds):
+// for 2 NT multiply-adds).  Measured on one MI355X, 4096 x 32 768 (A/B builds on the same box):
 //   * a workgroup's window (2048 + NT - 1 samples) travels HBM -> registers -> LDS with all of a thread's loads in flight
-//     at once (under a branch each would be waited for on its own: 2.25 ms instead of 0.60 for 4096 x 32 768), and a
-//     workgroup walks four tiles with the next window requested before the current one is worked on;
-//   * a thread forms EIGHT CONSECUTIVE outputs from the 8 + NT - 1 samples under them, read from LDS once (40 bytes of
-//     LDS traffic per output instead of the 8 NT of one-output-per-tap-read), taps in scalar registers, multiply-adds
-//     packed over (re, im);
+//     at once -- under a branch each is waited for on its own: 2.25 ms instead of 0.60 -- as 16-byte pairs where the whole
+//     window lies inside the chunk (8-byte loads everywhere: +2 %);
+//   * a thread forms EIGHT CONSECUTIVE outputs from the 8 + NT - 1 samples under them, read from LDS once (40 bytes of LDS
+//     traffic per output; with one output per tap-read, 8 NT bytes per output, the kernel was LDS-bound: 0.60 ms,
+//     SQ_WAIT_INST_LDS 60 % of the wave cycles), taps in scalar registers, multiply-adds packed over (re, im);
 //   * the outputs leave through LDS, transposed, so that consecutive lanes store consecutive 16-byte pairs;
 //   * the LDS layout has two pad slots per eight samples: a lane's window starts 80 bytes after its neighbour's, so the
-//     lanes of a 16-byte read fall on different banks and every pair stays 16-byte aligned.
+//     lanes of a read fall on different banks and every pair stays 16-byte aligned;
+//   * ONE tile per workgroup: 0.371 ms = 5.79 TB/s = 0.72 of 8 TB/s.  (A workgroup walking 2 / 4 / 8 tiles with the next
+//     window in flight: 0.377 / 0.390 / 0.424 ms -- with seven workgroups per compute unit the dispatcher's interleaving
+//     hides the load phase better than a static walk does.)
 template <int NT>
 __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restrict__ x, int64_t in_stride, const TetraParams P,
                                                          float2 *__restrict__ y, int64_t y_pitch)
@@ -175,11 +181,14 @@ __device__ __forceinline__ GardnerTaps gardner_taps(const float2 *ring_row, int 
 }
 __device__ __forceinline__ float2 gardner_eval(const GardnerTaps &g, float mu)
 {
-    const float2 ym1 = g.ym1, y0 = g.y0, y1 = g.y1, y2 = g.y2;
-    const float c1x = y1.x - ym1.x * (1.f / 3.f) - y0.x * 0.5f - y2.x * (1.f / 6.f), c1y = y1.y - ym1.y * (1.f / 3.f) - y0.y * 0.5f - y2.y * (1.f / 6.f);
-    const float c2x = (ym1.x + y1.x) * 0.5f - y0.x, c2y = (ym1.y + y1.y) * 0.5f - y0.y;
-    const float c3x = (y2.x - ym1.x) * (1.f / 6.f) + (y0.x - y1.x) * 0.5f, c3y = (y2.y - ym1.y) * (1.f / 6.f) + (y0.y - y1.y) * 0.5f;
-    return make_float2(((c3x * mu + c2x) * mu + c1x) * mu + y0.x, ((c3y * mu + c2y) * mu + c1y) * mu + y0.y);
+    // the cubic through the four samples at -1, 0, 1, 2 as Lagrange weights of mu (the definition's _farrow1 in Horner form is
+    // the same polynomial): 11 scalar operations, then four multiply-adds per component -- half the instructions of forming
+    // the three Horner coefficients per component (3.11 -> 2.92 ms)
+    const float a = mu + 1.f, b = mu - 1.f, c = mu - 2.f;
+    const float s1 = (mu * b) * (1.f / 6.f), s2 = (a * c) * 0.5f;
+    const float w2 = s1 * a, wm1 = -(s1 * c), w0 = s2 * b, w1 = -(s2 * mu);
+    return make_float2(fmaf(g.ym1.x, wm1, fmaf(g.y0.x, w0, fmaf(g.y1.x, w1, g.y2.x * w2))),
+                       fmaf(g.ym1.y, wm1, fmaf(g.y0.y, w0, fmaf(g.y1.y, w1, g.y2.y * w2))));
 }
 
 __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__ y, int64_t y_pitch, const TetraParams P,
@@ -244,48 +253,55 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
     const int k_mid = (int)(0.5 * (double)n / sps);
     auto in_chunk = [&](int mm, float uu) { return mm < m_end || (mm == m_end && uu == 0.f); };
     bool active = mine && in_chunk(m, mu);
-    const int max_turns = 4 * P.max_soft + 64;      // (bounded whatever the input: every turn advances the slowest active carrier)
-    for (int turn = 0; turn < max_turns; ++turn) {
+    // Turns come in blocks of kGBlock without any wavefront-wide decision inside (a carrier outside the resident chunks
+    // simply waits out the turn); whether the ring can move on, and whether anybody is still active, is voted on between
+    // blocks.  (With the votes in every turn: 3.62 ms instead of 2.92 for 4096 x 32 768.)
+    constexpr int kGBlock = 8;
+    const int max_blocks = (4 * P.max_soft + 64) / kGBlock;   // (bounded whatever the input: every turn advances the slowest active carrier)
+    for (int blk = 0; blk < max_blocks; ++blk) {
         if (!__any(active)) break;
-        // a carrier takes its strobes when the samples both of them can touch lie in the resident chunks; one that has run
-        // ahead of the wavefront's slowest carrier by more than three chunks waits for the ring to move on
-        const int mlo = max(m - back, 0), mhi = m + 2;
-        const bool ok = active && mlo >= kGChunk * c0 && mhi < kGChunk * (c0 + kGChunks);
-        if (ok) {
-            // both strobes in one basic block (the mid-symbol one is formed for the first symbol too and not used): two
-            // independent chains of LDS reads and multiply-adds that the scheduler interleaves -- with one wavefront per
-            // SIMD every dependent instruction's latency is exposed, and the turn's length is its longest chain
-            // mid-symbol strobe at t - 0.5 sps (1 - integ), not before sample 1.  All eight ring reads are issued before
-            // either interpolation starts
-            const float um = mu - 0.5f * sps_f * (1.f - integ), fm = floorf(um);
-            const int m2 = m + (int)fm;
-            const GardnerTaps ta = gardner_taps(my, m), tb = gardner_taps(my, max(m2, 1));
-            __builtin_amdgcn_sched_barrier(0);
-            const float2 sk = gardner_eval(ta, mu);
-            const float2 mid = gardner_eval(tb, m2 >= 1 ? um - fm : 0.f);
-            float v = 0.f;
-            {
-                const float pw_n = 0.99f * pw + 0.01f * (sk.x * sk.x + sk.y * sk.y);
-                const float dx = sk.x - prev.x, dy = sk.y - prev.y;
-                const float e = (dx * mid.x + dy * mid.y) * __builtin_amdgcn_rcpf(fmaxf(pw_n, 1e-12f));
-                const float integ_n = integ + G.k2 * e;
-                pw = have_prev ? pw_n : pw;
-                integ = have_prev ? integ_n : integ;
-                v = have_prev ? G.k1 * e + integ_n : 0.f;
+#pragma unroll
+        for (int turn = 0; turn < kGBlock; ++turn) {
+            // a carrier takes its strobes when the samples both of them can touch lie in the resident chunks; one that has
+            // run ahead of the wavefront's slowest carrier by more than three chunks waits for the ring to move on
+            const int mlo = max(m - back, 0), mhi = m + 2;
+            const bool ok = active && mlo >= kGChunk * c0 && mhi < kGChunk * (c0 + kGChunks);
+            if (ok) {
+                // mid-symbol strobe at t - 0.5 sps (1 - integ), not before sample 1 (formed for the first symbol too and not
+                // used).  All eight ring reads are issued before either interpolation starts: two independent chains the
+                // scheduler interleaves -- with one wavefront per SIMD every dependent instruction's latency is exposed
+                const float um = mu - 0.5f * sps_f * (1.f - integ), fm = floorf(um);
+                const int m2 = m + (int)fm;
+                const GardnerTaps ta = gardner_taps(my, m), tb = gardner_taps(my, max(m2, 1));
+                __builtin_amdgcn_sched_barrier(0);
+                const float2 sk = gardner_eval(ta, mu);
+                const float2 mid = gardner_eval(tb, m2 >= 1 ? um - fm : 0.f);
+                float v = 0.f;
+                {
+                    const float pw_n = 0.99f * pw + 0.01f * (sk.x * sk.x + sk.y * sk.y);
+                    const float dx = sk.x - prev.x, dy = sk.y - prev.y;
+                    const float e = (dx * mid.x + dy * mid.y) * __builtin_amdgcn_rcpf(fmaxf(pw_n, 1e-12f));
+                    const float integ_n = integ + G.k2 * e;
+                    pw = have_prev ? pw_n : pw;
+                    integ = have_prev ? integ_n : integ;
+                    v = have_prev ? G.k1 * e + integ_n : 0.f;
+                }
+                sr[k] = sk;
+                if (k == k_mid) t_mid_sym = (double)m + (double)mu;
+                prev = sk;
+                have_prev = true;
+                ++k;
+                const float un = mu + sps_f * (1.f - v), fn = floorf(un);   // (a late strobe makes e positive: shorten the period)
+                m += (int)fn;
+                mu = un - fn;
+                active = in_chunk(m, mu) && k < P.max_soft;
             }
-            sr[k] = sk;
-            if (k == k_mid) t_mid_sym = (double)m + (double)mu;
-            prev = sk;
-            have_prev = true;
-            ++k;
-            const float un = mu + sps_f * (1.f - v), fn = floorf(un);   // (a late strobe makes e positive: shorten the period)
-            m += (int)fn;
-            mu = un - fn;
-            active = in_chunk(m, mu) && k < P.max_soft;
         }
-        // the ring moves on when no active carrier needs its oldest chunk any more (a wavefront-uniform vote)
-        const bool can_drop = !active || (m - back) >= kGChunk * (c0 + 1);
-        if (__all(can_drop) && __any(active)) {
+        // the ring moves on while no active carrier needs its oldest chunk any more (wavefront-uniform votes)
+#pragma unroll 1
+        for (int hop = 0; hop < 2; ++hop) {
+            const bool can_drop = !active || (m - back) >= kGChunk * (c0 + 1);
+            if (!(__all(can_drop) && __any(active))) break;
             __syncthreads();                         // (one wavefront: orders the ring reads above against the writes below)
             land(c0 + kGChunks);                     // into the slots chunk c0 held
             ++c0;
