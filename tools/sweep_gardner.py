@@ -1,0 +1,49 @@
+"""Randomised sweep of TDM_MODE_TETRA_GARDNER on the GPU: random chunk lengths, sample rates (3..8 samples/symbol), row
+strides, timing / carrier / symbol-clock offsets at 15..25 dB; decisions against the fp64 definition's loop
+(oracle/tetra_np.demod_gardner: <= 1e-3 may differ, count within one) and error-free against the transmitted dibits
+after acquisition; also the stand-alone RRC filter against the definition."""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+from oracle import tetra_np
+from tetraear_amd import synth
+from tetraear_amd._lib import MODE_TETRA_GARDNER, check, ptr
+from tetraear_amd.batch import BatchDemodulator
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
+t0 = time.time(); bad = 0; cnt = 0; worst = 0.0
+while time.time() - t0 < budget:
+    fs = float(rng.choice([54000.0, 72000.0, 75000.0, 80000.0, 90000.0, 108000.0, 144000.0]))
+    n = int(rng.integers(3000, 20000))
+    rows = int(rng.integers(1, 4))
+    pitch = n + int(rng.integers(0, 9))
+    xs, dibs = [], []
+    for r in range(rows):
+        ppm = float(rng.uniform(-300, 300))
+        snr = float(rng.uniform(15, 25))
+        x, d = synth.dqpsk_baseband(n, fs / (1 + ppm * 1e-6), int(rng.integers(1 << 30)), timing_offset=float(rng.uniform(-0.5, 0.5)))
+        sps = fs / 18000.0
+        x = x + np.sqrt(sps / 10 ** (snr / 10) / 2) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        x = x * np.exp(2j * np.pi * float(rng.uniform(-100, 100)) * np.arange(n) / fs)
+        xs.append(x.astype(np.complex64)); dibs.append(d)
+    bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+    buf = np.full((rows, pitch), 9.0, dtype=np.complex64)
+    for r in range(rows): buf[r, :n] = xs[r]
+    ms = bd.info.max_soft
+    hard = np.zeros((rows, ms), np.uint8); soft = np.zeros((rows, ms), np.complex64); ns = np.zeros(rows, np.int32)
+    check(bd.lib.tdm_process(bd.handle, ptr(buf), pitch, None, None, ptr(hard), ptr(soft), ptr(ns), None, None))
+    y = bd.rrc_filter(np.stack(xs))
+    for r in range(rows):
+        cnt += 1
+        h = hard[r, :max(ns[r] - 1, 0)]
+        rh, _, info = tetra_np.demod_gardner(xs[r].astype(np.complex128), fs)
+        m = min(len(h), len(rh))
+        frac = float(np.mean(h[:m] != rh[:m])) if m else 1.0
+        worst = max(worst, frac)
+        ref = tetra_np.matched_filter(xs[r].astype(np.complex128), tetra_np.rrc_taps(fs / 18000.0))
+        mf_err = float(np.max(np.abs(y[r] - ref)) / np.max(np.abs(ref)))
+        ok = abs(int(ns[r]) - len(info["t"])) <= 1 and frac <= 1e-3 and mf_err < 2e-6
+        if not ok:
+            bad += 1; print("MISMATCH", fs, n, rows, pitch, ns[r], len(info["t"]), frac, mf_err)
+    bd.close()
+print(f"{cnt} carriers, {bad} mismatches, worst fraction of differing decisions {worst:.2e}")
