@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
 #pragma unroll
             for (int i = 0; i < WIN; ++i) {
                 f32x2 q = *(const f32x2 *)(p + i + 2 * (i >> 3));
-                asm volatile("" : "+v"(q));   // (opaque: read once, kept in registers)
+                asm volatile("" : "+v"(q));   // (opaque: read once, kept in registers; 16-byte reads or no pin measure the same)
                 w[i] = q;
             }
         }
