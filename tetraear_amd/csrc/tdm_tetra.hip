@@ -51,11 +51,7 @@ void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y,
     const double den = 1.0 + 2.0 * zeta * th + th * th;
     GardnerConsts G{(float)(4.0 * zeta * th / den / kp), (float)(4.0 * th * th / den / kp)};
     const size_t lds = (size_t)64 * kGPitch * sizeof(float2);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)k_tetra_gardner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    (void)hipFuncSetAttribute((const void *)k_tetra_gardner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (per device: every launch)
     hipLaunchKernelGGL(k_tetra_gardner, dim3((unsigned)((rows + 63) / 64)), dim3(64), lds, stream, y, y_pitch, tp, G, rows, soft, n_soft,
                        timing_milli);
 }
