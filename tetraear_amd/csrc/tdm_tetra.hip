@@ -49,11 +49,9 @@ void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y,
     const double bn_t = 0.01, zeta = 0.7071, kp = 2.7;
     const double th = bn_t / (zeta + 0.25 / zeta);
     const double den = 1.0 + 2.0 * zeta * th + th * th;
-    GardnerConsts G{(float)(4.0 * zeta * th / den / kp), (float)(4.0 * th * th / den / kp)};
-    const size_t lds = (size_t)64 * kGPitch * sizeof(float2);
-    (void)hipFuncSetAttribute((const void *)k_tetra_gardner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (per device: every launch)
-    hipLaunchKernelGGL(k_tetra_gardner, dim3((unsigned)((rows + 63) / 64)), dim3(64), lds, stream, y, y_pitch, tp, G, rows, soft, n_soft,
-                       timing_milli);
+    GardnerConsts G{(float)(100.0 * 4.0 * zeta * th / den / kp), (float)(100.0 * 4.0 * th * th / den / kp)};   // (x 100: see GardnerConsts)
+    hipLaunchKernelGGL(k_tetra_gardner, dim3((unsigned)((rows + kGQuads - 1) / kGQuads)), dim3(64), 0, stream, y, y_pitch, tp, G, rows,
+                       soft, n_soft, timing_milli);
 }
 
 void tetra_decide_launch(const TetraParams &tp, int rows, const float2 *soft, const int32_t *n_soft, uint8_t *hard, double *min_margin,

@@ -6,19 +6,26 @@
 // before it), so it cannot be tiled over time like the feed-forward receiver of tetra_kernels.hpp: the parallel axis is
 // the CARRIER.  Three kernels:
 //   k_tetra_mf       matched filter, LDS-tiled sliding window, fp32, output to HBM (one workgroup per 2048 outputs)
-//   k_tetra_gardner  ONE LANE PER CARRIER walks its carrier's symbols; a wavefront's 64 carriers share an LDS ring of
-//                    matched-filter samples (four 64-sample chunks per carrier, refilled cooperatively with coalesced
-//                    loads one chunk ahead), so that the loop's dependent chain sees LDS latency, not HBM latency
+//   k_tetra_gardner  FOUR LANES PER CARRIER walk its symbols (lane = strobe x component); a wavefront's 16 carriers share
+//                    an LDS ring of matched-filter samples (four 64-sample chunks per carrier, refilled cooperatively
+//                    with coalesced loads one chunk ahead), so that the loop's dependent chain sees LDS latency, not HBM
+//                    latency
 //   k_tetra_decide   differential products, 4th-power carrier-offset estimate, quadrant decisions, margin (one workgroup
 //                    per carrier)
 // It is the slower receiver by construction and exists because the north-star names it: tests compare it with the fp64
 // definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768): matched filter 0.37 ms
-// (5.8 TB/s), loop 2.92 ms, decisions 0.10 ms.  The loop's time does not depend on the number of carriers up to 16 384 (64
-// per wavefront, one wavefront per SIMD): 8190 turns x ~860 cycles, a turn being its ~100 vector instructions at one issue
-// per four cycles plus the LDS round trip and the loop filter's dependent chain.
+// (5.8 TB/s), loop 1.47 ms, decisions 0.10 ms.  The loop's time does not depend on the number of carriers up to 16 384
+// (one wavefront per SIMD): it is 8190 symbols x the ~180 ns ONE symbol's chain of ~45 vector instructions takes in a
+// wavefront that has its SIMD to itself (tools/harness/ubench_chain.hip: a lone wavefront issues one vector instruction
+// per 3.4 ns, a dependent multiply-add takes 4.6 ns, an LDS round trip 23 ns).  History of that number: one lane per carrier
+// 2.92 ms (135 instructions a turn); four lanes per carrier 2.31; first symbol peeled, one-compare window test 2.18; the rare
+// work (capacity, middle symbol, clamp) in a second copy of the block, cross-lane operands folded into the arithmetic (DPP),
+// all four lanes store 1.83; straight-line turns behind ONE wavefront-uniform branch 1.76; ring moves without clamps and
+// address arithmetic, 16-turn blocks 1.47.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "tetra_params.hpp"
 
@@ -159,147 +166,218 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
 }
 
 // ---- the loop ---------------------------------------------------------------------------------------------------------
-constexpr int kGChunk = 64, kGChunks = 4, kGRing = kGChunks * kGChunk, kGPitch = kGRing + 1;   // LDS slots per carrier (+1: rows on different banks)
+// FOUR LANES PER CARRIER: lane (s, c) of a carrier's quad forms component c (re / im) of strobe s (on time / mid-symbol) --
+// its own four ring reads, its own Lagrange weights, four dependent multiply-adds -- and the detector's two sums over the
+// quad travel by DPP (no LDS, no cross-lane latency beyond the instruction itself).  The loop's time is the length of ONE
+// symbol's dependent chain times the symbols of a carrier, whatever the number of carriers (every wavefront has a SIMD to
+// itself up to 16 384 carriers), so the lanes are spent on shortening that chain: one lane per carrier (both strobes, both
+// components and eight ring reads in every lane: ~135 instructions a turn, 64 carriers and 131 KB of ring per wavefront)
+// took 2.92 ms for 4096 x 32 768; this one 1.47 ms (the steps in between: head of this file).
+constexpr int kGChunk = 64, kGChunks = 4, kGRing = kGChunks * kGChunk;
+constexpr int kGQuads = 16;                  // carriers per wavefront
+constexpr int kGPitch = kGRing + 3;          // LDS slots per carrier: the ring and its first three slots once more behind it, so that
+                                             // a lane's four taps are four CONSECUTIVE slots wherever the window starts (odd: rows on different banks)
 static_assert((kGRing & (kGRing - 1)) == 0, "ring index by mask");
 
 struct GardnerConsts {
     float k1, k2;      // loop filter gains (oracle/tetra_np.py demod_gardner: Rice eq. C.61, detector gain 2.7, bn_t 0.01, zeta 0.7071)
+                       // x 100: the kernel tracks 100 x the symbol power (one multiplication less per symbol)
 };
 
-// cubic Lagrange interpolation (the definition's _farrow1: samples at -1, 0, 1, 2 around the whole part m of t).  Sample g of
-// a carrier lives in slot g mod 256 of its ring row (a chunk is 64 slots, four chunks are resident), so any index --
-// also that of a carrier whose loop has run away -- stays inside the row.
-struct GardnerTaps { float2 ym1, y0, y1, y2; };
-__device__ __forceinline__ GardnerTaps gardner_taps(const float2 *ring_row, int m)
+template <int CTRL>
+__device__ __forceinline__ float gardner_quad(float v)   // DPP quad_perm: lane i of a quad reads lane (CTRL >> 2 i) & 3
 {
-    GardnerTaps g;
-    g.ym1 = ring_row[(m - 1) & (kGRing - 1)];
-    g.y0 = ring_row[m & (kGRing - 1)];
-    g.y1 = ring_row[(m + 1) & (kGRing - 1)];
-    g.y2 = ring_row[(m + 2) & (kGRing - 1)];
-    return g;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float2 gardner_eval(const GardnerTaps &g, float mu)
-{
-    // the cubic through the four samples at -1, 0, 1, 2 as Lagrange weights of mu (the definition's _farrow1 in Horner form is
-    // the same polynomial): 11 scalar operations, then four multiply-adds per component -- half the instructions of forming
-    // the three Horner coefficients per component (3.11 -> 2.92 ms)
-    const float a = mu + 1.f, b = mu - 1.f, c = mu - 2.f;
-    const float s1 = (mu * b) * (1.f / 6.f), s2 = (a * c) * 0.5f;
-    const float w2 = s1 * a, wm1 = -(s1 * c), w0 = s2 * b, w1 = -(s2 * mu);
-    return make_float2(fmaf(g.ym1.x, wm1, fmaf(g.y0.x, w0, fmaf(g.y1.x, w1, g.y2.x * w2))),
-                       fmaf(g.ym1.y, wm1, fmaf(g.y0.y, w0, fmaf(g.y1.y, w1, g.y2.y * w2))));
-}
+constexpr int kQuadOtherComponent = 0xB1;    // [1, 0, 3, 2]
+constexpr int kQuadMidStrobe = 0xEE;         // [2, 3, 2, 3]
+constexpr int kQuadFirst = 0x00;             // [0, 0, 0, 0]
+constexpr int kQuadSymbolPair = 0x44;        // [0, 1, 0, 1]
 
 __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__ y, int64_t y_pitch, const TetraParams P,
                                                       const GardnerConsts G, int rows, float2 *__restrict__ soft,
                                                       int32_t *__restrict__ n_soft, int32_t *__restrict__ timing_milli)
 {
-    extern __shared__ float2 ring[];               // [64 carriers][kGPitch]
-    const int lane = threadIdx.x;
-    const int row = min((int)blockIdx.x * 64 + lane, rows - 1);
-    const bool mine = (int)blockIdx.x * 64 + lane < rows;
+    __shared__ float2 ring[kGQuads * kGPitch];      // sample g of a carrier in slot g mod 256 of its row (33 KB)
+    const int lane = threadIdx.x, quad = lane >> 2, s = (lane >> 1) & 1, c = lane & 1;
+    const int row = min((int)blockIdx.x * kGQuads + quad, rows - 1);
+    const bool mine = (int)blockIdx.x * kGQuads + quad < rows;
     const int n = P.n;
     const double sps = P.sps;
     const int back = (int)sps + 4;                 // samples behind floor(t) a strobe may need (mid-symbol strobe + interpolator)
-    float2 *my = ring + lane * kGPitch;
-    float2 *sr = soft + (int64_t)row * P.max_soft;
+    const float *my = (const float *)(ring + quad * kGPitch) + c;      // component c of slot i: my[2 i]
+    // soft symbols: the workgroup's rows from a scalar base, a lane's position in them as a 32-bit byte offset that also
+    // counts the carrier's symbols (k = (off - off0) / 8)
+    char *const wg_soft = (char *)(soft + (int64_t)blockIdx.x * kGQuads * P.max_soft);
+    const uint32_t off0 = (uint32_t)quad * (uint32_t)P.max_soft * 8u + 4u * (uint32_t)c;
+    uint32_t off = off0;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (a clamped pair at the end of an odd-length row starts on an odd sample)
-    // ---- cooperative chunk moves: chunk c = samples [64 c, 64 c + 64) of every carrier of the wavefront.  One 16-byte load
+    // ---- cooperative chunk moves: chunk cn = samples [64 cn, 64 cn + 64) of every carrier of the wavefront.  One 16-byte load
     // fetches two samples; lanes 0..31 serve carrier 2 q, lanes 32..63 carrier 2 q + 1 (rows are 16-byte aligned: even pitch)
-    f32x4 pf[32];
+    f32x4 pf[kGQuads / 2];
     const int half = lane >> 5, l32 = lane & 31;
-    auto request = [&](int c) {
+    const float2 *src[kGQuads / 2];                // this lane's pair in chunk 0 of the carriers it serves
+    float2 *dst0[kGQuads / 2];                     // ... and its slots in their ring rows
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int r = min((int)blockIdx.x * 64 + 2 * q + half, rows - 1);
-            const int g = kGChunk * c + 2 * l32;
-            const int gg = min(g, max(n - 2, 0));                      // (clamped address; masked when it lands)
-            pf[q] = *(const f32x4_a8 *)(y + (int64_t)r * y_pitch + gg);
+    for (int q = 0; q < kGQuads / 2; ++q) {
+        src[q] = y + (int64_t)min((int)blockIdx.x * kGQuads + 2 * q + half, rows - 1) * y_pitch + 2 * l32;
+        dst0[q] = ring + (2 * q + half) * kGPitch + 2 * l32;
+    }
+    // (a chunk that ends inside the row -- all but the last one or two -- moves without clamps and masks: a ring move is
+    //  paid by the sixteen symbols a chunk holds)
+    auto request = [&](int cn) {
+        if (kGChunk * cn + kGChunk <= n) {
+#pragma unroll
+            for (int q = 0; q < kGQuads / 2; ++q) pf[q] = *(const f32x4_a8 *)(src[q] + kGChunk * cn);
+        } else {
+            const int g = kGChunk * cn + 2 * l32;
+            const int gg = min(g, max(n - 2, 0)) - 2 * l32;            // (clamped address; masked when it lands)
+#pragma unroll
+            for (int q = 0; q < kGQuads / 2; ++q) pf[q] = *(const f32x4_a8 *)(src[q] + gg);
         }
     };
-    auto land = [&](int c) {
+    auto land = [&](int cn) {
+        const int g = kGChunk * cn + 2 * l32, ring0 = (kGChunk * cn) & (kGRing - 1);
+        const bool inside = kGChunk * cn + kGChunk <= n;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int g = kGChunk * c + 2 * l32;
+        for (int q = 0; q < kGQuads / 2; ++q) {
             float2 a = make_float2(pf[q].x, pf[q].y), b = make_float2(pf[q].z, pf[q].w);
-            if (g >= n) a = make_float2(0.f, 0.f);
-            if (g + 1 >= n) b = make_float2(0.f, 0.f);
-            if (g == n - 1 && n >= 2) a = make_float2(pf[q].z, pf[q].w);   // (the clamped pair ends at n - 1: its second half is sample n - 1)
-            float2 *dst = ring + (2 * q + half) * kGPitch + (g & (kGRing - 1));
+            if (!inside) {
+                if (g >= n) a = make_float2(0.f, 0.f);
+                if (g + 1 >= n) b = make_float2(0.f, 0.f);
+                if (g == n - 1 && n >= 2) a = make_float2(pf[q].z, pf[q].w);   // (the clamped pair ends at n - 1: its second half is sample n - 1)
+            }
+            float2 *dst = dst0[q] + ring0;
             dst[0] = a;
             dst[1] = b;
+            if (ring0 == 0) {                                          // slots 0..2 once more behind the ring
+                if (l32 == 0) { dst[kGRing] = a; dst[kGRing + 1] = b; }
+                if (l32 == 1) dst[kGRing] = a;
+            }
         }
     };
 #pragma unroll 1
-    for (int c = 0; c < kGChunks; ++c) { request(c); land(c); }
+    for (int cn = 0; cn < kGChunks; ++cn) { request(cn); land(cn); }
     int c0 = 0;                                     // oldest resident chunk: chunks c0 .. c0 + kGChunks - 1 are in the ring
     request(kGChunks);                              // in flight while the first symbols are formed
     __syncthreads();
-    // ---- per-carrier loop state (oracle/tetra_np.py demod_gardner)
+    // ---- per-carrier loop state (oracle/tetra_np.py demod_gardner), the same in the four lanes of a quad
     // the symbol instant t = m + mu, whole samples and a fraction in [0, 1): integer and fp32 arithmetic only in the loop's
     // dependent chain (an fp32 t would be good to 4e-3 samples at the end of a 32 768-sample chunk, an fp64 t puts a dozen
     // long-latency instructions into every turn)
     const float sps_f = (float)sps;
+    const float half_lane = s ? 0.5f * sps_f : 0.f;  // lanes s = 0: the "mid-symbol" formulas below yield the symbol instant itself
+    const float gain_t = sps_f * G.k1;              // period correction in samples per unit of error
+    const float k2_v = G.k2;
     int m = 1 + (int)floor(sps);
     float mu = (float)(sps - floor(sps));
-    float integ = 0.f, pw = 1.f;
-    float2 prev = make_float2(0.f, 0.f);
-    bool have_prev = false;
-    int k = 0;
-    double t_mid_sym = 0.0;
+    float integ = 0.f;
+    float q = 100.f;                                // running symbol power x 100 (the factor rides on the gains: GardnerConsts)
+    float prev = 0.f;                               // lanes s = 0: component c of the previous symbol
+    int m_mid = 0;
+    float mu_mid = 0.f;                             // the instant of the chunk's middle symbol
     const int m_end = n - 3;                        // t <= n - 3  <=>  m < n - 3 or (m == n - 3 and mu == 0)
     const int k_mid = (int)(0.5 * (double)n / sps);
+    // a carrier takes its strobes in a turn when m < hi_v: see the block loop
+    int hi_v = -0x7fffffff;
+    // One symbol of one carrier (the quad's four lanes together).  FIRST: no predecessor yet -- no error, nominal period.
+    // SLOW: the work only a few turns of a carrier need -- the mid strobe held at sample 1 (first chunk), the middle symbol's
+    // instant, the capacity of the output row -- compiled into a second copy of the block that runs when some carrier of
+    // the wavefront is near one of them.
+    // The symbol goes to position off + 8 T of the row (T: the turn of an unrolled run; `off` moves on behind it).
+    auto symbol = [&](auto first, auto slow, const int T) {
+        constexpr bool FIRST = decltype(first)::value, SLOW = decltype(slow)::value;
+        // mid-symbol strobe at t - 0.5 sps (1 - integ), not before sample 1 (formed for the first symbol too and not used);
+        // in lanes s = 0 the half period is zero: um = mu, floor(um) = 0, and the strobe is the symbol's
+        const float um = fmaf(half_lane, integ, mu - half_lane), fm = floorf(um);
+        const int m2 = m + (int)fm;
+        const int mym = SLOW ? max(m2, 1) : m2;
+        const float u = (!SLOW || m2 >= 1) ? um - fm : 0.f;
+        // cubic Lagrange interpolation (the definition's _farrow1: samples at -1, 0, 1, 2 around the whole part of the
+        // instant; in Horner form it is the same polynomial): 11 operations for the weights, in the shadow of the ring reads
+        const float *p = my + 2 * ((mym - 1) & (kGRing - 1));
+        const float ym1 = p[0], y0 = p[2], y1 = p[4], y2 = p[6];
+        const float a = u + 1.f, b = u - 1.f, cc = u - 2.f;
+        const float s1 = (u * b) * (1.f / 6.f), s2 = (a * cc) * 0.5f;
+        const float w2 = s1 * a, wm1 = -(s1 * cc), w0 = s2 * b, w1 = -(s2 * u);
+        const float val = fmaf(ym1, wm1, fmaf(y0, w0, fmaf(y1, w1, y2 * w2)));   // s = 0: the symbol's component c; s = 1: the mid strobe's
+        float un = mu + sps_f;
+        if (!FIRST) {
+            // detector e = Re{(s_k - s_k-1) conj(s_k-1/2)} / (running power), right in lane (0, re) of the quad and broadcast from
+            // there; loop filter and the next instant in every lane (the cross-lane operands ride on the instructions: DPP)
+#pragma clang fp contract(off)   // (the cross-lane operands below stay operands of the additions and products: DPP folds into them)
+            const float t = gardner_quad<kQuadMidStrobe>(val) * (val - prev);
+            const float ee = gardner_quad<kQuadOtherComponent>(t) + t;
+            const float v2 = val * val;
+            q = fmaf(0.99f, q, gardner_quad<kQuadOtherComponent>(v2) + v2);
+            const float e = ee * __builtin_amdgcn_rcpf(fmaxf(q, 1e-10f));
+            integ = fmaf(gardner_quad<kQuadFirst>(e), k2_v, integ);
+            un = fmaf(gardner_quad<kQuadFirst>(e), -gain_t, fmaf(-sps_f, integ, un));   // t + sps (1 - (k1 e + integ)): a late strobe makes e positive and shortens the period
+        }
+        // (all four lanes store: lanes s = 1 their partner's value to their partner's address -- cheaper than masking them out)
+        *(float *)(wg_soft + off + 8 * T) = gardner_quad<kQuadSymbolPair>(val);
+        if (SLOW) {
+            const int k = (int)((off - off0) >> 3) + T;
+            if (k == k_mid) { m_mid = m; mu_mid = mu; }
+            if (k + 1 >= P.max_soft) hi_v = -0x7fffffff;     // the row is full
+        }
+        prev = val;
+        const float fn = floorf(un);
+        m += (int)fn;
+        mu = un - fn;
+    };
     auto in_chunk = [&](int mm, float uu) { return mm < m_end || (mm == m_end && uu == 0.f); };
-    bool active = mine && in_chunk(m, mu);
-    // Turns come in blocks of kGBlock without any wavefront-wide decision inside (a carrier outside the resident chunks
-    // simply waits out the turn); whether the ring can move on, and whether anybody is still active, is voted on between
-    // blocks.  (With the votes in every turn: 3.62 ms instead of 2.92 for 4096 x 32 768.)
-    constexpr int kGBlock = 8;
+    bool active = mine && in_chunk(m, mu) && P.max_soft > 0;
+    if (active) {                                   // (its samples lie in the first chunks: m = 1 + floor(sps))
+        symbol(std::true_type{}, std::true_type{}, 0);
+        off += 8;
+    }
+    // Turns come in blocks of kGBlock with nothing wavefront-wide -- and nothing that only changes slowly -- inside: whether a
+    // carrier is still inside its chunk and its row, whether the ring can move on and whether anybody is still active is
+    // settled between blocks (a carrier outside the resident chunks simply waits out the turn).
+    constexpr int kGBlock = 16;
     const int max_blocks = (4 * P.max_soft + 64) / kGBlock;   // (bounded whatever the input: every turn advances the slowest active carrier)
     for (int blk = 0; blk < max_blocks; ++blk) {
+        const int k = (int)((off - off0) >> 3);
+        const bool corner = m == m_end && mu == 0.f;          // t = n - 3 exactly: the last instant inside the chunk
+        active = mine && (m < m_end || corner) && k < P.max_soft;
         if (!__any(active)) break;
+        // a carrier takes its strobes when the samples both of them can touch lie in the resident chunks -- m - back >= 64 c0
+        // (nothing lies before sample 0; settled here for the whole block: m does not go back in a loop that works) and
+        // m + 2 < 64 (c0 + 4) -- and m is inside the chunk: per turn ONE comparison, m < hi_v; one that has run ahead of the
+        // wavefront's slowest carrier by more than three chunks waits for the ring to move on
+        hi_v = (active && (c0 == 0 || m - back >= kGChunk * c0)) ? min(kGChunk * (c0 + kGChunks) - 2, m_end + (corner ? 1 : 0)) : -0x7fffffff;
+        const bool near = (k <= k_mid && k_mid < k + kGBlock) || k + kGBlock > P.max_soft;
+        // The block's turns run with the active carriers' lanes enabled and NO per-lane decision while every one of them can
+        // take its strobes (one wavefront-uniform branch per turn: carriers of a wavefront move in step unless their clocks
+        // differ by more than three chunks); what is left of the block when one cannot is done lane by lane.
+        int turn = 0;
+        const int first_active = __ffsll((unsigned long long)__ballot(active)) - 1;
+        auto block = [&](auto slow) {
+            if (active) {
 #pragma unroll
-        for (int turn = 0; turn < kGBlock; ++turn) {
-            // a carrier takes its strobes when the samples both of them can touch lie in the resident chunks; one that has
-            // run ahead of the wavefront's slowest carrier by more than three chunks waits for the ring to move on
-            const int mlo = max(m - back, 0), mhi = m + 2;
-            const bool ok = active && mlo >= kGChunk * c0 && mhi < kGChunk * (c0 + kGChunks);
-            if (ok) {
-                // mid-symbol strobe at t - 0.5 sps (1 - integ), not before sample 1 (formed for the first symbol too and not
-                // used).  All eight ring reads are issued before either interpolation starts: two independent chains the
-                // scheduler interleaves -- with one wavefront per SIMD every dependent instruction's latency is exposed
-                const float um = mu - 0.5f * sps_f * (1.f - integ), fm = floorf(um);
-                const int m2 = m + (int)fm;
-                const GardnerTaps ta = gardner_taps(my, m), tb = gardner_taps(my, max(m2, 1));
-                __builtin_amdgcn_sched_barrier(0);
-                const float2 sk = gardner_eval(ta, mu);
-                const float2 mid = gardner_eval(tb, m2 >= 1 ? um - fm : 0.f);
-                float v = 0.f;
-                {
-                    const float pw_n = 0.99f * pw + 0.01f * (sk.x * sk.x + sk.y * sk.y);
-                    const float dx = sk.x - prev.x, dy = sk.y - prev.y;
-                    const float e = (dx * mid.x + dy * mid.y) * __builtin_amdgcn_rcpf(fmaxf(pw_n, 1e-12f));
-                    const float integ_n = integ + G.k2 * e;
-                    pw = have_prev ? pw_n : pw;
-                    integ = have_prev ? integ_n : integ;
-                    v = have_prev ? G.k1 * e + integ_n : 0.f;
+                for (int t = 0; t < kGBlock; ++t) {
+                    if (!__all(m < hi_v)) break;
+                    symbol(std::false_type{}, slow, t);
+                    ++turn;
                 }
-                sr[k] = sk;
-                if (k == k_mid) t_mid_sym = (double)m + (double)mu;
-                prev = sk;
-                have_prev = true;
-                ++k;
-                const float un = mu + sps_f * (1.f - v), fn = floorf(un);   // (a late strobe makes e positive: shorten the period)
-                m += (int)fn;
-                mu = un - fn;
-                active = in_chunk(m, mu) && k < P.max_soft;
+                off += 8 * turn;
             }
-        }
-        // the ring moves on while no active carrier needs its oldest chunk any more (wavefront-uniform votes)
+            turn = __builtin_amdgcn_readlane(turn, first_active);   // (lanes outside the branch hold 0: the count of a lane inside)
 #pragma unroll 1
-        for (int hop = 0; hop < 2; ++hop) {
+            for (; turn < kGBlock; ++turn)
+                if (m < hi_v) {                              // (the same in a quad's four lanes)
+                    symbol(std::false_type{}, slow, 0);
+                    off += 8;
+                }
+        };
+        if (c0 == 0 || __any(active && near)) block(std::true_type{});
+        else block(std::false_type{});
+        // the ring moves on while no active carrier needs its oldest chunk any more (wavefront-uniform votes)
+        active = mine && in_chunk(m, mu) && (int)((off - off0) >> 3) < P.max_soft;
+#pragma unroll 1
+        for (int hop = 0; hop < 4; ++hop) {
             const bool can_drop = !active || (m - back) >= kGChunk * (c0 + 1);
             if (!(__all(can_drop) && __any(active))) break;
             __syncthreads();                         // (one wavefront: orders the ring reads above against the writes below)
@@ -309,10 +387,11 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
             __syncthreads();
         }
     }
-    if (mine) {
+    const int k = (int)((off - off0) >> 3);
+    if (mine && (lane & 3) == 0) {
         n_soft[row] = k;
         if (timing_milli) {
-            const double u = t_mid_sym / sps;
+            const double u = ((double)m_mid + (double)mu_mid) / sps;
             timing_milli[row] = (int32_t)rint((u - rint(u)) * 1000.0);
         }
     }

@@ -1,6 +1,6 @@
 """Randomised sweep of TDM_MODE_TETRA_GARDNER on the GPU: random chunk lengths, sample rates (3..8 samples/symbol), row
 strides, timing / carrier / symbol-clock offsets at 15..25 dB; decisions against the fp64 definition's loop
-(oracle/tetra_np.demod_gardner: <= 1e-3 may differ, count within one) and error-free against the transmitted dibits
+(oracle/tetra_np.demod_gardner: decisions may differ where the definition's own derotated product lies within 0.1 rad of a quadrant boundary -- an fp32 loop against an fp64 one at 15 dB --, at most 2e-3 of them; count within one) and error-free against the transmitted dibits
 after acquisition; also the stand-alone RRC filter against the definition."""
 import sys, time
 import numpy as np
@@ -36,13 +36,17 @@ while time.time() - t0 < budget:
     for r in range(rows):
         cnt += 1
         h = hard[r, :max(ns[r] - 1, 0)]
-        rh, _, info = tetra_np.demod_gardner(xs[r].astype(np.complex128), fs)
+        rh, rdd, info = tetra_np.demod_gardner(xs[r].astype(np.complex128), fs)
         m = min(len(h), len(rh))
-        frac = float(np.mean(h[:m] != rh[:m])) if m else 1.0
+        diff = np.flatnonzero(h[:m] != rh[:m])
+        frac = len(diff) / m if m else 1.0
+        # distance of the definition's derotated products from the nearest quadrant boundary, at the differing decisions
+        ang = np.angle(rdd[diff]) if len(diff) else np.zeros(0)
+        marginal = bool(np.all(np.abs((ang + np.pi / 4) % (np.pi / 2) - np.pi / 4) < 0.1))
         worst = max(worst, frac)
         ref = tetra_np.matched_filter(xs[r].astype(np.complex128), tetra_np.rrc_taps(fs / 18000.0))
         mf_err = float(np.max(np.abs(y[r] - ref)) / np.max(np.abs(ref)))
-        ok = abs(int(ns[r]) - len(info["t"])) <= 1 and frac <= 1e-3 and mf_err < 2e-6
+        ok = abs(int(ns[r]) - len(info["t"])) <= 1 and marginal and frac <= 2e-3 and mf_err < 2e-6
         if not ok:
             bad += 1; print("MISMATCH", fs, n, rows, pitch, ns[r], len(info["t"]), frac, mf_err)
     bd.close()
