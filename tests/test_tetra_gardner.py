@@ -96,7 +96,7 @@ def _check_against_definition(x, fs, hard, soft, dib, skip=300):
 
 @pytest.mark.gpu
 def test_gpu_gardner_receiver_matches_definition_and_transmitted():
-    """Gardner TED + PI loop + Farrow on the device, one lane per carrier: against oracle/tetra_np.demod_gardner (decisions)
+    """Gardner TED + PI loop + Farrow on the device, four lanes per carrier: against oracle/tetra_np.demod_gardner (decisions)
     and against the transmitted dibits (error-free after the loop's acquisition at 20 dB), at 3..8 samples per symbol,
     with timing and carrier offsets and a symbol clock 200 ppm off"""
     from tetraear_amd._lib import MODE_TETRA_GARDNER
@@ -115,7 +115,7 @@ def test_gpu_gardner_receiver_matches_definition_and_transmitted():
 
 @pytest.mark.gpu
 def test_gpu_gardner_receiver_many_carriers_share_a_wavefront():
-    """130 carriers (two full wavefronts of 64 and a partial one) with different symbol-clock offsets: the carriers of a
+    """130 carriers (eight full wavefronts of 16 and a partial one) with different symbol-clock offsets: the carriers of a
     wavefront drift apart by several samples over the chunk while sharing one ring of matched-filter samples; every one
     equals the definition"""
     from tetraear_amd._lib import MODE_TETRA_GARDNER
@@ -133,3 +133,57 @@ def test_gpu_gardner_receiver_many_carriers_share_a_wavefront():
         m = len(hards[r])
         dib = sig[r][1]
         assert min(int(np.sum(hards[r][300:m - 8] != dib[lag + 300:lag + m - 8])) for lag in range(40) if len(dib) - lag >= m) == 0, r
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_carriers_of_a_wavefront_more_than_three_chunks_apart():
+    """Symbol clocks on time and 1 % slow in ONE wavefront: over 24 576 samples the carriers drift 245 samples apart,
+    more than the three chunks of the shared ring -- the fast ones wait for the ring to move on (turns taken lane by lane
+    instead of the straight-line run).  Every carrier equals the definition (a loop of this bandwidth slips symbols while it pulls
+    in a 1 % offset -- the definition's does too --, so only the carriers on time are also held against what was sent)."""
+    from tetraear_amd._lib import MODE_TETRA_GARDNER
+    from tetraear_amd.batch import BatchDemodulator
+    fs, n, rows = 72000.0, 24576, 20
+    sig = [_gardner_case(n, fs, 900 + r, 0.1 * (r % 5) - 0.2, float((r * 31) % 200 - 100), 25.0, 0.0 if r % 2 else -10000.0)
+           for r in range(rows)]
+    bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+    hards, softs, timing, margin = bd.process(np.concatenate([s[0] for s in sig]))
+    bd.close()
+    counts = [len(s) for s in softs]
+    assert max(counts) - min(counts) >= 55, counts      # (1 % of 6144 symbols: the two groups really are that far apart)
+    for r in range(rows):
+        errs = _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1], skip=600)
+        assert errs == 0 or r % 2 == 0, (r, errs)
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_short_rows_silence_and_capacity():
+    """rows as short as a plan takes (64 samples: one ring chunk, one block of turns), a silent carrier beside live ones (zero error, nominal
+    period: at 4 samples per symbol its last instant is n - 3 exactly, the closed end of the chunk), odd lengths and
+    pitches: symbol counts and decisions against the definition"""
+    from tetraear_amd._lib import MODE_TETRA_GARDNER, check, ptr
+    from tetraear_amd.batch import BatchDemodulator
+    fs = 72000.0
+    for n in (64, 65, 67, 131, 257, 1000, 4096):
+        rows, pitch = 5, n + 3
+        xs = [_gardner_case(n, fs, 70 + r, 0.2 * r - 0.3, 0.0, 30.0)[0] for r in range(rows)]
+        xs[2] = np.zeros(n, np.complex64)
+        bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+        ms = bd.info.max_soft
+        buf = np.full((rows, pitch), 7.0 + 7.0j, dtype=np.complex64)
+        for r in range(rows):
+            buf[r, :n] = xs[r]
+        hard = np.full((rows, ms), 9, np.uint8)
+        soft = np.zeros((rows, ms), np.complex64)
+        ns = np.zeros(rows, np.int32)
+        check(bd.lib.tdm_process(bd.handle, ptr(buf), pitch, None, None, ptr(hard), ptr(soft), ptr(ns), None, None))
+        bd.close()
+        for r in range(rows):
+            ref_hard, _, info = tetra_np.demod_gardner(xs[r].astype(np.complex128), fs)
+            if r == 2:
+                assert ns[r] == len(info["t"]), (n, ns[r], len(info["t"]))      # exact arithmetic on zeros: the same count
+                assert not np.any(soft[r, :ns[r]])
+                continue
+            assert abs(int(ns[r]) - len(info["t"])) <= 1, (n, r, ns[r], len(info["t"]))
+            m = min(max(int(ns[r]) - 1, 0), len(ref_hard))
+            assert int(np.sum(hard[r, :m] != ref_hard[:m])) <= (1 if m > 200 else 0), (n, r)
