@@ -898,7 +898,7 @@ def leg_rrc(bd, rows, n, steps):
 
 def leg_gardner(rows, base, chk, steps):
     """The same carriers through TDM_MODE_TETRA_GARDNER -- the timing recovery `north_star` names (Gardner TED + PI loop +
-    period-controlled Farrow), a recurrence over a carrier's symbols run with one lane per carrier -- timed beside the
+    period-controlled Farrow), a recurrence over a carrier's symbols run with four lanes per carrier -- timed beside the
     feed-forward receiver that is the leg's headline.  Output check: every prototype row against the decisions of the fp64
     definition's loop (oracle/tetra_np.demod_gardner via the fixture): the device's loop runs in fp32, so the count may
     differ by one symbol at the chunk's end and at most 1e-3 of the decisions (symbols the definition itself puts within
@@ -933,7 +933,7 @@ def leg_gardner(rows, base, chk, steps):
         check = {"against": "oracle/tetra_np.py demod_gardner (fp64 loop), pinned by tests/golden/make_bench_checks.py",
                  "worst_fraction_of_differing_decisions": worst, "rows_equal_their_prototype": bool(same),
                  "status": "decisions match the definition's loop (<= 1e-3 differing, count within one)" if (ok and same) else "DIFFERS from the definition"}
-    return {"what": "TDM_MODE_TETRA_GARDNER: matched filter -> HBM -> Gardner TED + PI loop + Farrow, one lane per carrier -> decisions (3 launches)",
+    return {"what": "TDM_MODE_TETRA_GARDNER: matched filter -> HBM -> Gardner TED + PI loop + Farrow, four lanes per carrier -> decisions (3 launches)",
 
             "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s", "steps": steps, "stage_ms_per_launch": st,
             "output_check": check}

@@ -63,7 +63,7 @@ typedef enum tdm_mode {
                                the input's scale and of the alignment of its rows */
     TDM_MODE_TETRA_GARDNER = 2 /* the same receiver with the timing recovery BASELINE.json's north_star names: Gardner
                                timing-error detector -> proportional-integral loop -> period-controlled Farrow
-                               interpolation (oracle/tetra_np.py demod_gardner), one lane per carrier.  Same I/O as
+                               interpolation (oracle/tetra_np.py demod_gardner), four lanes per carrier.  Same I/O as
                                TDM_MODE_TETRA; slower by construction (a recurrence over a carrier's symbols) */
 } tdm_mode;
 
