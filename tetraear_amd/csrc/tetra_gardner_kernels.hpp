@@ -14,14 +14,15 @@
 //                    per carrier)
 // It is the slower receiver by construction and exists because the north-star names it: tests compare it with the fp64
 // definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768): matched filter 0.37 ms
-// (5.8 TB/s), loop 1.47 ms, decisions 0.10 ms.  The loop's time does not depend on the number of carriers up to 16 384
-// (one wavefront per SIMD): it is 8190 symbols x the ~180 ns ONE symbol's chain of ~45 vector instructions takes in a
+// (5.8 TB/s), loop 1.37 ms, decisions 0.10 ms.  The loop's time does not depend on the number of carriers up to 16 384
+// (one wavefront per SIMD): it is 8190 symbols x the ~165 ns ONE symbol's chain of ~40 vector instructions takes in a
 // wavefront that has its SIMD to itself (tools/harness/ubench_chain.hip: a lone wavefront issues one vector instruction
 // per 3.4 ns, a dependent multiply-add takes 4.6 ns, an LDS round trip 23 ns).  History of that number: one lane per carrier
 // 2.92 ms (135 instructions a turn); four lanes per carrier 2.31; first symbol peeled, one-compare window test 2.18; the rare
 // work (capacity, middle symbol, clamp) in a second copy of the block, cross-lane operands folded into the arithmetic (DPP),
 // all four lanes store 1.83; straight-line turns behind ONE wavefront-uniform branch 1.76; ring moves without clamps and
-// address arithmetic, 16-turn blocks 1.47.
+// address arithmetic, 16-turn blocks 1.47; weights and taps as packed instructions 1.46 (they sat in the shadow of the ring
+// reads); the next symbol's ring reads issued at the end of the turn (software pipeline) 1.37.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
 // symbol's dependent chain times the symbols of a carrier, whatever the number of carriers (every wavefront has a SIMD to
 // itself up to 16 384 carriers), so the lanes are spent on shortening that chain: one lane per carrier (both strobes, both
 // components and eight ring reads in every lane: ~135 instructions a turn, 64 carriers and 131 KB of ring per wavefront)
-// took 2.92 ms for 4096 x 32 768; this one 1.47 ms (the steps in between: head of this file).
+// took 2.92 ms for 4096 x 32 768; this one 1.37 ms (the steps in between: head of this file).
 constexpr int kGChunk = 64, kGChunks = 4, kGRing = kGChunks * kGChunk;
 constexpr int kGQuads = 16;                  // carriers per wavefront
 constexpr int kGPitch = kGRing + 3;          // LDS slots per carrier: the ring and its first three slots once more behind it, so that
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
     char *const wg_soft = (char *)(soft + (int64_t)blockIdx.x * kGQuads * P.max_soft);
     const uint32_t off0 = (uint32_t)quad * (uint32_t)P.max_soft * 8u + 4u * (uint32_t)c;
     uint32_t off = off0;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (a clamped pair at the end of an odd-length row starts on an odd sample)
     // ---- cooperative chunk moves: chunk cn = samples [64 cn, 64 cn + 64) of every carrier of the wavefront.  One 16-byte load
@@ -281,6 +283,30 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
     const int k_mid = (int)(0.5 * (double)n / sps);
     // a carrier takes its strobes in a turn when m < hi_v: see the block loop
     int hi_v = -0x7fffffff;
+    // Software pipeline over the symbols: the strobe positions of the NEXT symbol are known as soon as this symbol's error is
+    // (both follow from the instant of this symbol, the loop filter's state and e), so a turn ends by issuing the next
+    // turn's ring reads -- their round trip passes behind the store, the state update and the turn's branch, and behind
+    // the next turn's weights.  aim: whole part and fraction of a lane's strobe at m0 + x samples, and the reads.
+    int pm = 1;                                     // the lane's strobe of the coming symbol: taps in slots pm - 1 .. pm + 2,
+    float pu = 0.f;                                 // fraction pu
+    f32x2 py01 = {0.f, 0.f}, py23 = {0.f, 0.f};     // the taps, on their way
+    auto fetch = [&]() {
+        const float *p = my + 2 * ((pm - 1) & (kGRing - 1));
+        py01 = f32x2{p[0], p[2]};
+        py23 = f32x2{p[4], p[6]};
+    };
+    auto aim = [&](auto slow, int m0, float x) {
+        constexpr bool SLOW = decltype(slow)::value;
+        const float fx = floorf(x);
+        const int m2 = m0 + (int)fx;
+        // (the mid-symbol strobe is not taken before sample 1: the first chunk's business)
+        pm = SLOW ? max(m2, 1) : m2;
+        pu = (!SLOW || m2 >= 1) ? x - fx : 0.f;
+        fetch();
+    };
+    const float c_int = half_lane - sps_f;          // d(strobe position) / d(integrator)
+    const float c_err = c_int * G.k2 - gain_t;      // d(strobe position) / d(error)
+    const float c_err_t = -sps_f * G.k2 - gain_t;   // the same for the symbol instant itself (lanes s = 0: c_err)
     // One symbol of one carrier (the quad's four lanes together).  FIRST: no predecessor yet -- no error, nominal period.
     // SLOW: the work only a few turns of a carrier need -- the mid strobe held at sample 1 (first chunk), the middle symbol's
     // instant, the capacity of the output row -- compiled into a second copy of the block that runs when some carrier of
@@ -288,21 +314,24 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
     // The symbol goes to position off + 8 T of the row (T: the turn of an unrolled run; `off` moves on behind it).
     auto symbol = [&](auto first, auto slow, const int T) {
         constexpr bool FIRST = decltype(first)::value, SLOW = decltype(slow)::value;
-        // mid-symbol strobe at t - 0.5 sps (1 - integ), not before sample 1 (formed for the first symbol too and not used);
-        // in lanes s = 0 the half period is zero: um = mu, floor(um) = 0, and the strobe is the symbol's
-        const float um = fmaf(half_lane, integ, mu - half_lane), fm = floorf(um);
-        const int m2 = m + (int)fm;
-        const int mym = SLOW ? max(m2, 1) : m2;
-        const float u = (!SLOW || m2 >= 1) ? um - fm : 0.f;
         // cubic Lagrange interpolation (the definition's _farrow1: samples at -1, 0, 1, 2 around the whole part of the
-        // instant; in Horner form it is the same polynomial): 11 operations for the weights, in the shadow of the ring reads
-        const float *p = my + 2 * ((mym - 1) & (kGRing - 1));
-        const float ym1 = p[0], y0 = p[2], y1 = p[4], y2 = p[6];
-        const float a = u + 1.f, b = u - 1.f, cc = u - 2.f;
-        const float s1 = (u * b) * (1.f / 6.f), s2 = (a * cc) * 0.5f;
-        const float w2 = s1 * a, wm1 = -(s1 * cc), w0 = s2 * b, w1 = -(s2 * u);
-        const float val = fmaf(ym1, wm1, fmaf(y0, w0, fmaf(y1, w1, y2 * w2)));   // s = 0: the symbol's component c; s = 1: the mid strobe's
-        float un = mu + sps_f;
+        // instant; in Horner form it is the same polynomial) as Lagrange weights:
+        // w-1 = -u(u-1)(u-2)/6, w0 = (u+1)(u-1)(u-2)/2, w1 = -(u+1)u(u-2)/2, w2 = (u+1)u(u-1)/6, two at a time -- a packed
+        // instruction costs a lone wavefront the same issue slot as a plain one (ubench_chain) --: 6 instructions, and the four
+        // taps as a packed product, a packed multiply-add and one addition
+        const f32x2 uu = {pu, pu};
+        const f32x2 A = uu + f32x2{0.f, 1.f};                  // {u, u + 1}
+        const f32x2 Bn = f32x2{1.f, 2.f} - uu;                 // {1 - u, 2 - u}   (signs arranged so that no half needs a negation of its own)
+        const f32x2 S = (A * Bn) * f32x2{-1.f / 6.f, 0.5f};    // {u (u-1) / 6, -(u+1)(u-2) / 2}
+        const f32x2 W21 = S * f32x2{A.y, A.x};                 // {w2, w1}
+        const f32x2 Wm10 = S * f32x2{Bn.y, Bn.x};              // {w-1, w0}
+        const f32x2 acc = __builtin_elementwise_fma(py23, f32x2{W21.y, W21.x}, py01 * Wm10);
+        const float val = acc.x + acc.y;                       // s = 0: the symbol's component c; s = 1: the mid strobe's
+        // where the next symbol's strobes lie, up to the error's share: this symbol's instant + sps (1 - integ) for the
+        // symbol, half a period (0.5 sps (1 - integ)) earlier for the mid strobe (half_lane: 0 in lanes s = 0)
+        const float base = mu + sps_f;
+        float x = fmaf(c_int, integ, base - half_lane);        // the lane's strobe, relative to m
+        float un = fmaf(-sps_f, integ, base);                  // the instant
         if (!FIRST) {
             // detector e = Re{(s_k - s_k-1) conj(s_k-1/2)} / (running power), right in lane (0, re) of the quad and broadcast from
             // there; loop filter and the next instant in every lane (the cross-lane operands ride on the instructions: DPP)
@@ -311,10 +340,13 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
             const float ee = gardner_quad<kQuadOtherComponent>(t) + t;
             const float v2 = val * val;
             q = fmaf(0.99f, q, gardner_quad<kQuadOtherComponent>(v2) + v2);
-            const float e = ee * __builtin_amdgcn_rcpf(fmaxf(q, 1e-10f));
-            integ = fmaf(gardner_quad<kQuadFirst>(e), k2_v, integ);
-            un = fmaf(gardner_quad<kQuadFirst>(e), -gain_t, fmaf(-sps_f, integ, un));   // t + sps (1 - (k1 e + integ)): a late strobe makes e positive and shortens the period
+            const float e = gardner_quad<kQuadFirst>(ee * __builtin_amdgcn_rcpf(fmaxf(q, 1e-10f)));
+            // t + sps (1 - (k1 e + integ')), integ' = integ + k2 e: a late strobe makes e positive and shortens the period
+            x = fmaf(c_err, e, x);
+            un = fmaf(c_err_t, e, un);
+            integ = fmaf(k2_v, e, integ);
         }
+        aim(slow, m, x);                                       // the next symbol's reads leave here
         // (all four lanes store: lanes s = 1 their partner's value to their partner's address -- cheaper than masking them out)
         *(float *)(wg_soft + off + 8 * T) = gardner_quad<kQuadSymbolPair>(val);
         if (SLOW) {
@@ -329,7 +361,8 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
     };
     auto in_chunk = [&](int mm, float uu) { return mm < m_end || (mm == m_end && uu == 0.f); };
     bool active = mine && in_chunk(m, mu) && P.max_soft > 0;
-    if (active) {                                   // (its samples lie in the first chunks: m = 1 + floor(sps))
+    aim(std::true_type{}, m, mu - half_lane);       // the first symbol's strobes (its samples lie in the first chunks: m = 1 + floor(sps))
+    if (active) {
         symbol(std::true_type{}, std::true_type{}, 0);
         off += 8;
     }
@@ -352,6 +385,7 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
         // The block's turns run with the active carriers' lanes enabled and NO per-lane decision while every one of them can
         // take its strobes (one wavefront-uniform branch per turn: carriers of a wavefront move in step unless their clocks
         // differ by more than three chunks); what is left of the block when one cannot is done lane by lane.
+        fetch();                                             // (what was read ahead before a ring move, or by a carrier that waited, is read again)
         int turn = 0;
         const int first_active = __ffsll((unsigned long long)__ballot(active)) - 1;
         auto block = [&](auto slow) {

@@ -7,6 +7,8 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k(float *out, int iters, float a, float b)
 {
     float x = (float)threadIdx.x, y = a;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 xp = {x, y}, yp = {a, b}, zp = {b, a};
     __shared__ float sm[256];
     sm[threadIdx.x] = 0.f;
     __syncthreads();
@@ -21,10 +23,14 @@ __global__ __launch_bounds__(64) void k(float *out, int iters, float a, float b)
             if (MODE == 4) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(x) : "v"(y), "v"(b) : "vcc");
             if (MODE == 5) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(idx * 4) : "memory");
             if (MODE == 7) asm volatile("v_add_u32 %0, %0, %1" : "+v"(idx) : "v"(idx));
+            if (MODE == 9) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(xp) : "v"(yp));
+            if (MODE == 10) asm volatile("v_pk_fma_f32 %0, %0, %1, %1\n\tv_pk_fma_f32 %2, %2, %1, %1" : "+v"(xp), "+v"(zp) : "v"(yp));   // two independent chains
+            if (MODE == 11) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(xp) : "v"(yp));
+            if (MODE == 12) asm volatile("v_pk_mul_f32 %0, %1, %1\n\tv_mul_f32 %2, %2, %3" : "=v"(xp), "+v"(yp), "+v"(x) : "v"(y));      // packed and plain, independent
             if (MODE == 8) asm volatile("v_floor_f32 %0, %0\n\tv_cvt_i32_f32 %0, %0\n\tv_cvt_f32_i32 %0, %0" : "+v"(x));
         }
     }
-    out[blockIdx.x * 64 + threadIdx.x] = x + (float)idx;
+    out[blockIdx.x * 64 + threadIdx.x] = x + (float)idx + xp.x + xp.y + zp.x + zp.y;
 }
 template <int MODE>
 void run(const char *name, int per_iter)
@@ -55,5 +61,9 @@ int main()
     run<5>("ds_read_b32 + wait", 1);
     run<7>("dependent v_add_u32", 1);
     run<8>("v_floor + v_cvt_i32 + v_cvt_f32", 3);
+    run<9>("dependent v_pk_mul_f32", 1);
+    run<10>("two independent v_pk_fma_f32 chains", 2);
+    run<11>("dependent v_pk_add_f32", 1);
+    run<12>("v_pk_mul_f32 + v_mul_f32, independent", 2);
     return 0;
 }
