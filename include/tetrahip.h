@@ -79,7 +79,7 @@ typedef struct tdm_plan_info {
     int32_t q;            /* decimation factor actually applied (1 = none) */
     int32_t sps;          /* int(rate_dec / 18000) */
     int32_t phase_step;   /* max(1, sps // 8) */
-    int32_t max_soft;     /* capacity per carrier of the soft-symbol output */
+    int32_t max_soft;     /* capacity per carrier of the soft-symbol output (TDM_MODE_TETRA_GARDNER: room for a symbol clock 2 % fast) */
     int32_t lpf_applied;  /* 0 when n_dec <= 15 (reference falls back to unfiltered) */
     int32_t in_fmt;
     int32_t mode;

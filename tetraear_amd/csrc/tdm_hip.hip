@@ -686,7 +686,9 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         };
         for (int v = 0; v < kRrcPerThread; ++v) clock((double)(256 * (v >> 2) + kRrcRun * (v & 3)), tp.ev_c[v], tp.ev_s[v]);
         clock((double)kRrcTile, tp.tile_c, tp.tile_s);
-        tp.max_soft = (int32_t)(n_samples / sps) + 4;
+        // capacity of a carrier's output row: the feed-forward receiver emits the nominal count; the Gardner loop follows the
+        // carrier's own symbol clock, so its rows leave room for a clock 2 % fast
+        tp.max_soft = mode == TDM_MODE_TETRA_GARDNER ? (int32_t)(1.02 * (double)n_samples / sps) + 8 : (int32_t)(n_samples / sps) + 4;
         for (size_t i = 0; i < h.size(); ++i) tp.taps[i] = (float)h[i];
         {
             // the matched filter's constant operands, lane by lane (every carrier of every launch reads the same 4-6 KB)
