@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
 
 // ---- the loop ---------------------------------------------------------------------------------------------------------
 // FOUR LANES PER CARRIER: lane (s, c) of a carrier's quad forms component c (re / im) of strobe s (on time / mid-symbol) --
-// its own four ring reads, its own Lagrange weights, four dependent multiply-adds -- and the detector's two sums over the
+// its own four ring reads, its own Lagrange weights (packed, two at a time), its four taps -- and the detector's two sums over the
 // quad travel by DPP (no LDS, no cross-lane latency beyond the instruction itself).  The loop's time is the length of ONE
 // symbol's dependent chain times the symbols of a carrier, whatever the number of carriers (every wavefront has a SIMD to
 // itself up to 16 384 carriers), so the lanes are spent on shortening that chain: one lane per carrier (both strobes, both
