@@ -189,3 +189,44 @@ def test_gpu_gardner_short_rows_silence_and_capacity():
             assert abs(int(ns[r]) - len(info["t"])) <= 1, (n, r, ns[r], len(info["t"]))
             m = min(max(int(ns[r]) - 1, 0), len(ref_hard))
             assert int(np.sum(hard[r, :m] != ref_hard[:m])) <= (1 if m > 200 else 0), (n, r)
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_fused_kernel_agrees_with_the_three_launches():
+    """the default path (matched filter by producer wavefronts inside the loop's workgroup, filter output in LDS only) against
+    the three-launch path (k_tetra_mf -> HBM -> loop; TDM_GARDNER_FUSED=0) on the same batch: the same symbol counts and
+    decisions, soft symbols within fp32 rounding -- at every tap count a plan can have (3..8 samples per symbol), with rows
+    that are no multiple of a wavefront's sixteen carriers and a pitch that is not the row length"""
+    import os
+    from tetraear_amd._lib import MODE_TETRA_GARDNER, check, ptr
+    from tetraear_amd.batch import BatchDemodulator
+    for fs, n in ((54000.0, 5000), (72000.0, 8192), (75000.0, 6001), (90000.0, 7000), (108000.0, 9000), (126000.0, 8000), (144000.0, 12000)):
+        rows, pitch = 21, n + 5
+        xs = [_gardner_case(n, fs, 300 + r, 0.04 * r - 0.4, float(r * 9 - 90), 22.0, float((r % 5) - 2) * 150.0)[0] for r in range(rows)]
+        buf = np.full((rows, pitch), 3.0 - 2.0j, dtype=np.complex64)
+        for r in range(rows):
+            buf[r, :n] = xs[r]
+        outs = []
+        for fused in ("1", "0"):
+            os.environ["TDM_GARDNER_FUSED"] = fused
+            try:
+                bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+                ms = bd.info.max_soft
+                hard = np.zeros((rows, ms), np.uint8)
+                soft = np.zeros((rows, ms), np.complex64)
+                ns = np.zeros(rows, np.int32)
+                tm = np.zeros(rows, np.int32)
+                check(bd.lib.tdm_process(bd.handle, ptr(buf), pitch, None, None, ptr(hard), ptr(soft), ptr(ns), ptr(tm), None))
+                bd.close()
+            finally:
+                del os.environ["TDM_GARDNER_FUSED"]
+            outs.append((hard, soft, ns, tm))
+        (h1, s1, n1, t1), (h0, s0, n0, t0) = outs
+        assert np.array_equal(n1, n0), (fs, n1, n0)
+        assert np.array_equal(t1, t0)
+        for r in range(rows):
+            k = int(n1[r])
+            assert k > 0.9 * n / (fs / 18000.0) - 10
+            assert np.array_equal(h1[r, :k - 1], h0[r, :k - 1]), (fs, r)
+            scale = float(np.max(np.abs(s0[r, :k])))
+            assert float(np.max(np.abs(s1[r, :k] - s0[r, :k]))) <= 2e-6 * scale, (fs, r)

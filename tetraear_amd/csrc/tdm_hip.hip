@@ -817,12 +817,21 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
             // matched filter -> HBM -> Gardner loop, one lane per carrier -> decisions (tetra_gardner_kernels.hpp)
             // (TDM_GARDNER_STAGES: bit mask of the launches to make -- 1 matched filter, 2 loop, 4 decisions; profiling only)
             static const int stages = [] { const char *e = std::getenv("TDM_GARDNER_STAGES"); return e ? std::atoi(e) : 7; }();
-            if (stages & 1) {
+            // the matched filter and the loop in ONE kernel (the filter output stays in LDS); TDM_GARDNER_FUSED=0 (read at every
+            // call: tests switch it) or a stage mask: the three launches with the filter output in HBM
+            const char *fe = std::getenv("TDM_GARDNER_FUSED");
+            const bool fused = stages == 7 && !(fe && std::atoi(fe) == 0);
+            if (fused) {
+                HipBackend::Scope s(be, ST_TETRA_LOOP);
+                if (!tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream))
+                    return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
+            }
+            if (!fused && (stages & 1)) {
                 HipBackend::Scope s(be, ST_TETRA_MF);
                 if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))
                     return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
             }
-            if (stages & 2) {
+            if (!fused && (stages & 2)) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 tetra_gardner_loop_launch(tp, plan->rows, plan->d_gy, plan->gy_pitch, (float2 *)soft, n_soft, best_phase, be.stream);
             }

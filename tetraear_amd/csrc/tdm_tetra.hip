@@ -41,17 +41,35 @@ bool tetra_mf_launch(const TetraParams &tp, int rows, const float2 *x, int64_t i
     }
 }
 
-void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y, int64_t y_pitch, float2 *soft, int32_t *n_soft,
-                               int32_t *timing_milli, hipStream_t stream)
+static GardnerConsts gardner_gains()
 {
     // loop filter gains of the definition (oracle/tetra_np.py demod_gardner: noise bandwidth 1 % of the symbol rate,
-    // damping 0.7071, detector gain 2.7 per symbol; Rice, Digital Communications, eq. C.61)
+    // damping 0.7071, detector gain 2.7 per symbol; Rice, Digital Communications, eq. C.61); x 100: see GardnerConsts
     const double bn_t = 0.01, zeta = 0.7071, kp = 2.7;
     const double th = bn_t / (zeta + 0.25 / zeta);
     const double den = 1.0 + 2.0 * zeta * th + th * th;
-    GardnerConsts G{(float)(100.0 * 4.0 * zeta * th / den / kp), (float)(100.0 * 4.0 * th * th / den / kp)};   // (x 100: see GardnerConsts)
-    hipLaunchKernelGGL(k_tetra_gardner, dim3((unsigned)((rows + kGQuads - 1) / kGQuads)), dim3(64), 0, stream, y, y_pitch, tp, G, rows,
+    return GardnerConsts{(float)(100.0 * 4.0 * zeta * th / den / kp), (float)(100.0 * 4.0 * th * th / den / kp)};
+}
+
+void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y, int64_t y_pitch, float2 *soft, int32_t *n_soft,
+                               int32_t *timing_milli, hipStream_t stream)
+{
+    const GardnerConsts G = gardner_gains();
+    hipLaunchKernelGGL(k_tetra_gardner<0>, dim3((unsigned)((rows + kGQuads - 1) / kGQuads)), dim3(64), 0, stream, y, y_pitch, tp, G, rows,
                        soft, n_soft, timing_milli);
+}
+
+bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
+                                int32_t *timing_milli, hipStream_t stream)
+{
+    const GardnerConsts G = gardner_gains();
+    const dim3 grid((unsigned)((rows + kGQuads - 1) / kGQuads)), block(64 * (1 + kGProducers));
+    switch (tp.ntaps) {
+#define TDM_GF_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_gardner<NT>), grid, block, 0, stream, x, in_stride, tp, G, rows, soft, n_soft, timing_milli); return true;
+        TDM_GF_CASE(17) TDM_GF_CASE(25) TDM_GF_CASE(33) TDM_GF_CASE(35) TDM_GF_CASE(41) TDM_GF_CASE(49) TDM_GF_CASE(57) TDM_GF_CASE(65)
+#undef TDM_GF_CASE
+    default: return false;
+    }
 }
 
 void tetra_decide_launch(const TetraParams &tp, int rows, const float2 *soft, const int32_t *n_soft, uint8_t *hard, double *min_margin,

@@ -174,11 +174,21 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
 // itself up to 16 384 carriers), so the lanes are spent on shortening that chain: one lane per carrier (both strobes, both
 // components and eight ring reads in every lane: ~135 instructions a turn, 64 carriers and 131 KB of ring per wavefront)
 // took 2.92 ms for 4096 x 32 768; this one 1.37 ms (the steps in between: head of this file).
-constexpr int kGChunk = 64, kGChunks = 4, kGRing = kGChunks * kGChunk;
+constexpr int kGChunk = 64, kGChunks = 4;    // the loop works inside four resident chunks of 64 samples
 constexpr int kGQuads = 16;                  // carriers per wavefront
-constexpr int kGPitch = kGRing + 3;          // LDS slots per carrier: the ring and its first three slots once more behind it, so that
-                                             // a lane's four taps are four CONSECUTIVE slots wherever the window starts (odd: rows on different banks)
-static_assert((kGRing & (kGRing - 1)) == 0, "ring index by mask");
+// LDS slots per carrier: the ring (a power of two: index by mask) and its first three slots once more behind it, so that a
+// lane's four taps are four CONSECUTIVE slots wherever the window starts (odd pitch: rows on different banks).  The loop fed
+// from HBM keeps exactly the four chunks; the loop fed by the matched-filter wavefronts of its own workgroup (below) eight:
+// four for the loop, four the producers may fill ahead.
+template <bool FUSED> struct GardnerRing {
+    static constexpr int chunks = FUSED ? 8 : kGChunks, slots = chunks * kGChunk, pitch = slots + 3;
+};
+constexpr int kGProducers = 2;               // matched-filter wavefronts of the fused kernel: eight carriers each
+constexpr int kGQuota = 2;                   // chunks a producer makes between two hand-overs (a block of 16 symbols uses sps / 4)
+template <int NT> struct GardnerWindow {     // a producer's input window per carrier and chunk
+    static constexpr int H = (NT - 1) / 2, W = kGChunk + NT - 1, pitch = W + 4, pairs = W / 2;
+    static constexpr int loads = (8 * pairs + 63) / 64;
+};
 
 struct GardnerConsts {
     float k1, k2;      // loop filter gains (oracle/tetra_np.py demod_gardner: Rice eq. C.61, detector gain 2.7, bn_t 0.01, zeta 0.7071)
@@ -195,12 +205,115 @@ constexpr int kQuadMidStrobe = 0xEE;         // [2, 3, 2, 3]
 constexpr int kQuadFirst = 0x00;             // [0, 0, 0, 0]
 constexpr int kQuadSymbolPair = 0x44;        // [0, 1, 0, 1]
 
-__global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__ y, int64_t y_pitch, const TetraParams P,
+// NT = 0: the loop alone, one wavefront per workgroup, fed from the matched filter's output y in HBM (k_tetra_mf before it).
+// NT > 0: FUSED -- the workgroup has two more wavefronts that run the NT-tap matched filter for the loop's sixteen carriers
+// (eight each, a 64-sample chunk at a time, from the raw input x) straight into the LDS ring: the filter output never goes
+// to HBM.  A lone wavefront leaves two thirds of its SIMD's issue slots and the other three SIMDs of its compute unit idle;
+// the producers' 330 instructions per chunk fit there many times over.  Hand-over at the loop's block boundaries through
+// ONE workgroup barrier per block (no polling): the producers publish how many chunks are complete, the loop how far it has
+// moved on; every wavefront passes the same barriers and leaves after the one at which `done` was set.
+template <int NT>
+__global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_gardner(const float2 *__restrict__ y, int64_t y_pitch, const TetraParams P,
                                                       const GardnerConsts G, int rows, float2 *__restrict__ soft,
                                                       int32_t *__restrict__ n_soft, int32_t *__restrict__ timing_milli)
 {
-    __shared__ float2 ring[kGQuads * kGPitch];      // sample g of a carrier in slot g mod 256 of its row (33 KB)
-    const int lane = threadIdx.x, quad = lane >> 2, s = (lane >> 1) & 1, c = lane & 1;
+    constexpr bool FUSED = NT > 0;
+    constexpr int kGRing = GardnerRing<FUSED>::slots, kGPitch = GardnerRing<FUSED>::pitch;
+    __shared__ float2 ring[kGQuads * kGPitch];      // sample g of a carrier in slot g mod kGRing of its row (33 KB; fused: 66 KB)
+    __shared__ __attribute__((aligned(16))) float2 xwin[FUSED ? kGProducers * 8 * GardnerWindow<FUSED ? NT : 1>::pitch : 1];
+    __shared__ int sh_prod[kGProducers], sh_c0, sh_done;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (a clamped pair at the end of an odd-length row starts on an odd sample)
+    const int lane = threadIdx.x & 63;
+    if constexpr (FUSED) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        if (wave > 0) {
+            // ---- a producer: carriers 8 (wave - 1) .. + 7 of the workgroup; lane = (carrier j, group of eight outputs gI)
+            typedef GardnerWindow<FUSED ? NT : 1> GW;
+            const int n = P.n, j = lane >> 3, gI = lane & 7, car0 = 8 * (wave - 1);
+            float2 *xw = xwin + (wave - 1) * 8 * GW::pitch;
+            const float2 *xrow[GW::loads];              // this lane's pair of every load, in chunk 0's window
+            int xcar[GW::loads], xpr[GW::loads];
+#pragma unroll
+            for (int k = 0; k < GW::loads; ++k) {
+                const int f = min(lane + 64 * k, 8 * GW::pairs - 1);
+                xcar[k] = f / GW::pairs;
+                xpr[k] = f - xcar[k] * GW::pairs;
+                xrow[k] = y + (int64_t)min((int)blockIdx.x * kGQuads + car0 + xcar[k], rows - 1) * y_pitch + 2 * xpr[k] - GW::H;
+            }
+            float2 *myring = ring + (car0 + j) * kGPitch;
+            auto produce = [&](int cn) {
+                const int g0 = kGChunk * cn - GW::H;            // the window's first sample
+                if (kGChunk * cn >= n) {                        // past the row: zeros
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) myring[((kGChunk * cn + 8 * gI) & (kGRing - 1)) + o] = make_float2(0.f, 0.f);
+                } else {
+                    // window: HBM -> registers -> this wavefront's LDS rows (nobody else reads them: no barrier, only the wait)
+                    if (g0 >= 0 && g0 + GW::W <= n) {
+                        f32x4 pf[GW::loads];
+#pragma unroll
+                        for (int k = 0; k < GW::loads; ++k) pf[k] = __builtin_nontemporal_load((const f32x4_a8 *)(xrow[k] + kGChunk * cn));
+#pragma unroll
+                        for (int k = 0; k < GW::loads; ++k)
+                            if (k < GW::loads - 1 || lane + 64 * k < 8 * GW::pairs) *(f32x4 *)(xw + xcar[k] * GW::pitch + 2 * xpr[k]) = pf[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < GW::loads; ++k) {
+                            const int ga = g0 + 2 * xpr[k];
+                            const float2 *rowp = xrow[k] - (2 * xpr[k] - GW::H);     // the carrier's sample 0
+                            const float2 a = rowp[min(max(ga, 0), n - 1)], b = rowp[min(max(ga + 1, 0), n - 1)];
+                            if (k < GW::loads - 1 || lane + 64 * k < 8 * GW::pairs) {
+                                float2 *d = xw + xcar[k] * GW::pitch + 2 * xpr[k];
+                                d[0] = (ga >= 0 && ga < n) ? a : make_float2(0.f, 0.f);
+                                d[1] = (ga + 1 >= 0 && ga + 1 < n) ? b : make_float2(0.f, 0.f);
+                            }
+                        }
+                    }
+                    // (the same wavefront reads what it wrote: LDS operations of a wavefront are served in order)
+                    // eight consecutive outputs from the 8 + NT - 1 samples under them (as k_tetra_mf), taps in scalar registers
+                    f32x2 w[8 + NT - 1];
+                    const float2 *pw = xw + j * GW::pitch + 8 * gI;
+#pragma unroll
+                    for (int i = 0; i < 8 + NT - 1; ++i) {
+                        f32x2 v = *(const f32x2 *)(pw + i);
+                        asm volatile("" : "+v"(v));
+                        w[i] = v;
+                    }
+                    f32x2 acc[8];
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) acc[o] = f32x2{0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float h = P.taps[t];
+#pragma unroll
+                        for (int o = 0; o < 8; ++o) acc[o] = __builtin_elementwise_fma(w[o + t], f32x2{h, h}, acc[o]);
+                    }
+                    const int gs = kGChunk * cn + 8 * gI;
+                    float2 *d = myring + (gs & (kGRing - 1));
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        const float2 v = gs + o < n ? make_float2(acc[o].x, acc[o].y) : make_float2(0.f, 0.f);
+                        d[o] = v;
+                        if (o < 3 && (gs & (kGRing - 1)) == 0) d[kGRing + o] = v;    // slots 0..2 once more behind the ring
+                    }
+                }
+            };
+            int next = 0;
+            for (; next < GardnerRing<true>::chunks; ++next) produce(next);
+            if (lane == 0) sh_prod[wave - 1] = next;
+            __syncthreads();                                    // the first hand-over: eight chunks
+            for (;;) {
+                if (*(volatile int *)&sh_done) break;
+                const int c0_seen = *(volatile int *)&sh_c0;    // (possibly the value of the hand-over before: it only grows)
+                for (int made = 0; made < kGQuota && next <= c0_seen + GardnerRing<true>::chunks - 1; ++made, ++next) produce(next);
+                if (lane == 0) sh_prod[wave - 1] = next;
+                __syncthreads();
+            }
+            return;
+        }
+    }
+    const int quad = lane >> 2, s = (lane >> 1) & 1, c = lane & 1;
     const int row = min((int)blockIdx.x * kGQuads + quad, rows - 1);
     const bool mine = (int)blockIdx.x * kGQuads + quad < rows;
     const int n = P.n;
@@ -212,9 +325,6 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
     char *const wg_soft = (char *)(soft + (int64_t)blockIdx.x * kGQuads * P.max_soft);
     const uint32_t off0 = (uint32_t)quad * (uint32_t)P.max_soft * 8u + 4u * (uint32_t)c;
     uint32_t off = off0;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (a clamped pair at the end of an odd-length row starts on an odd sample)
     // ---- cooperative chunk moves: chunk cn = samples [64 cn, 64 cn + 64) of every carrier of the wavefront.  One 16-byte load
     // fetches two samples; lanes 0..31 serve carrier 2 q, lanes 32..63 carrier 2 q + 1 (rows are 16-byte aligned: even pitch)
     f32x4 pf[kGQuads / 2];
@@ -259,11 +369,13 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
             }
         }
     };
-#pragma unroll 1
-    for (int cn = 0; cn < kGChunks; ++cn) { request(cn); land(cn); }
     int c0 = 0;                                     // oldest resident chunk: chunks c0 .. c0 + kGChunks - 1 are in the ring
-    request(kGChunks);                              // in flight while the first symbols are formed
-    __syncthreads();
+    if constexpr (!FUSED) {
+#pragma unroll 1
+        for (int cn = 0; cn < kGChunks; ++cn) { request(cn); land(cn); }
+        request(kGChunks);                          // in flight while the first symbols are formed
+        __syncthreads();
+    }
     // ---- per-carrier loop state (oracle/tetra_np.py demod_gardner), the same in the four lanes of a quad
     // the symbol instant t = m + mu, whole samples and a fraction in [0, 1): integer and fp32 arithmetic only in the loop's
     // dependent chain (an fp32 t would be good to 4e-3 samples at the end of a 32 768-sample chunk, an fp64 t puts a dozen
@@ -361,6 +473,12 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
     };
     auto in_chunk = [&](int mm, float uu) { return mm < m_end || (mm == m_end && uu == 0.f); };
     bool active = mine && in_chunk(m, mu) && P.max_soft > 0;
+    bool done = !__any(active);
+    if constexpr (FUSED) {
+        if (lane == 0) { sh_c0 = 0; sh_done = done ? 1 : 0; }
+        __syncthreads();                            // the first hand-over: the producers have made the ring's eight chunks
+    }
+    int produced = GardnerRing<true>::chunks;
     aim(std::true_type{}, m, mu - half_lane);       // the first symbol's strobes (its samples lie in the first chunks: m = 1 + floor(sps))
     if (active) {
         symbol(std::true_type{}, std::true_type{}, 0);
@@ -371,11 +489,10 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
     // settled between blocks (a carrier outside the resident chunks simply waits out the turn).
     constexpr int kGBlock = 16;
     const int max_blocks = (4 * P.max_soft + 64) / kGBlock;   // (bounded whatever the input: every turn advances the slowest active carrier)
-    for (int blk = 0; blk < max_blocks; ++blk) {
+    for (int blk = 0; !done; ++blk) {
         const int k = (int)((off - off0) >> 3);
         const bool corner = m == m_end && mu == 0.f;          // t = n - 3 exactly: the last instant inside the chunk
         active = mine && (m < m_end || corner) && k < P.max_soft;
-        if (!__any(active)) break;
         // a carrier takes its strobes when the samples both of them can touch lie in the resident chunks -- m - back >= 64 c0
         // (nothing lies before sample 0; settled here for the whole block: m does not go back in a loop that works) and
         // m + 2 < 64 (c0 + 4) -- and m is inside the chunk: per turn ONE comparison, m < hi_v; one that has run ahead of the
@@ -410,15 +527,33 @@ __global__ __launch_bounds__(64) void k_tetra_gardner(const float2 *__restrict__
         else block(std::false_type{});
         // the ring moves on while no active carrier needs its oldest chunk any more (wavefront-uniform votes)
         active = mine && in_chunk(m, mu) && (int)((off - off0) >> 3) < P.max_soft;
-#pragma unroll 1
-        for (int hop = 0; hop < 4; ++hop) {
-            const bool can_drop = !active || (m - back) >= kGChunk * (c0 + 1);
-            if (!(__all(can_drop) && __any(active))) break;
-            __syncthreads();                         // (one wavefront: orders the ring reads above against the writes below)
-            land(c0 + kGChunks);                     // into the slots chunk c0 held
-            ++c0;
-            request(c0 + kGChunks);
+        done = !__any(active) || blk + 1 >= max_blocks;
+        if constexpr (FUSED) {
+            // hand-over: ONE barrier per block with the producers; behind it their counts of complete chunks are valid, and
+            // `done`, set in front of it, is what every wavefront of the workgroup leaves on
+            if (lane == 0 && done) sh_done = 1;
             __syncthreads();
+            if (!done) {
+                produced = min(*(volatile int *)&sh_prod[0], *(volatile int *)&sh_prod[1]);
+#pragma unroll 1
+                for (int hop = 0; hop < 4; ++hop) {
+                    const bool can_drop = !active || (m - back) >= kGChunk * (c0 + 1);
+                    if (!__all(can_drop) || produced < c0 + kGChunks + 1) break;
+                    ++c0;                               // (chunk c0 + 4 is complete: the window moves on)
+                }
+                if (lane == 0) sh_c0 = c0;
+            }
+        } else {
+#pragma unroll 1
+            for (int hop = 0; hop < 4 && !done; ++hop) {
+                const bool can_drop = !active || (m - back) >= kGChunk * (c0 + 1);
+                if (!__all(can_drop)) break;
+                __syncthreads();                         // (one wavefront: orders the ring reads above against the writes below)
+                land(c0 + kGChunks);                     // into the slots chunk c0 held
+                ++c0;
+                request(c0 + kGChunks);
+                __syncthreads();
+            }
         }
     }
     const int k = (int)((off - off0) >> 3);
