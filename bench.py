@@ -933,7 +933,7 @@ def leg_gardner(rows, base, chk, steps):
         check = {"against": "oracle/tetra_np.py demod_gardner (fp64 loop), pinned by tests/golden/make_bench_checks.py",
                  "worst_fraction_of_differing_decisions": worst, "rows_equal_their_prototype": bool(same),
                  "status": "decisions match the definition's loop (<= 1e-3 differing, count within one)" if (ok and same) else "DIFFERS from the definition"}
-    return {"what": "TDM_MODE_TETRA_GARDNER: matched filter -> HBM -> Gardner TED + PI loop + Farrow, four lanes per carrier -> decisions (3 launches)",
+    return {"what": "TDM_MODE_TETRA_GARDNER: matched filter (producer wavefronts) -> LDS ring -> Gardner TED + PI loop + Farrow, four lanes per carrier, one kernel -> decisions (2 launches)",
 
             "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s", "steps": steps, "stage_ms_per_launch": st,
             "output_check": check}

@@ -4,20 +4,25 @@
 //
 // The loop is a nonlinear recurrence over a carrier's symbols (every symbol instant depends on the errors of all symbols
 // before it), so it cannot be tiled over time like the feed-forward receiver of tetra_kernels.hpp: the parallel axis is
-// the CARRIER.  Three kernels:
-//   k_tetra_mf       matched filter, LDS-tiled sliding window, fp32, output to HBM (one workgroup per 2048 outputs)
-//   k_tetra_gardner  FOUR LANES PER CARRIER walk its symbols (lane = strobe x component); a wavefront's 16 carriers share
-//                    an LDS ring of matched-filter samples (four 64-sample chunks per carrier, refilled cooperatively
-//                    with coalesced loads one chunk ahead), so that the loop's dependent chain sees LDS latency, not HBM
-//                    latency
+// the CARRIER.  Kernels:
+//   k_tetra_gardner<NT>  (the default) one workgroup = THREE wavefronts for sixteen carriers: the LOOP wavefront, FOUR LANES
+//                    PER CARRIER (lane = strobe x component), walks the symbols out of an LDS ring of matched-filter
+//                    samples; two PRODUCER wavefronts run the NT-tap RRC matched filter for eight carriers each, a
+//                    64-sample chunk at a time, from the raw input straight into that ring (the filter output never goes to
+//                    HBM); hand-over once per block of 16 symbols through one workgroup barrier
+//   k_tetra_mf       the matched filter alone, LDS-tiled sliding window, fp32, output to HBM (one workgroup per 2048
+//                    outputs): the RRC stage as its own kernel (tdm_plan_rrc_filter) and the first of the three launches
+//   k_tetra_gardner<0>   the loop alone, fed from k_tetra_mf's output in HBM (TDM_GARDNER_FUSED=0: three launches)
 //   k_tetra_decide   differential products, 4th-power carrier-offset estimate, quadrant decisions, margin (one workgroup
 //                    per carrier)
 // It is the slower receiver by construction and exists because the north-star names it: tests compare it with the fp64
-// definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768): matched filter 0.37 ms
-// (5.8 TB/s), loop 1.37 ms, decisions 0.10 ms.  The loop's time does not depend on the number of carriers up to 16 384
-// (one wavefront per SIMD): it is 8190 symbols x the ~165 ns ONE symbol's chain of ~40 vector instructions takes in a
+// definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768): fused filter + loop
+// 1.37 ms, decisions 0.08 ms = 1.47 ms per batch (three launches: matched filter 0.37 ms at 5.8 TB/s, loop 1.37, decisions
+// 0.10 = 1.85).  The loop's time does not depend on the number of carriers up to 16 384
+// (one loop wavefront per compute unit): it is 8190 symbols x the ~165 ns ONE symbol's chain of ~40 vector instructions takes in a
 // wavefront that has its SIMD to itself (tools/harness/ubench_chain.hip: a lone wavefront issues one vector instruction
-// per 3.4 ns, a dependent multiply-add takes 4.6 ns, an LDS round trip 23 ns).  History of that number: one lane per carrier
+// per 3.4 ns, a dependent multiply-add takes 4.6 ns, an LDS round trip 23 ns) -- which is also why the producers are free:
+// the loop wavefront uses a third of ONE of its compute unit's four SIMDs.  History of that number: one lane per carrier
 // 2.92 ms (135 instructions a turn); four lanes per carrier 2.31; first symbol peeled, one-compare window test 2.18; the rare
 // work (capacity, middle symbol, clamp) in a second copy of the block, cross-lane operands folded into the arithmetic (DPP),
 // all four lanes store 1.83; straight-line turns behind ONE wavefront-uniform branch 1.76; ring moves without clamps and
