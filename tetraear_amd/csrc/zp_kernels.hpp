@@ -1052,7 +1052,11 @@ TDM_HD uint8_t dqpsk_decide(double cr, double ci, double pr, double pi_, double 
     const double br = pr, bi = -pi_;
     const double dr = sub_rn(mul_rn(cr, br), mul_rn(ci, bi));
     const double di = add_rn(mul_rn(cr, bi), mul_rn(ci, br));
+#ifdef TDM_FINISH_NOATAN   // experiment: what the exact arctangent costs the finish kernel (wrong results, timing only)
+    const double ph = di + dr;
+#else
     const double ph = atan2(di, dr);
+#endif
     const double t0 = -5 * M_PI / 8, t1 = -3 * M_PI / 8, t2 = 3 * M_PI / 8, t3 = 5 * M_PI / 8;
     uint8_t sym;
     if (ph < t0) sym = 3;
