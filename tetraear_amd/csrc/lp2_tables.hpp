@@ -20,7 +20,10 @@ namespace tdm {
 #define TDM_LP2_LA 16
 #endif
 constexpr int kLp2La = TDM_LP2_LA;            // samples per lane (16; 8: see above)
-constexpr int kLp2Waves = 64 / kLp2La;        // wavefronts per workgroup: the span is 4096 positions = 64 KB of staging
+#ifndef TDM_LP2_WAVES
+#define TDM_LP2_WAVES (64 / TDM_LP2_LA)
+#endif
+constexpr int kLp2Waves = TDM_LP2_WAVES;      // wavefronts per workgroup: the span is 4096 positions = 64 KB of staging (8 with 16-sample lanes: 8192, 128 KB)
 constexpr int kLp2GBits = 9;                  // item word 0: group in the span (< 512) | direction << 9 | pair mask << 10
 constexpr int kLp2Lanes = kLp2Waves * kWave;
 constexpr int kLp2Span = kLp2Lanes * kLp2La;   // positions a workgroup covers (chunk + both halos)
