@@ -821,17 +821,18 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
             // call: tests switch it) or a stage mask: the three launches with the filter output in HBM
             const char *fe = std::getenv("TDM_GARDNER_FUSED");
             const bool fused = stages == 7 && !(fe && std::atoi(fe) == 0);
-            if (fused) {
+            bool fused_done = false;
+            if (fused && tetra_gardner_fused_available(tp.ntaps)) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
-                if (!tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream))
-                    return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
+                fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream);
             }
-            if (!fused && (stages & 1)) {
+            const bool three = !fused_done;   // (no fused kernel for this tap count: more than 5 samples per symbol)
+            if (three && (stages & 1)) {
                 HipBackend::Scope s(be, ST_TETRA_MF);
                 if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))
                     return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
             }
-            if (!fused && (stages & 2)) {
+            if (three && (stages & 2)) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 tetra_gardner_loop_launch(tp, plan->rows, plan->d_gy, plan->gy_pitch, (float2 *)soft, n_soft, best_phase, be.stream);
             }

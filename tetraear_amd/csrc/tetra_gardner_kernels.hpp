@@ -16,9 +16,12 @@
 //   k_tetra_decide   differential products, 4th-power carrier-offset estimate, quadrant decisions, margin (one workgroup
 //                    per carrier)
 // It is the slower receiver by construction and exists because the north-star names it: tests compare it with the fp64
-// definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768): fused filter + loop
-// 1.37 ms, decisions 0.08 ms = 1.47 ms per batch (three launches: matched filter 0.37 ms at 5.8 TB/s, loop 1.37, decisions
-// 0.10 = 1.85).  The loop's time does not depend on the number of carriers up to 16 384
+// definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768 at 4 samples per symbol):
+// fused filter + loop 1.28 ms, decisions 0.08 ms = 1.37 ms per batch (three launches: matched filter 0.37 ms at 5.8 TB/s, loop
+// 1.37, decisions 0.10 = 1.85).  The fused kernel serves up to 5 samples per symbol (41 taps: 3 / 4 / 5 samples per symbol
+// 1.62 / 1.28 / 1.34 ms against 2.07 / 1.74 / 1.6 for filter + loop as two launches); above, the producers would set the pace
+// (a chunk costs them 8 NT multiply-adds per lane while the loop uses chunks up faster: 6 samples per symbol 1.51 against
+// 1.44 ms, 8: 1.93 against 1.31) and the three launches run.  The loop's time does not depend on the number of carriers up to 16 384
 // (one loop wavefront per compute unit): it is 8190 symbols x the ~165 ns ONE symbol's chain of ~40 vector instructions takes in a
 // wavefront that has its SIMD to itself (tools/harness/ubench_chain.hip: a lone wavefront issues one vector instruction
 // per 3.4 ns, a dependent multiply-add takes 4.6 ns, an LDS round trip 23 ns) -- which is also why the producers are free:
@@ -27,7 +30,8 @@
 // work (capacity, middle symbol, clamp) in a second copy of the block, cross-lane operands folded into the arithmetic (DPP),
 // all four lanes store 1.83; straight-line turns behind ONE wavefront-uniform branch 1.76; ring moves without clamps and
 // address arithmetic, 16-turn blocks 1.47; weights and taps as packed instructions 1.46 (they sat in the shadow of the ring
-// reads); the next symbol's ring reads issued at the end of the turn (software pipeline) 1.37.
+// reads); the next symbol's ring reads issued at the end of the turn (software pipeline) 1.37; fed by the producers (no ring
+// moves of its own) 1.28.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -191,7 +195,9 @@ template <bool FUSED> struct GardnerRing {
 constexpr int kGProducers = 2;               // matched-filter wavefronts of the fused kernel: eight carriers each
 constexpr int kGQuota = 2;                   // chunks a producer makes between two hand-overs (a block of 16 symbols uses sps / 4)
 template <int NT> struct GardnerWindow {     // a producer's input window per carrier and chunk
-    static constexpr int H = (NT - 1) / 2, W = kGChunk + NT - 1, pitch = W + 4, pairs = W / 2;
+    static constexpr int H = (NT - 1) / 2, W = kGChunk + NT - 1, pairs = W / 2;
+    static constexpr int pitch = W + 2 * (W / 8) + 6;      // two pad slots per eight samples (slot()): a lane's window starts 80 bytes after its neighbour's
+    static constexpr int slot(int s) { return s + 2 * (s >> 3); }
     static constexpr int loads = (8 * pairs + 63) / 64;
 };
 
@@ -227,11 +233,17 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
     __shared__ float2 ring[kGQuads * kGPitch];      // sample g of a carrier in slot g mod kGRing of its row (33 KB; fused: 66 KB)
     __shared__ __attribute__((aligned(16))) float2 xwin[FUSED ? kGProducers * 8 * GardnerWindow<FUSED ? NT : 1>::pitch : 1];
     __shared__ int sh_prod[kGProducers], sh_c0, sh_done;
+    // the producers' taps, in LDS: as kernel arguments they are scalar registers, and a packed multiply-add wants its scalar
+    // operand as an aligned PAIR -- 2 x 65 scalar registers do not exist, and the compiler's spills (two v_readlane and a
+    // wait state per multiply-add) made a 65-tap chunk take 5.5 us instead of 2.  A broadcast 8-byte LDS read per two taps.
+    __shared__ __attribute__((aligned(8))) float taps_s[FUSED ? kRrcMaxTaps + 2 : 2];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (a clamped pair at the end of an odd-length row starts on an odd sample)
     const int lane = threadIdx.x & 63;
     if constexpr (FUSED) {
+        for (int t = threadIdx.x; t < NT + 1; t += 64 * (1 + kGProducers)) taps_s[t] = t < NT ? P.taps[t] : 0.f;
+        __syncthreads();
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
         if (wave > 0) {
             // ---- a producer: carriers 8 (wave - 1) .. + 7 of the workgroup; lane = (carrier j, group of eight outputs gI)
@@ -248,6 +260,17 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
                 xrow[k] = y + (int64_t)min((int)blockIdx.x * kGQuads + car0 + xcar[k], rows - 1) * y_pitch + 2 * xpr[k] - GW::H;
             }
             float2 *myring = ring + (car0 + j) * kGPitch;
+            // the window of the NEXT chunk is requested while this chunk's arithmetic runs (a chunk's 2 us of load latency
+            // would otherwise be paid 512 times in a row: the producers, not the loop, set the pace above 4 samples per symbol)
+            f32x4 pf[GW::loads];
+            auto inside = [&](int cn) { return kGChunk * cn - GW::H >= 0 && kGChunk * cn - GW::H + GW::W <= n; };
+            auto issue = [&](int cn) {
+                if (inside(cn)) {
+#pragma unroll
+                    for (int k = 0; k < GW::loads; ++k) pf[k] = __builtin_nontemporal_load((const f32x4_a8 *)(xrow[k] + kGChunk * cn));
+                }
+            };
+            issue(0);
             auto produce = [&](int cn) {
                 const int g0 = kGChunk * cn - GW::H;            // the window's first sample
                 if (kGChunk * cn >= n) {                        // past the row: zeros
@@ -255,13 +278,10 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
                     for (int o = 0; o < 8; ++o) myring[((kGChunk * cn + 8 * gI) & (kGRing - 1)) + o] = make_float2(0.f, 0.f);
                 } else {
                     // window: HBM -> registers -> this wavefront's LDS rows (nobody else reads them: no barrier, only the wait)
-                    if (g0 >= 0 && g0 + GW::W <= n) {
-                        f32x4 pf[GW::loads];
-#pragma unroll
-                        for (int k = 0; k < GW::loads; ++k) pf[k] = __builtin_nontemporal_load((const f32x4_a8 *)(xrow[k] + kGChunk * cn));
+                    if (inside(cn)) {
 #pragma unroll
                         for (int k = 0; k < GW::loads; ++k)
-                            if (k < GW::loads - 1 || lane + 64 * k < 8 * GW::pairs) *(f32x4 *)(xw + xcar[k] * GW::pitch + 2 * xpr[k]) = pf[k];
+                            if (k < GW::loads - 1 || lane + 64 * k < 8 * GW::pairs) *(f32x4 *)(xw + xcar[k] * GW::pitch + GW::slot(2 * xpr[k])) = pf[k];
                     } else {
 #pragma unroll
                         for (int k = 0; k < GW::loads; ++k) {
@@ -269,19 +289,20 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
                             const float2 *rowp = xrow[k] - (2 * xpr[k] - GW::H);     // the carrier's sample 0
                             const float2 a = rowp[min(max(ga, 0), n - 1)], b = rowp[min(max(ga + 1, 0), n - 1)];
                             if (k < GW::loads - 1 || lane + 64 * k < 8 * GW::pairs) {
-                                float2 *d = xw + xcar[k] * GW::pitch + 2 * xpr[k];
+                                float2 *d = xw + xcar[k] * GW::pitch + GW::slot(2 * xpr[k]);
                                 d[0] = (ga >= 0 && ga < n) ? a : make_float2(0.f, 0.f);
                                 d[1] = (ga + 1 >= 0 && ga + 1 < n) ? b : make_float2(0.f, 0.f);
                             }
                         }
                     }
+                    issue(cn + 1);
                     // (the same wavefront reads what it wrote: LDS operations of a wavefront are served in order)
                     // eight consecutive outputs from the 8 + NT - 1 samples under them (as k_tetra_mf), taps in scalar registers
                     f32x2 w[8 + NT - 1];
-                    const float2 *pw = xw + j * GW::pitch + 8 * gI;
+                    const float2 *pw = xw + j * GW::pitch + 10 * gI;            // slot(8 gI)
 #pragma unroll
                     for (int i = 0; i < 8 + NT - 1; ++i) {
-                        f32x2 v = *(const f32x2 *)(pw + i);
+                        f32x2 v = *(const f32x2 *)(pw + GW::slot(i));
                         asm volatile("" : "+v"(v));
                         w[i] = v;
                     }
@@ -289,10 +310,14 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
 #pragma unroll
                     for (int o = 0; o < 8; ++o) acc[o] = f32x2{0.f, 0.f};
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const float h = P.taps[t];
+                    for (int t = 0; t < NT; t += 2) {
+                        const f32x2 hp = *(const f32x2 *)(taps_s + t);     // taps t, t + 1 (a zero behind the last)
 #pragma unroll
-                        for (int o = 0; o < 8; ++o) acc[o] = __builtin_elementwise_fma(w[o + t], f32x2{h, h}, acc[o]);
+                        for (int o = 0; o < 8; ++o) acc[o] = __builtin_elementwise_fma(w[o + t], f32x2{hp.x, hp.x}, acc[o]);
+                        if (t + 1 < NT) {
+#pragma unroll
+                            for (int o = 0; o < 8; ++o) acc[o] = __builtin_elementwise_fma(w[o + t + 1], f32x2{hp.y, hp.y}, acc[o]);
+                        }
                     }
                     const int gs = kGChunk * cn + 8 * gI;
                     float2 *d = myring + (gs & (kGRing - 1));
