@@ -19,7 +19,7 @@
 // definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768 at 4 samples per symbol):
 // fused filter + loop 1.28 ms, decisions 0.08 ms = 1.37 ms per batch (three launches: matched filter 0.37 ms at 5.8 TB/s, loop
 // 1.37, decisions 0.10 = 1.85).  The fused kernel serves up to 5 samples per symbol (41 taps: 3 / 4 / 5 samples per symbol
-// 1.62 / 1.28 / 1.34 ms against 2.07 / 1.74 / 1.6 for filter + loop as two launches); above, the producers would set the pace
+// 1.62 / 1.28 / 1.35 ms against 2.07 / 1.74 / 1.57 for filter + loop as two launches); above, the producers would set the pace
 // (a chunk costs them 8 NT multiply-adds per lane while the loop uses chunks up faster: 6 samples per symbol 1.51 against
 // 1.44 ms, 8: 1.93 against 1.31) and the three launches run.  The loop's time does not depend on the number of carriers up to 16 384
 // (one loop wavefront per compute unit): it is 8190 symbols x the ~165 ns ONE symbol's chain of ~40 vector instructions takes in a
