@@ -826,7 +826,7 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream);
             }
-            const bool three = !fused_done;   // (no fused kernel for this tap count: more than 5 samples per symbol)
+            const bool three = !fused_done;   // (TDM_GARDNER_FUSED=0, a stage mask, or no fused kernel for this tap count)
             if (three && (stages & 1)) {
                 HipBackend::Scope s(be, ST_TETRA_MF);
                 if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))

@@ -59,7 +59,7 @@ void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y,
                        soft, n_soft, timing_milli);
 }
 
-bool tetra_gardner_fused_available(int ntaps) { return ntaps == 17 || ntaps == 25 || ntaps == 33 || ntaps == 35 || ntaps == 41; }
+bool tetra_gardner_fused_available(int ntaps) { return ntaps == 17 || ntaps == 25 || ntaps == 33 || ntaps == 35 || ntaps == 41 || ntaps == 49 || ntaps == 57 || ntaps == 65; }
 
 bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
                                 int32_t *timing_milli, hipStream_t stream)
@@ -68,10 +68,7 @@ bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x
     const dim3 grid((unsigned)((rows + kGQuads - 1) / kGQuads)), block(64 * (1 + kGProducers));
     switch (tp.ntaps) {
 #define TDM_GF_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_gardner<NT>), grid, block, 0, stream, x, in_stride, tp, G, rows, soft, n_soft, timing_milli); return true;
-        // (up to 41 taps = 5 samples per symbol: above, the two producers set the pace -- a chunk costs them 8 NT multiply-adds and
-        //  the loop uses chunks up faster -- and the three launches are quicker: 6 samples per symbol 1.51 against 1.53 ms, 8: 1.93
-        //  against 1.39)
-        TDM_GF_CASE(17) TDM_GF_CASE(25) TDM_GF_CASE(33) TDM_GF_CASE(35) TDM_GF_CASE(41)
+        TDM_GF_CASE(17) TDM_GF_CASE(25) TDM_GF_CASE(33) TDM_GF_CASE(35) TDM_GF_CASE(41) TDM_GF_CASE(49) TDM_GF_CASE(57) TDM_GF_CASE(65)
 #undef TDM_GF_CASE
     default: return false;
     }

@@ -18,10 +18,14 @@
 // It is the slower receiver by construction and exists because the north-star names it: tests compare it with the fp64
 // definition, bench.py times it beside the feed-forward receiver.  Measured (MI355X, 4096 x 32 768 at 4 samples per symbol):
 // fused filter + loop 1.28 ms, decisions 0.08 ms = 1.37 ms per batch (three launches: matched filter 0.37 ms at 5.8 TB/s, loop
-// 1.37, decisions 0.10 = 1.85).  The fused kernel serves up to 5 samples per symbol (41 taps: 3 / 4 / 5 samples per symbol
-// 1.62 / 1.28 / 1.35 ms against 2.07 / 1.74 / 1.57 for filter + loop as two launches); above, the producers would set the pace
-// (a chunk costs them 8 NT multiply-adds per lane while the loop uses chunks up faster: 6 samples per symbol 1.51 against
-// 1.44 ms, 8: 1.93 against 1.31) and the three launches run.  The loop's time does not depend on the number of carriers up to 16 384
+// 1.37, decisions 0.10 = 1.85).  Fused filter + loop at 3 / 4 / 5 / 6 / 8 samples per symbol (25 ... 65 taps): 1.65 / 1.28 /
+// 1.14 / 1.13 / 1.17 ms against 2.07 / 1.74 / 1.57 / 1.44 / 1.31 for filter and loop as two launches.  What the producers
+// needed for that (a chunk costs them 8 NT multiply-adds per lane, and at 8 samples per symbol the loop uses up a chunk in
+// 1.4 us): the next window requested during this chunk's arithmetic; taps from LDS as pairs (as scalar kernel arguments
+// they spilled: two v_readlane and a wait state per multiply-add); the multiply-adds written out tap by tap (the compiler
+// walks output by output: dependent, each behind a wait state, every tap first copied into a (h, h) pair); all window
+// reads in flight together (k_tetra_mf's one-wait-per-read is hidden by six other workgroups there, by nobody here).
+// The loop's time does not depend on the number of carriers up to 16 384
 // (one loop wavefront per compute unit): it is 8190 symbols x the ~165 ns ONE symbol's chain of ~40 vector instructions takes in a
 // wavefront that has its SIMD to itself (tools/harness/ubench_chain.hip: a lone wavefront issues one vector instruction
 // per 3.4 ns, a dependent multiply-add takes 4.6 ns, an LDS round trip 23 ns) -- which is also why the producers are free:
@@ -301,23 +305,30 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
                     f32x2 w[8 + NT - 1];
                     const float2 *pw = xw + j * GW::pitch + 10 * gI;            // slot(8 gI)
 #pragma unroll
-                    for (int i = 0; i < 8 + NT - 1; ++i) {
-                        f32x2 v = *(const f32x2 *)(pw + GW::slot(i));
-                        asm volatile("" : "+v"(v));
-                        w[i] = v;
-                    }
-                    f32x2 acc[8];
+                    for (int i = 0; i < 8 + NT - 1; ++i) w[i] = *(const f32x2 *)(pw + GW::slot(i));   // (all reads in flight together:
+                    f32x2 acc[8];                                                                         //  a lone wavefront has nobody to hide a wait per read)
 #pragma unroll
                     for (int o = 0; o < 8; ++o) acc[o] = f32x2{0.f, 0.f};
+                    // Tap by tap, eight INDEPENDENT packed multiply-adds per tap, the tap taken from its half of the pair by the
+                    // instruction's operand select -- written out: left to itself the compiler walks output by output (a chain of
+                    // NT dependent packed multiply-adds, each behind a wait state) and copies every tap into a (h, h) register
+                    // pair first: 5.9 ns per multiply-add instead of under 3.
+                    // (the asm statements keep their place, so the read of the NEXT pair of taps stands in front of this pair's
+                    //  sixteen multiply-adds: its LDS round trip passes behind them)
+                    f32x2 hp = *(const f32x2 *)taps_s;                     // taps t, t + 1 (a zero behind the last)
 #pragma unroll
                     for (int t = 0; t < NT; t += 2) {
-                        const f32x2 hp = *(const f32x2 *)(taps_s + t);     // taps t, t + 1 (a zero behind the last)
+                        f32x2 hn = hp;
+                        if (t + 2 < NT) hn = *(const f32x2 *)(taps_s + t + 2);
 #pragma unroll
-                        for (int o = 0; o < 8; ++o) acc[o] = __builtin_elementwise_fma(w[o + t], f32x2{hp.x, hp.x}, acc[o]);
+                        for (int o = 0; o < 8; ++o)
+                            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[o]) : "v"(w[o + t]), "v"(hp));
                         if (t + 1 < NT) {
 #pragma unroll
-                            for (int o = 0; o < 8; ++o) acc[o] = __builtin_elementwise_fma(w[o + t + 1], f32x2{hp.y, hp.y}, acc[o]);
+                            for (int o = 0; o < 8; ++o)
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc[o]) : "v"(w[o + t + 1]), "v"(hp));
                         }
+                        hp = hn;
                     }
                     const int gs = kGChunk * cn + 8 * gI;
                     float2 *d = myring + (gs & (kGRing - 1));

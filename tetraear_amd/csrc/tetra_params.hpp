@@ -61,7 +61,7 @@ bool tetra_mf_launch(const TetraParams &tp, int rows, const float2 *x, int64_t i
 void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y, int64_t y_pitch, float2 *soft, int32_t *n_soft,
                                int32_t *timing_milli, hipStream_t stream);
 // the matched filter and the loop in ONE kernel (the filter output stays in LDS); false when not instantiated for tp.ntaps
-// (more than 41 taps: the caller makes the three launches)
+// (the caller then makes the three launches)
 bool tetra_gardner_fused_available(int ntaps);
 bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
                                 int32_t *timing_milli, hipStream_t stream);
