@@ -35,7 +35,7 @@
 // all four lanes store 1.83; straight-line turns behind ONE wavefront-uniform branch 1.76; ring moves without clamps and
 // address arithmetic, 16-turn blocks 1.47; weights and taps as packed instructions 1.46 (they sat in the shadow of the ring
 // reads); the next symbol's ring reads issued at the end of the turn (software pipeline) 1.37; fed by the producers (no ring
-// moves of its own) 1.28.
+// moves of its own) 1.28; the strobe and the instant updated side by side in packed instructions 1.25.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -460,6 +460,8 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
     const float c_int = half_lane - sps_f;          // d(strobe position) / d(integrator)
     const float c_err = c_int * G.k2 - gain_t;      // d(strobe position) / d(error)
     const float c_err_t = -sps_f * G.k2 - gain_t;   // the same for the symbol instant itself (lanes s = 0: c_err)
+    // {the lane's strobe, the symbol instant} as pairs: position relative to m = mu + k_base + k_int integ + k_err e
+    const f32x2 k_base = {sps_f - half_lane, sps_f}, k_int = {c_int, -sps_f}, k_err = {c_err, c_err_t};
     // One symbol of one carrier (the quad's four lanes together).  FIRST: no predecessor yet -- no error, nominal period.
     // SLOW: the work only a few turns of a carrier need -- the mid strobe held at sample 1 (first chunk), the middle symbol's
     // instant, the capacity of the output row -- compiled into a second copy of the block that runs when some carrier of
@@ -482,9 +484,8 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
         const float val = acc.x + acc.y;                       // s = 0: the symbol's component c; s = 1: the mid strobe's
         // where the next symbol's strobes lie, up to the error's share: this symbol's instant + sps (1 - integ) for the
         // symbol, half a period (0.5 sps (1 - integ)) earlier for the mid strobe (half_lane: 0 in lanes s = 0)
-        const float base = mu + sps_f;
-        float x = fmaf(c_int, integ, base - half_lane);        // the lane's strobe, relative to m
-        float un = fmaf(-sps_f, integ, base);                  // the instant
+        // (the lane's strobe and the instant side by side in packed instructions: {x, un})
+        f32x2 xu = __builtin_elementwise_fma(k_int, f32x2{integ, integ}, f32x2{mu, mu} + k_base);
         if (!FIRST) {
             // detector e = Re{(s_k - s_k-1) conj(s_k-1/2)} / (running power), right in lane (0, re) of the quad and broadcast from
             // there; loop filter and the next instant in every lane (the cross-lane operands ride on the instructions: DPP)
@@ -495,11 +496,18 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
             q = fmaf(0.99f, q, gardner_quad<kQuadOtherComponent>(v2) + v2);
             const float e = gardner_quad<kQuadFirst>(ee * __builtin_amdgcn_rcpf(fmaxf(q, 1e-10f)));
             // t + sps (1 - (k1 e + integ')), integ' = integ + k2 e: a late strobe makes e positive and shortens the period
-            x = fmaf(c_err, e, x);
-            un = fmaf(c_err_t, e, un);
+            xu = __builtin_elementwise_fma(k_err, f32x2{e, e}, xu);
             integ = fmaf(k2_v, e, integ);
         }
-        aim(slow, m, x);                                       // the next symbol's reads leave here
+        const f32x2 fl = {floorf(xu.x), floorf(xu.y)};
+        const f32x2 fr = xu - fl;                              // {the strobe's fraction, the instant's}
+        {                                                      // the next symbol's reads leave here
+            const int m2 = m + (int)fl.x;
+            // (the mid-symbol strobe is not taken before sample 1: the first chunk's business)
+            pm = SLOW ? max(m2, 1) : m2;
+            pu = (!SLOW || m2 >= 1) ? fr.x : 0.f;
+            fetch();
+        }
         // (all four lanes store: lanes s = 1 their partner's value to their partner's address -- cheaper than masking them out)
         *(float *)(wg_soft + off + 8 * T) = gardner_quad<kQuadSymbolPair>(val);
         if (SLOW) {
@@ -508,9 +516,8 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
             if (k + 1 >= P.max_soft) hi_v = -0x7fffffff;     // the row is full
         }
         prev = val;
-        const float fn = floorf(un);
-        m += (int)fn;
-        mu = un - fn;
+        m += (int)fl.y;
+        mu = fr.y;
     };
     auto in_chunk = [&](int mm, float uu) { return mm < m_end || (mm == m_end && uu == 0.f); };
     bool active = mine && in_chunk(m, mu) && P.max_soft > 0;
