@@ -433,6 +433,34 @@ def test_gpu_wideband_receiver_device_chain():
 
 
 @pytest.mark.gpu
+def test_gpu_wideband_receiver_with_the_gardner_loop():
+    """the chain `north_star` spells out, on the device end to end: wideband stream -> polyphase channeliser -> RRC matched
+    filter -> Gardner timing-error detector + loop -> Farrow -> differential decisions (WidebandReceiver(mode=
+    MODE_TETRA_GARDNER)); every occupied channel gives back its transmitted dibits after the loop's acquisition, and its
+    decisions equal the fp64 definition's loop run on the definition's channeliser output"""
+    from oracle import pfb_np, tetra_np
+    from tetraear_amd._lib import MODE_TETRA_GARDNER
+    from tetraear_amd.wideband import WidebandReceiver
+    M, D, fs, n = 96, 32, 2.4e6, 131072
+    ks = [0, 5, 47, 49, 90]
+    x, dibs = _wideband(n, fs, ks, M, seed0=640)
+    xin = (x / 6).astype(np.complex64)
+    rx = WidebandReceiver(fs, n, M, D, streams=1, fmt="cf32", mode=MODE_TETRA_GARDNER)
+    hard, n_sym, timing, margin = rx.process(xin)
+    rx.close()
+    ref = dict(zip(ks, pfb_np.channelise(xin.astype(np.complex128), M, D, channels=ks)))
+    for k in ks:
+        got = hard[0, k, :n_sym[0, k]]
+        assert n_sym[0, k] > 900
+        m = len(got)
+        errs = min(int(np.sum(got[700:m - 8] != dibs[k][lag + 700:lag + m - 8])) for lag in range(40) if len(dibs[k]) - lag >= m)
+        assert errs == 0, (k, errs)           # (a loop of this bandwidth may need a few hundred symbols from a half-symbol offset)
+        ref_hard, _, info = tetra_np.demod_gardner(ref[k], fs / D)
+        mm = min(m, len(ref_hard))
+        assert abs(m + 1 - len(info["t"])) <= 1 and np.mean(got[:mm] != ref_hard[:mm]) <= 2e-3, k
+
+
+@pytest.mark.gpu
 def test_gpu_channeliser_random_configurations():
     """seeded random (M, D, length, wire format, pitch): channeliser vs the fp64 definition on probe channels
     (tools/sweep_pfb.py runs the same sweep open-ended: 76 115 cases without a mismatch in round 1)"""

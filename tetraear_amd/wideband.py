@@ -21,8 +21,11 @@ class WidebandReceiver:
     """`streams` wideband streams of `n_in` samples at `sample_rate` -> M channels each, spaced
     sample_rate/M and decimated by D (channel rate sample_rate/D), all demodulated per call."""
 
-    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0, slots=1, group=None):
-        """slots = 2: two independent (channel buffer, demodulator plan) pairs, each with its own stream.  Consecutive
+    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0, slots=1, group=None, mode=MODE_TETRA):
+        """mode: MODE_TETRA (feed-forward timing, the default) or MODE_TETRA_GARDNER (Gardner detector + loop) for the channels'
+        demodulation.
+
+        slots = 2: two independent (channel buffer, demodulator plan) pairs, each with its own stream.  Consecutive
         batches go to alternating slots (enqueue(slot=k % 2)), so the channeliser of batch k+1 -- bound by its output
         stores -- runs beside the demodulation of batch k -- bound by instruction issue -- instead of behind it.
 
@@ -45,7 +48,7 @@ class WidebandReceiver:
         for _ in range(int(slots)):
             d_ch = DeviceBuffer(device, self.group * self.M * self.pitch * 8)
             demod = BatchDemodulator(self.sample_rate / self.D, self.n_out, self.group * self.M, "cf32",
-                                     device=device, mode=MODE_TETRA)
+                                     device=device, mode=mode)
             if self.group == self.streams:
                 demod.alloc_device_io()
             self.slots.append((d_ch, demod))
