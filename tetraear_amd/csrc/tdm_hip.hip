@@ -822,11 +822,11 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
             const char *fe = std::getenv("TDM_GARDNER_FUSED");
             const bool fused = stages == 7 && !(fe && std::atoi(fe) == 0);
             bool fused_done = false;
-            if (fused && tetra_gardner_fused_available(tp.ntaps)) {
+            if (fused && tetra_gardner_fused_available(tp.ntaps, plan->rows)) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream);
             }
-            const bool three = !fused_done;   // (TDM_GARDNER_FUSED=0, a stage mask, or no fused kernel for this tap count)
+            const bool three = !fused_done;   // (TDM_GARDNER_FUSED=0, a stage mask, no fused kernel for this tap count, or too many carriers for it)
             if (three && (stages & 1)) {
                 HipBackend::Scope s(be, ST_TETRA_MF);
                 if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))

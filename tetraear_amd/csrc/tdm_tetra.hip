@@ -59,7 +59,30 @@ void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y,
                        soft, n_soft, timing_milli);
 }
 
-bool tetra_gardner_fused_available(int ntaps) { return ntaps == 17 || ntaps == 25 || ntaps == 33 || ntaps == 35 || ntaps == 41 || ntaps == 49 || ntaps == 57 || ntaps == 65; }
+static const void *gardner_fused_kernel(int ntaps)
+{
+    switch (ntaps) {
+#define TDM_GF_CASE(NT) case NT: return (const void *)k_tetra_gardner<NT>;
+        TDM_GF_CASE(17) TDM_GF_CASE(25) TDM_GF_CASE(33) TDM_GF_CASE(35) TDM_GF_CASE(41) TDM_GF_CASE(49) TDM_GF_CASE(57) TDM_GF_CASE(65)
+#undef TDM_GF_CASE
+    default: return nullptr;
+    }
+}
+
+// The fused kernel's time is one workgroup's (the loop's serial chain) times the ROUNDS the launch takes: workgroups over what
+// the device holds at once (compute units x workgroups per unit: two up to 41 taps -- 79 KB of LDS each --, one above).
+// With two per unit it stays ahead of the three launches at any size (4096 / 8192 / 16 384 carriers at 4 samples per
+// symbol: 1.35 / 1.86 / 3.51 ms against 1.85 / 2.4 / 3.57); with one per unit only while the launch is a single round (the
+// loop on its own needs 33 KB and runs four workgroups per unit: 8192 carriers at 8 samples per symbol 1.96 ms).
+bool tetra_gardner_fused_available(int ntaps, int rows)
+{
+    const void *fn = gardner_fused_kernel(ntaps);
+    if (!fn) return false;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return true;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * (1 + kGProducers), 0) != hipSuccess || per_cu < 1) return true;
+    return per_cu >= 2 || (int64_t)(rows + kGQuads - 1) / kGQuads <= (int64_t)cus * per_cu;
+}
 
 bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
                                 int32_t *timing_milli, hipStream_t stream)

@@ -200,8 +200,11 @@ constexpr int kGProducers = 2;               // matched-filter wavefronts of the
 constexpr int kGQuota = 2;                   // chunks a producer makes between two hand-overs (a block of 16 symbols uses sps / 4)
 template <int NT> struct GardnerWindow {     // a producer's input window per carrier and chunk
     static constexpr int H = (NT - 1) / 2, W = kGChunk + NT - 1, pairs = W / 2;
-    static constexpr int pitch = W + 2 * (W / 8) + 6;      // two pad slots per eight samples (slot()): a lane's window starts 80 bytes after its neighbour's
-    static constexpr int slot(int s) { return s + 2 * (s >> 3); }
+    // (no pad slots, unlike k_tetra_mf's window: padding the rows did not change the producers' time -- they wait on
+    //  arithmetic, not on LDS banks -- and without it TWO workgroups fit a compute unit's 160 KB up to 41 taps: 8192 carriers
+    //  in the time of 4096)
+    static constexpr int pitch = W + 4;
+    static constexpr int slot(int s) { return s; }
     static constexpr int loads = (8 * pairs + 63) / 64;
 };
 
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
                     // (the same wavefront reads what it wrote: LDS operations of a wavefront are served in order)
                     // eight consecutive outputs from the 8 + NT - 1 samples under them (as k_tetra_mf), taps in scalar registers
                     f32x2 w[8 + NT - 1];
-                    const float2 *pw = xw + j * GW::pitch + 10 * gI;            // slot(8 gI)
+                    const float2 *pw = xw + j * GW::pitch + GW::slot(8 * gI);
 #pragma unroll
                     for (int i = 0; i < 8 + NT - 1; ++i) w[i] = *(const f32x2 *)(pw + GW::slot(i));   // (all reads in flight together:
                     f32x2 acc[8];                                                                         //  a lone wavefront has nobody to hide a wait per read)

@@ -62,7 +62,7 @@ void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y,
                                int32_t *timing_milli, hipStream_t stream);
 // the matched filter and the loop in ONE kernel (the filter output stays in LDS); false when not instantiated for tp.ntaps
 // (the caller then makes the three launches)
-bool tetra_gardner_fused_available(int ntaps);
+bool tetra_gardner_fused_available(int ntaps, int rows);   // instantiated for the tap count, and not slower than the three launches at this size
 bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
                                 int32_t *timing_milli, hipStream_t stream);
 void tetra_decide_launch(const TetraParams &tp, int rows, const float2 *soft, const int32_t *n_soft, uint8_t *hard, double *min_margin,
