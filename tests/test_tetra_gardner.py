@@ -230,3 +230,32 @@ def test_gpu_gardner_fused_kernel_agrees_with_the_three_launches():
             assert np.array_equal(h1[r, :k - 1], h0[r, :k - 1]), (fs, r)
             scale = float(np.max(np.abs(s0[r, :k])))
             assert float(np.max(np.abs(s1[r, :k] - s0[r, :k]))) <= 2e-6 * scale, (fs, r)
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_more_carriers_than_one_round_of_workgroups():
+    """4200 carriers = 263 workgroups of the fused kernel on 256 compute units: at 4 samples per symbol two workgroups share a
+    compute unit, at 8 one fits and the call takes the three launches instead; either way every carrier equals what the
+    three launches give"""
+    import os
+    from tetraear_amd._lib import MODE_TETRA_GARDNER
+    from tetraear_amd.batch import BatchDemodulator
+    for fs in (72000.0, 144000.0):
+        n, rows, distinct = 3000, 4200, 24
+        base = [_gardner_case(n, fs, 1200 + r, 0.03 * r - 0.35, float(r * 7 - 80), 22.0, float((r % 7) - 3) * 100.0)[0] for r in range(distinct)]
+        iq = np.concatenate([base[r % distinct] for r in range(rows)])
+        outs = []
+        for fused in ("1", "0"):
+            os.environ["TDM_GARDNER_FUSED"] = fused
+            try:
+                bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+                outs.append(bd.process(iq))
+                bd.close()
+            finally:
+                del os.environ["TDM_GARDNER_FUSED"]
+        (h1, s1, t1, m1), (h0, s0, t0, m0) = outs
+        assert np.array_equal(t1, t0)
+        for r in range(rows):
+            assert len(s1[r]) == len(s0[r]) and len(h1[r]) > 0.9 * n / (fs / 18000.0) - 10, (fs, r)
+            assert np.array_equal(h1[r], h0[r]), (fs, r)
+            assert np.array_equal(h1[r], h1[r % distinct]), (fs, r)      # (and its prototype row)
