@@ -227,7 +227,7 @@ constexpr int kQuadSymbolPair = 0x44;        // [0, 1, 0, 1]
 // NT > 0: FUSED -- the workgroup has two more wavefronts that run the NT-tap matched filter for the loop's sixteen carriers
 // (eight each, a 64-sample chunk at a time, from the raw input x) straight into the LDS ring: the filter output never goes
 // to HBM.  A lone wavefront leaves two thirds of its SIMD's issue slots and the other three SIMDs of its compute unit idle;
-// the producers' 330 instructions per chunk fit there many times over.  Hand-over at the loop's block boundaries through
+// the producers' ~350 instructions per chunk (33 taps) fit there many times over.  Hand-over at the loop's block boundaries through
 // ONE workgroup barrier per block (no polling): the producers publish how many chunks are complete, the loop how far it has
 // moved on; every wavefront passes the same barriers and leaves after the one at which `done` was set.
 template <int NT>
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
                     }
                     issue(cn + 1);
                     // (the same wavefront reads what it wrote: LDS operations of a wavefront are served in order)
-                    // eight consecutive outputs from the 8 + NT - 1 samples under them (as k_tetra_mf), taps in scalar registers
+                    // eight consecutive outputs from the 8 + NT - 1 samples under them (as k_tetra_mf), the taps as pairs from LDS
                     f32x2 w[8 + NT - 1];
                     const float2 *pw = xw + j * GW::pitch + GW::slot(8 * gI);
 #pragma unroll
