@@ -641,14 +641,25 @@ __global__ __launch_bounds__(256) void k_tetra_decide(const float2 *__restrict__
         const float px = p.x * sc, py = p.y * sc, cx = c.x * sc, cy = c.y * sc;
         return make_float2(cx * px + cy * py, cy * px - cx * py);
     };
+    // A thread's products d_i (i = 1 + tid + 256 j) stay in registers between the estimate and the decisions -- the kernel waits
+    // on memory for most of its time, so the soft symbols are read once, and with clamped indices all of a thread's loads
+    // are in flight together.  (Rows longer than 1 + 256 kKeep symbols: the rest is read twice, as before.)
+    constexpr int kKeep = 40;
+    float2 dk[kKeep];
+    const int last = max(ns - 1, 1);
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) dk[j] = product(min(1 + tid + 256 * j, last));
     float a_pp = 0.f, a_qq = 0.f, a_pq = 0.f;
-    for (int i = 1 + tid; i < ns; i += 256) {
-        const float2 d = product(i);
+    auto gather = [&](const float2 d) {
         const float p4 = fmaf(d.x, d.x, -(d.y * d.y)), q4 = d.x * d.y;
         a_pp = fmaf(p4, p4, a_pp);
         a_qq = fmaf(q4, q4, a_qq);
         a_pq = fmaf(p4, q4, a_pq);
-    }
+    };
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j)
+        if (1 + tid + 256 * j < ns) gather(dk[j]);
+    for (int i = 1 + tid + 256 * kKeep; i < ns; i += 256) gather(product(i));
     float r = fmaf(-4.f, a_qq, a_pp), q = 4.f * a_pq;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { r += __shfl_xor(r, d, 64); q += __shfl_xor(q, d, 64); }
@@ -663,8 +674,7 @@ __global__ __launch_bounds__(256) void k_tetra_decide(const float2 *__restrict__
     float rs, rc;
     __sincosf(-delta_s, &rs, &rc);
     float mlo = 3.0e38f, mhi = 1.f, hmin = 3.0e38f;
-    for (int i = 1 + tid; i < ns; i += 256) {
-        const float2 d = product(i);
+    auto decide = [&](int i, const float2 d) {
         const float ddx = d.x * rc - d.y * rs, ddy = d.x * rs + d.y * rc;
         hr[i - 1] = (uint8_t)(((ddy < 0.f) ? 2u : 0u) | ((ddx < 0.f) ? 1u : 0u));
         const float lo = fminf(fabsf(ddx), fabsf(ddy)), hi = fmaxf(fabsf(ddx), fabsf(ddy));
@@ -672,7 +682,11 @@ __global__ __launch_bounds__(256) void k_tetra_decide(const float2 *__restrict__
         const bool take = lo * mhi < mlo * hi;
         mlo = take ? lo : mlo;
         mhi = take ? hi : mhi;
-    }
+    };
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j)
+        if (1 + tid + 256 * j < ns) decide(1 + tid + 256 * j, dk[j]);
+    for (int i = 1 + tid + 256 * kKeep; i < ns; i += 256) decide(i, product(i));
     const float mratio = hmin == 0.f ? 0.f : mlo / mhi;
     float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;
 #pragma unroll
