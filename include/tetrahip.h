@@ -94,6 +94,21 @@ TDM_API int tdm_version(void);
 TDM_API int tdm_device_count(void);
 /* copies the calling thread's last error text (NUL-terminated) into buf; returns its length */
 TDM_API int tdm_last_error(char *buf, size_t buflen);
+/* Debug / experiment switches.  No counterpart in the reference (it has no kernel choices to make); the library never
+ * reads the environment, so this call is the only way to override a kernel choice -- tests use it to put small inputs on
+ * the kernels large batches take.  Process-wide; an unknown key is TDM_ERR_INVALID.  Every switch selects between
+ * COMPLETE code paths with equal results (none skips work):
+ *   "no_raw"          1: reference-mode cu8 plans created from now on never take the raw-byte decimator       (default 0)
+ *   "raw_min_blocks"  >= 0: decimator blocks below which a batch stays on the double-based kernel, for plans
+ *                     created from now on                                                                   (default -1: 8 per CU)
+ *   "row_walk"        low-rate stage of reference mode: 0 one workgroup per chunk and a finish launch, 1 the row-walking
+ *                     kernel (carries + stage + finish in one persistent launch; bit-identical, measured slower)  (default 0)
+ *   "gardner_fused"   0: TDM_MODE_TETRA_GARDNER as three launches (matched filter -> HBM -> loop -> decisions)  (default 1)
+ *   "pfb_direct"      1: channeliser plans created from now on use the direct-DFT kernel                     (default 0)
+ *   "pfb_rounds"      > 0: rounds per channeliser workgroup, for plans created from now on                  (default 0: computed)
+ *   "pfb_halftile"    1: half-tile channeliser kernel for 8-bit formats, plans created from now on          (default 0) */
+TDM_API int tdm_debug_set(const char *key, int64_t value);
+TDM_API int tdm_debug_get(const char *key, int64_t *value);
 
 /* ---- plan: one (sample_rate, n_samples, n_carriers, format) configuration ----------------
  * replaces SignalProcessor.__init__ (processor.py:21-33) + the per-call filter design

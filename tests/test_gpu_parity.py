@@ -51,12 +51,15 @@ def test_process_c128_matches_reference(name, gold_process, SP):
 @pytest.fixture(params=["auto", "raw"])
 def cu8_engine(request, monkeypatch):
     """A few carriers run the decimator that holds its samples as doubles (shorter blocks fill the chip sooner), big
-    batches the raw-integer one; "raw" puts single carriers on the raw-integer kernel too (TDM_RAW_MIN_BLOCKS=0)."""
+    batches the raw-integer one; "raw" puts single carriers on the raw-integer kernel too (tdm_debug_set raw_min_blocks 0)."""
+    from tetraear_amd._lib import debug_option
     from tetraear_amd.signal import processor as P
     P.close_plans()
     if request.param == "raw":
-        monkeypatch.setenv("TDM_RAW_MIN_BLOCKS", "0")
-    yield request.param
+        with debug_option("raw_min_blocks", 0):
+            yield request.param
+    else:
+        yield request.param
     P.close_plans()
 
 

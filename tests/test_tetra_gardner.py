@@ -194,11 +194,10 @@ def test_gpu_gardner_short_rows_silence_and_capacity():
 @pytest.mark.gpu
 def test_gpu_gardner_fused_kernel_agrees_with_the_three_launches():
     """the default path (matched filter by producer wavefronts inside the loop's workgroup, filter output in LDS only) against
-    the three-launch path (k_tetra_mf -> HBM -> loop; TDM_GARDNER_FUSED=0) on the same batch: the same symbol counts and
+    the three-launch path (k_tetra_mf -> HBM -> loop; tdm_debug_set gardner_fused 0) on the same batch: the same symbol counts and
     decisions, soft symbols within fp32 rounding -- at every tap count a plan can have (3..8 samples per symbol), with rows
     that are no multiple of a wavefront's sixteen carriers and a pitch that is not the row length"""
-    import os
-    from tetraear_amd._lib import MODE_TETRA_GARDNER, check, ptr
+    from tetraear_amd._lib import MODE_TETRA_GARDNER, check, debug_option, ptr
     from tetraear_amd.batch import BatchDemodulator
     for fs, n in ((54000.0, 5000), (72000.0, 8192), (75000.0, 6001), (90000.0, 7000), (108000.0, 9000), (126000.0, 8000), (144000.0, 12000)):
         rows, pitch = 21, n + 5
@@ -207,9 +206,8 @@ def test_gpu_gardner_fused_kernel_agrees_with_the_three_launches():
         for r in range(rows):
             buf[r, :n] = xs[r]
         outs = []
-        for fused in ("1", "0"):
-            os.environ["TDM_GARDNER_FUSED"] = fused
-            try:
+        for fused in (1, 0):
+            with debug_option("gardner_fused", fused):
                 bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
                 ms = bd.info.max_soft
                 hard = np.zeros((rows, ms), np.uint8)
@@ -218,8 +216,6 @@ def test_gpu_gardner_fused_kernel_agrees_with_the_three_launches():
                 tm = np.zeros(rows, np.int32)
                 check(bd.lib.tdm_process(bd.handle, ptr(buf), pitch, None, None, ptr(hard), ptr(soft), ptr(ns), ptr(tm), None))
                 bd.close()
-            finally:
-                del os.environ["TDM_GARDNER_FUSED"]
             outs.append((hard, soft, ns, tm))
         (h1, s1, n1, t1), (h0, s0, n0, t0) = outs
         assert np.array_equal(n1, n0), (fs, n1, n0)
@@ -237,22 +233,18 @@ def test_gpu_gardner_more_carriers_than_one_round_of_workgroups():
     """4200 carriers = 263 workgroups of the fused kernel on 256 compute units: at 4 samples per symbol two workgroups share a
     compute unit, at 8 one fits and the call takes the three launches instead; either way every carrier equals what the
     three launches give"""
-    import os
-    from tetraear_amd._lib import MODE_TETRA_GARDNER
+    from tetraear_amd._lib import MODE_TETRA_GARDNER, debug_option
     from tetraear_amd.batch import BatchDemodulator
     for fs in (72000.0, 144000.0):
         n, rows, distinct = 3000, 4200, 24
         base = [_gardner_case(n, fs, 1200 + r, 0.03 * r - 0.35, float(r * 7 - 80), 22.0, float((r % 7) - 3) * 100.0)[0] for r in range(distinct)]
         iq = np.concatenate([base[r % distinct] for r in range(rows)])
         outs = []
-        for fused in ("1", "0"):
-            os.environ["TDM_GARDNER_FUSED"] = fused
-            try:
+        for fused in (1, 0):
+            with debug_option("gardner_fused", fused):
                 bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
                 outs.append(bd.process(iq))
                 bd.close()
-            finally:
-                del os.environ["TDM_GARDNER_FUSED"]
         (h1, s1, t1, m1), (h0, s0, t0, m0) = outs
         assert np.array_equal(t1, t0)
         for r in range(rows):

@@ -305,27 +305,27 @@ def test_gpu_channeliser_batch_and_general_decimation():
 
 
 @pytest.mark.gpu
-def test_gpu_channeliser_direct_kernel_agrees(monkeypatch):
+def test_gpu_channeliser_direct_kernel_agrees():
     """the general fallback kernel (direct small DFTs; taken when a window exceeds LDS) against the
     register-FFT kernel on the same input"""
+    from tetraear_amd._lib import debug_option
     from tetraear_amd.channeliser import channelise
     for M, D, fs, n in ((400, 125, 10e6, 7000), (96, 32, 2.4e6, 5000)):
         x, _ = _wideband(n, fs, [1, M // 3, M - 2], M, seed0=700)
         x32 = (x / 4).astype(np.complex64)
-        monkeypatch.delenv("TDM_PFB_DIRECT", raising=False)
         y_fft = channelise(x32, "cf32", M, D)
-        monkeypatch.setenv("TDM_PFB_DIRECT", "1")
-        y_dir = channelise(x32, "cf32", M, D)
-        monkeypatch.delenv("TDM_PFB_DIRECT", raising=False)
+        with debug_option("pfb_direct", 1):
+            y_dir = channelise(x32, "cf32", M, D)
         assert np.max(np.abs(y_fft - y_dir)) < 2e-5 * np.max(np.abs(y_dir))
 
 
 @pytest.mark.gpu
-def test_gpu_channeliser_half_tile_kernel_agrees(monkeypatch):
-    """k_pfb_h2 (round-4 experiment, opt-in by TDM_PFB_HALFTILE=1: fp16 window, branch sums fused with a radix-2 split of
+def test_gpu_channeliser_half_tile_kernel_agrees():
+    """k_pfb_h2 (round-4 experiment, opt-in by tdm_debug_set("pfb_halftile", 1): fp16 window, branch sums fused with a radix-2 split of
     pass 1, half the exchange tile, two workgroups per compute unit -- measured slower, kept off) against the full-tile
     kernel and the fp64 definition, 8-bit wire formats, lengths that end inside a round and inside a workgroup's rounds"""
     from oracle import pfb_np
+    from tetraear_amd._lib import debug_option
     from tetraear_amd.channeliser import channelise
     M, D, fs = 400, 125, 10e6
     for n, fmt in ((7000, "cu8"), (125 * 32 * 7 + 61, "cu8"), (40000, "cs8")):
@@ -339,11 +339,9 @@ def test_gpu_channeliser_half_tile_kernel_agrees(monkeypatch):
             raw[0::2] = np.clip(np.rint(128 * x.real), -128, 127)
             raw[1::2] = np.clip(np.rint(128 * x.imag), -128, 127)
             xq = (raw[0::2].astype(np.float64) + 1j * raw[1::2].astype(np.float64)) / 128.0
-        monkeypatch.delenv("TDM_PFB_HALFTILE", raising=False)
         y_full = channelise(raw, fmt, M, D)
-        monkeypatch.setenv("TDM_PFB_HALFTILE", "1")
-        y_half = channelise(raw, fmt, M, D)
-        monkeypatch.delenv("TDM_PFB_HALFTILE", raising=False)
+        with debug_option("pfb_halftile", 1):
+            y_half = channelise(raw, fmt, M, D)
         probe = [0, 1, M // 3, M // 2 + 3, M - 2, M - 1]
         ref = pfb_np.channelise(xq, M, D, channels=probe)
         scale = np.max(np.abs(ref))

@@ -36,6 +36,8 @@ SIGNATURES = {
     "tdm_version": (C.c_int, []),
     "tdm_device_count": (C.c_int, []),
     "tdm_last_error": (C.c_int, [C.c_char_p, _sz]),
+    "tdm_debug_set": (C.c_int, [C.c_char_p, _i64]),
+    "tdm_debug_get": (C.c_int, [C.c_char_p, _P(_i64)]),
     "tdm_plan_create": (C.c_int, [_f64, _i64, _i32, _i32, _i32, _i32, _P(_vp)]),
     "tdm_plan_destroy": (C.c_int, [_vp]),
     "tdm_plan_get_info": (C.c_int, [_vp, _P(PlanInfo)]),
@@ -103,6 +105,26 @@ def check(rc):
     if rc != 0:
         raise TetraHipError(rc, last_error())
     return rc
+
+
+class debug_option:
+    """`with debug_option("row_walk", 1): ...` -- set a tdm_debug_set switch for the duration of a block (tests and
+    experiments; include/tetrahip.h lists the switches)."""
+
+    def __init__(self, key, value):
+        self.key, self.value = key.encode(), int(value)
+
+    def __enter__(self):
+        lib = load()
+        old = C.c_int64(0)
+        check(lib.tdm_debug_get(self.key, C.byref(old)))
+        self.old = old.value
+        check(lib.tdm_debug_set(self.key, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        check(load().tdm_debug_set(self.key, self.old))
+        return False
 
 
 def ptr(a):

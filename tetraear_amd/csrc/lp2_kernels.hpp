@@ -44,6 +44,10 @@ extern __device__ unsigned long long g_lp2_dbg[16];
 #define TDM_SCHED_FENCE() do { } while (0)
 #endif
 
+// (TDM_OPAQUE_V, pz_kernels.hpp: a value the compiler must take as new wherever it stands.  Inside the row-walking kernel's
+// chunk loop everything that depends only on the thread -- staging addresses, table rows -- is otherwise hoisted out of the
+// loop and kept alive across the whole row: hundreds of spilled registers.)
+
 namespace tdm {
 
 // Staging area: one 16-byte slot per position of the workgroup's span, swizzled so that both access patterns are free of
@@ -62,7 +66,8 @@ struct Lp2Lds {
     static constexpr int kStage = 2 * kSlots;
     // small area (doubles): [0,256) wave totals and the causal state at the end of the row, [256, 256 + 40*32) power partials of the groups
     static constexpr int oTot = 0, oPow = 2 * (kLp2Lanes / 16) * kLp2Pairs * 4, kPowGroups = 39;
-    static constexpr int kSmall = oPow + (kPowGroups + 1) * kMaxSps;
+    static constexpr int oNco = oPow + (kPowGroups + 1) * kMaxSps;   // the NCO's step phasor when it is formed once per row (lp2_row_body)
+    static constexpr int kSmall = oNco + 2;
 };
 
 // ---- sample sources --------------------------------------------------------------------------------------------
@@ -73,6 +78,7 @@ struct Lp2SrcPlain {   // c128 rows already at the low rate (no decimation: k_co
     static constexpr double fs_out = 0.0;
     TDM_HD double foff(int) const { return 0.0; }
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(x + (int64_t)row * row_stride * 2); }
+    TDM_HD void row_carries(int, int) const {}
     struct Pref {};
     template <class Comm>
     TDM_HD void prefetch_words(const Lp2Params &, int, Comm &, Pref &) const {}
@@ -90,6 +96,13 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     static constexpr bool kFix = true;
     TDM_HD double foff(int row) const { return freq_offset ? freq_offset[row] : 0.0; }
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(dec.y0 + (int64_t)row * dec.n_out * 2); }
+    // the row-walking kernel forms the decimator's block carries of its row itself (thread = (block, component)): what
+    // the carry launch k_pz_carry does for all rows
+    TDM_HD void row_carries(int row, int tid) const
+    {
+        if (!dec.pform) return;
+        for (int k = tid; k < 2 * dec.nb; k += kLp2Lanes) pz_carry_body<PzLayout::kMaxPairs>(dec, row, k >> 1, k & 1);
+    }
     // The decimator's carry responses (y = y0 + T1.Gf + T2.Hb), added to the staged samples in place.  For the La
     // consecutive outputs of a group they are, per pole pair and direction, a second-order recurrence at the decimated
     // rate seeded by two table rows.  They decay from the block's ends, so only the groups near a block boundary need them,
@@ -133,7 +146,8 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     TDM_HD void prefetch_words(const Lp2Params &P, int chunk, Comm &cm, Pref &o) const
     {
         const int32_t *it = P.items + (size_t)chunk * P.items_stride;
-        const int k = cm.tid();
+        int k = cm.tid();
+        TDM_OPAQUE_V(k);
         o.w0 = it[2 + 2 * k];
         o.w1 = it[3 + 2 * k];
         o.mine = k < it[0];
@@ -230,58 +244,75 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     }
 };
 
+// What a thread has in flight for a chunk before the chunk's arithmetic starts: its La samples (coalesced: sample
+// i * 64 + lane of the wavefront's run) and the operands of its first carry-response item.  lp2_body issues them at
+// the top of the chunk; the row-walking kernel (lp2_row_body) issues the NEXT chunk's while the current chunk's output
+// is still on its way out, so that the round trips pass behind the stores.
+template <class Src>
+struct Lp2Loads {
+    f64x2 v[kLp2La];
+    typename Src::Pref pref;
+};
+
+// the item words of a chunk (two per thread, the oldest loads in flight), then the samples, then the operands the words name
 template <class Src, class Comm>
-TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, int row)
+TDM_HD void lp2_issue_words(const Lp2Params &P, const Src &src, Comm &cm, int chunk, Lp2Loads<Src> &L)
+{
+    if (Src::kFix) src.prefetch_words(P, chunk, cm, L.pref);
+}
+template <class Src, class Comm>
+TDM_HD void lp2_issue_samples(const Lp2Params &P, const Src &src, Comm &cm, int chunk, int row, Lp2Loads<Src> &L)
+{
+    constexpr int La = kLp2La;
+    int tid = cm.tid();
+    TDM_OPAQUE_V(tid);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t jc = (int64_t)chunk * P.U - P.H - P.off;   // position of lane 0's first sample
+    const f64x2 *rowp = src.raw_row(row);
+    const int64_t jw = jc + (int64_t)wave * (kWave * La);
+    // unconditional loads from a clamped 32-bit index (a load under a branch gets a wait of its own: sixteen serial
+    // round trips), all of a lane's loads in flight at once, values outside the row zeroed afterwards
+    const int jw32 = (int)jw + lane, n32 = (int)P.n;     // (|positions| < 2^31: tdm_plan_create bounds the chunk length)
+#pragma unroll
+    for (int i = 0; i < La; ++i) {
+        const int j = jw32 + i * kWave;
+        const int jj = j < 0 ? 0 : (j >= n32 ? n32 - 1 : j);
+#ifdef TDM_LP2_FAKE_LOADS   // experiment: every load hits the same cache-resident kilobytes (results are wrong, timing only)
+        L.v[i] = src.raw_row(0)[jj & 1023];
+#else
+        L.v[i] = rowp[jj];
+#endif
+    }
+    if (Src::kFix) src.prefetch_operands(P, row, L.pref);
+}
+
+// the chunk's arithmetic: the loaded samples to LDS, carry responses, NCO, channel filter; ends with the filter output in
+// the staging area (behind a barrier).  nco_w: the NCO's step phasor in LDS (formed by the caller)
+template <class Src, class Comm>
+TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk, int row, Lp2Loads<Src> &L, const double *nco_w)
 {
     constexpr int La = kLp2La, NP = kLp2Pairs;
-    const int tid = cm.tid(), lane = tid & 63, wave = tid >> 6;
+    int tid = cm.tid();
+    TDM_OPAQUE_V(tid);
+    const int lane = tid & 63, wave = tid >> 6;
+    const double *cst = P.cst, *lane_m = P.lane_m;
+    TDM_OPAQUE_SPTR(cst);
+    TDM_OPAQUE_SPTR(lane_m);
     const int64_t n = P.n;
     const int edge = P.edge;
     const int64_t jc = (int64_t)chunk * P.U - P.H - P.off;   // position of lane 0's first sample
     const int64_t js = jc + (int64_t)tid * La;
     f64x2 *stage = (f64x2 *)cm.stage();
     double *small = cm.small();
-
-    // ---------------- input: coalesced through LDS, then each lane takes its La consecutive samples ----------------
-    LP2_T0();
     const bool any_sig = (js + La > 0 && js < n);          // the lane holds at least one sample of the row
     // chunks that hold an end of the row: odd extension and start states (workgroup-uniform)
     const bool wg_edge = (jc < 0) || (jc + (int64_t)kLp2Span > n);
-    typename Src::Pref pref;
-    if (Src::kFix) src.prefetch_words(P, chunk, cm, pref);
-    double *nco_w = small + Lp2Lds::oPow + 16;     // (the power partials' area is free until the output stage)
+    typename Src::Pref &pref = L.pref;
+    LP2_T0();
     {
-        const f64x2 *rowp = src.raw_row(row);
         const int64_t jw = jc + (int64_t)wave * (kWave * La);
-        // unconditional loads from a clamped 32-bit index (a load under a branch gets a wait of its own: sixteen serial
-        // round trips), all of a lane's loads in flight at once, values outside the row zeroed afterwards
-        const int jw32 = (int)jw + lane, n32 = (int)n;     // (|positions| < 2^31: tdm_plan_create bounds the chunk length)
-        f64x2 v[La];
-#pragma unroll
-        for (int i = 0; i < La; ++i) {
-            const int j = jw32 + i * kWave;
-            const int jj = j < 0 ? 0 : (j >= n32 ? n32 - 1 : j);
-#ifdef TDM_LP2_FAKE_LOADS   // experiment: every load hits the same cache-resident kilobytes (results are wrong, timing only)
-            v[i] = src.raw_row(0)[jj & 1023];
-#else
-            v[i] = rowp[jj];
-#endif
-        }
-        // ---- while the samples are on their way: the operands of the thread's first carry-response item, and the NCO's
-        // step phasor exp(i Dd), which is the same for the whole row: the last wavefront (the one with the fewest items)
-        // forms it and leaves it in LDS for all lanes (round 2: every lane's own sincos, 120 instructions in each of the
-        // four wavefronts)
-        if (Src::kFix) {
-            src.prefetch_operands(P, row, pref);
-            if (wave == kLp2Waves - 1) {
-                const double f = src.foff(row);
-                if (f != 0.0) {
-                    double wre, wim;
-                    NcoRunT<1>::step_phasor(f, src.fs_out, wre, wim);
-                    if (lane == 0) { nco_w[0] = wre; nco_w[1] = wim; }
-                }
-            }
-        }
+        const int jw32 = (int)jw + lane, n32 = (int)n;
+        f64x2 (&v)[La] = L.v;
         if (!wg_edge) {   // every position of the span lies inside the row: nothing to mask
 #pragma unroll
             for (int i = 0; i < La; ++i) stage[lp2_slot(wave * (kWave * La) + i * kWave + lane)] = v[i];
@@ -390,8 +421,8 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     double lmf[NP][4], lmb[NP][4];   // C^(La (k+1)), k = lane's distance to the previous / next row of 16 lanes (scan)
     {
         const int r = lane & 15;
-        const f64x2 *tf = (const f64x2 *)P.lane_m + (size_t)r * NP * 2;
-        const f64x2 *tb = (const f64x2 *)P.lane_m + (size_t)(15 - r) * NP * 2;
+        const f64x2 *tf = (const f64x2 *)lane_m + (size_t)r * NP * 2;
+        const f64x2 *tb = (const f64x2 *)lane_m + (size_t)(15 - r) * NP * 2;
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
             const f64x2 a0 = tf[s * 2], a1 = tf[s * 2 + 1], c0 = tb[s * 2], c1 = tb[s * 2 + 1];
@@ -418,7 +449,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         ur[s][0] = a1r; ur[s][1] = a2r; uq[s][0] = a1q; uq[s][1] = a2q;
     }
     if (has_head && tid == t_head) {
-        const double *hv = P.cst + Lp2Cst::head_v;
+        const double *hv = cst + Lp2Cst::head_v;
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
             zr[s][0] = hv[s * 2] * e0r; zr[s][1] = hv[s * 2 + 1] * e0r;
@@ -443,7 +474,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         constexpr int dir = decltype(dir_c)::value;
         double(*vr)[2] = dir == 0 ? zr : ur;
         double(*vq)[2] = dir == 0 ? zq : uq;
-        const double *Msc = P.cst + Lp2Cst::Mscan;
+        const double *Msc = cst + Lp2Cst::Mscan;
         TDM_OPAQUE_SPTR(Msc);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -484,7 +515,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         double mrow[NP][4];
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
-            const auto M = TDM_CPTR(P.cst + Lp2Cst::Mrow + s * 4);
+            const auto M = TDM_CPTR(cst + Lp2Cst::Mrow + s * 4);
             mrow[s][0] = M[0]; mrow[s][1] = M[1]; mrow[s][2] = M[2]; mrow[s][3] = M[3];
         }
 #pragma unroll 1
@@ -550,7 +581,7 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
         cm.sync();   // (the causal state at the end of the row visible)
         if (tid == t_tail) {
             // the anticausal bank starts from the causal bank's state at the end of the row (scipy: zi * forward[last])
-            const double *tm = P.cst + Lp2Cst::tail_m, *tx = P.cst + Lp2Cst::tail_x;
+            const double *tm = cst + Lp2Cst::tail_m, *tx = cst + Lp2Cst::tail_x;
 #pragma unroll
             for (int r = 0; r < kLp2D; ++r) {
                 double ar = tx[r] * xlr, ai = tx[r] * xli;
@@ -603,6 +634,20 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{or_[i], oi[i]};
     cm.sync();
     LP2_T(5);
+}
+
+// the chunk's filter output from the staging area to memory, phase-major, with the chunk's power sums per timing phase;
+// ends behind a barrier after the last read of the staging area (the few threads that add up the partial sums after it
+// touch only the small area's power slots)
+template <class Comm>
+TDM_HD void lp2_store(const Lp2Params &P, Comm &cm, int chunk, int row)
+{
+    int tid = cm.tid();
+    TDM_OPAQUE_V(tid);
+    const int64_t n = P.n;
+    const int64_t jc = (int64_t)chunk * P.U - P.H - P.off;
+    f64x2 *stage = (f64x2 *)cm.stage();
+    double *small = cm.small();
     const int64_t j_lo = (int64_t)chunk * P.U - P.off > 0 ? (int64_t)chunk * P.U - P.off : 0;
     int64_t j_hi = (int64_t)(chunk + 1) * P.U - P.off;
     if (j_hi > n) j_hi = n;
@@ -610,10 +655,8 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     if (sps > 0) {
         f64x2 *zt = (f64x2 *)P.zt + (int64_t)row * sps * P.zt_k;
         constexpr int NG = Lp2Lds::kPowGroups;
-        const int ph = tid / NG, g = tid % NG;     // 512 threads: phases 0..12 x 39 groups (sps <= 13), else fewer groups per phase
         const int ngrp = kLp2Lanes / sps < NG ? kLp2Lanes / sps : NG;
-        const int p2 = tid / ngrp, g2 = tid % ngrp;
-        (void)ph; (void)g;
+        const int p2 = tid / ngrp, g2 = tid % ngrp;   // 256 threads: phases 0..12 x 19 groups (sps = 13)
         double acc = 0;
         if (p2 < sps) {
             // 32-bit index arithmetic (positions are below 2^31: tdm_plan_create bounds the chunk length), strength-reduced:
@@ -646,8 +689,125 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     } else {
         f64x2 *z = (f64x2 *)P.zt + (int64_t)row * P.zt_k;
         for (int64_t j = j_lo + tid; j < j_hi; j += kLp2Lanes) z[j] = stage[lp2_slot((int)(j - jc))];
+        cm.sync();
     }
-    LP2_T(6);
+}
+
+// one chunk of one row, start to end (the kernel with one workgroup per chunk)
+template <class Src, class Comm>
+TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, int row)
+{
+    Lp2Loads<Src> L;
+    lp2_issue_words(P, src, cm, chunk, L);
+    lp2_issue_samples(P, src, cm, chunk, row, L);
+    // ---- while the samples are on their way: the NCO's step phasor exp(i Dd), which is the same for the whole row: the
+    // last wavefront (the one with the fewest items) forms it and leaves it in LDS for all lanes (round 2: every lane's
+    // own sincos, 120 instructions in each of the four wavefronts)
+    double *nco_w = cm.small() + Lp2Lds::oPow + 16;     // (the power partials' area is free until the output stage)
+    if (Src::kFix && (cm.tid() >> 6) == kLp2Waves - 1) {
+        const double f = src.foff(row);
+        if (f != 0.0) {
+            double wre, wim;
+            NcoRunT<1>::step_phasor(f, src.fs_out, wre, wim);
+            if ((cm.tid() & 63) == 0) { nco_w[0] = wre; nco_w[1] = wim; }
+        }
+    }
+    lp2_compute(P, src, cm, chunk, row, L, nco_w);
+    lp2_store(P, cm, chunk, row);
+}
+
+// ---- the row-walking form: ONE workgroup takes a whole row through the stage, chunk by chunk, and finishes it ----------------
+// (batches with at least as many rows as the device holds workgroups of this kernel: every compute unit is busy with
+// whole rows).  What it changes against one workgroup per chunk + two more launches:
+//   * the decimator's block carries (pz_carry_body, the launch between the decimator and this stage) are formed by
+//     the row's own workgroup in front of its first chunk;
+//   * chunk c + 1's loads (samples and item operands) are issued when chunk c's filter output has left the registers, and
+//     their round trips pass behind chunk c's stores: the stage-in wait -- 30 % of a chunk's time when a workgroup
+//     starts cold -- is hidden;
+//   * extract_symbols' phase pick and demodulate_dqpsk (finish_body: processor.py:168-219, 102-166) run in the same
+//     workgroup behind the last chunk, on phase-major rows it wrote itself moments ago.
+// The arithmetic of a chunk is lp2_compute / lp2_store, unchanged: results are bit-identical to the three-launch path.
+//   BComm: the block-communication object of finish_body (reductions through LDS) on the same workgroup.
+#ifndef TDM_LP2_ROW_PREFETCH
+#define TDM_LP2_ROW_PREFETCH 1   // 0 (experiment): every chunk's loads at the top of the chunk, as the one-chunk kernel
+#endif
+
+// what the finish stage of a row needs beyond the low-rate stage's own parameters
+struct Lp2RowOut {
+    double *soft;          // [rows][max_soft] c128
+    uint8_t *hard;         // [rows][max_soft]
+    int32_t *n_soft;       // [rows]
+    int32_t *best_phase;   // [rows] or null
+    double *min_margin;    // [rows] or null
+    int32_t max_soft;
+};
+
+// extract_symbols' phase pick + demodulate_dqpsk of one row (finish_body) on the low-rate stage's own output; a function
+// of its own (not inlined): it runs once per row with nothing of the chunk loop alive
+template <class BComm>
+TDM_NOINLINE void lp2_row_finish(int64_t n, int sps, const double *partials, int n_chunks, const double *zt, int64_t zt_k,
+                                 const Lp2RowOut &out, BComm &bc, int row)
+{
+    FinishArgs fa{};
+    fa.n = n;
+    fa.row_stride = n;
+    fa.sps = sps;
+    fa.do_extract = 1;
+    fa.do_demod = 1;
+    fa.max_soft = out.max_soft;
+    fa.soft = out.soft;
+    fa.hard = out.hard;
+    fa.n_soft = out.n_soft;
+    fa.best_phase = out.best_phase;
+    fa.min_margin = out.min_margin;
+    fa.partials = partials;
+    fa.n_pblk = n_chunks;
+    fa.zt = zt;
+    fa.zt_k = zt_k;
+    finish_body(fa, bc, row);
+}
+
+template <class Src, class Comm, class BComm>
+TDM_HD void lp2_row_body(const Lp2Params &P, const Src &src, const Lp2RowOut &out, Comm &cm, BComm &bc, int row)
+{
+    const int tid = cm.tid();
+    double *nco_w = cm.small() + Lp2Lds::oNco;
+    if (Src::kFix) {
+        src.row_carries(row, tid);            // (reads the decimator's block end states, writes Gf / Hb of this row)
+        if ((tid >> 6) == kLp2Waves - 1) {    // the NCO's step phasor, once per row
+            const double f = src.foff(row);
+            if (f != 0.0) {
+                double wre, wim;
+                NcoRunT<1>::step_phasor(f, src.fs_out, wre, wim);
+                if ((tid & 63) == 0) { nco_w[0] = wre; nco_w[1] = wim; }
+            }
+        }
+        cm.sync();                            // the row's carries visible to the items' operand loads
+    }
+    Lp2Loads<Src> L;
+    const int nc = P.n_chunks;
+#if TDM_LP2_ROW_PREFETCH
+    lp2_issue_words(P, src, cm, 0, L);
+    lp2_issue_samples(P, src, cm, 0, row, L);
+#endif
+#pragma unroll 1
+    for (int c = 0; c < nc; ++c) {
+#if !TDM_LP2_ROW_PREFETCH
+        lp2_issue_words(P, src, cm, c, L);
+        lp2_issue_samples(P, src, cm, c, row, L);
+#endif
+        lp2_compute(P, src, cm, c, row, L, nco_w);
+#if TDM_LP2_ROW_PREFETCH
+        if (c + 1 < nc) {
+            lp2_issue_words(P, src, cm, c + 1, L);
+            lp2_issue_samples(P, src, cm, c + 1, row, L);
+        }
+#endif
+        lp2_store(P, cm, c, row);
+    }
+    cm.sync();                                // the row's phase-major output and its chunks' power sums are complete
+    lp2_row_finish(P.n, P.sps, P.partials, P.n_chunks, P.zt, P.zt_k, out, bc, row);
+    cm.sync();                                // (the small LDS area is the next row's again)
 }
 
 }  // namespace tdm

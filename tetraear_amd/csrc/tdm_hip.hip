@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -36,6 +37,33 @@ static thread_local std::string g_err;
 // the null stream unless the caller chose one with tdm_set_stream -- typically a plan's own stream, which puts
 // those launches in order with tdm_process_device without any host synchronisation
 static thread_local hipStream_t g_cur_stream = nullptr;
+
+// ------------------------------------------------------------------------------------------
+// debug / experiment switches (tdm_debug_set, include/tetrahip.h).  The library never reads the environment: a switch is
+// set by a call the header documents, or not at all.
+// ------------------------------------------------------------------------------------------
+struct DebugSwitch { const char *key; std::atomic<long long> value; long long dflt; };
+static DebugSwitch g_debug[] = {
+    {"no_raw", {0}, 0},                  // 1: cu8 plans made from now on never take the raw-integer decimator
+    {"raw_min_blocks", {-1}, -1},        // >= 0: blocks below which a batch stays on the double-based decimator (plans made from now on)
+    {"row_walk", {0}, 0},                // low-rate stage: 0 one workgroup per chunk + finish launch, 1 the row-walking kernel (measured slower)
+    {"gardner_fused", {1}, 1},           // 0: Gardner mode as three launches (matched filter -> HBM -> loop -> decisions)
+    {"pfb_direct", {0}, 0},              // 1: channeliser plans made from now on use the direct-DFT kernel
+    {"pfb_rounds", {0}, 0},              // > 0: rounds per channeliser workgroup (plans made from now on)
+    {"pfb_halftile", {0}, 0},
+};
+static DebugSwitch *debug_find(const char *key)
+{
+    if (!key) return nullptr;
+    for (auto &d : g_debug)
+        if (std::strcmp(d.key, key) == 0) return &d;
+    return nullptr;
+}
+static long long debug_value(const char *key)
+{
+    DebugSwitch *d = debug_find(key);
+    return d ? d->value.load(std::memory_order_relaxed) : 0;
+}
 
 static int fail(int code, const std::string &msg)
 {
@@ -233,6 +261,7 @@ struct HipBackend {
     hipStream_t stream = nullptr;
     StageTimer *timer = nullptr;
     hipError_t err = hipSuccess;
+    int device = 0;
 
     struct Scope {
         HipBackend &be; int stage; hipEvent_t a{}, b{}; bool on;
@@ -280,6 +309,27 @@ struct HipBackend {
     {
         lp2(P, src, rows);
         finish(fa, rows);
+    }
+    // The row-walking form of the low-rate stage (lp2_row_body: carries, stage and finish in one persistent kernel, a
+    // workgroup per row).  Measured on MI355X, 1024 x 262 144 (round 5): 0.49 ms (0.62 with the next chunk's loads in flight
+    // across the stores: 288 spilled registers) against 0.33 + 0.016 + 0.030 ms for one workgroup per chunk with its carry
+    // and finish launches -- 512 persistent workgroups walk their rows in step, so the chip's load, arithmetic and store
+    // phases coincide instead of overlapping, and each row's carries and finish are serial stretches of its own
+    // workgroup.  Off unless tdm_debug_set("row_walk", 1) asks for it (results are bit-identical).
+    bool lp2_row_walk(int rows)
+    {
+        const long long mode = debug_value("row_walk");
+        if (mode == 0) return false;
+        const int slots = lp2_row_slots<Lp2SrcDec>(device);
+        if (slots <= 0) return false;
+        (void)rows;
+        return mode == 1;
+    }
+    template <class Src>
+    void lp2_row(const Lp2Params &P, const Src &src, const FinishArgs &fa, int rows)
+    {
+        Scope s(*this, ST_LPF_BLOCK);
+        launch_lp2_row<Src>(P, src, fa, rows, lp2_row_slots<Src>(device), stream);
     }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
@@ -616,7 +666,11 @@ static void plan_free(tdm_plan *p)
 
 extern "C" {
 
+#ifdef TDM_EXPERIMENT
+int tdm_version(void) { return -TDM_VERSION; }   // a build with timing-only switches: never mistaken for the product
+#else
 int tdm_version(void) { return TDM_VERSION; }
+#endif
 
 int tdm_device_count(void)
 {
@@ -632,6 +686,28 @@ int tdm_last_error(char *buf, size_t buflen)
         std::snprintf(buf, buflen, "%s", g_err.c_str());
     }
     return (int)g_err.size();
+}
+
+int tdm_debug_set(const char *key, int64_t value)
+{
+    DebugSwitch *d = debug_find(key);
+    if (!d) return fail(TDM_ERR_INVALID, std::string("tdm_debug_set: unknown switch '") + (key ? key : "(null)") + "'");
+    d->value.store(value, std::memory_order_relaxed);
+    return TDM_OK;
+}
+
+int tdm_debug_get(const char *key, int64_t *value)
+{
+    if (key && value && std::strcmp(key, "lp2_row_slots") == 0) {   // (read-only: workgroups of the row-walking kernel the current device holds)
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        *value = lp2_row_slots<Lp2SrcDec>(dev);
+        return TDM_OK;
+    }
+    DebugSwitch *d = debug_find(key);
+    if (!d || !value) return fail(TDM_ERR_INVALID, std::string("tdm_debug_get: unknown switch '") + (key ? key : "(null)") + "'");
+    *value = d->value.load(std::memory_order_relaxed);
+    return TDM_OK;
 }
 
 int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, int32_t in_fmt, int32_t mode,
@@ -721,16 +797,15 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         *out = p.release();
         return TDM_OK;
     }
-    // (TDM_NO_RAW=1: experiments / tests keep cu8 plans on the kernel that holds its samples as doubles)
-    const char *no_raw = std::getenv("TDM_NO_RAW");
-    p->allow_raw = !(no_raw && no_raw[0] == '1');
+    // (tdm_debug_set("no_raw", 1): experiments / tests keep cu8 plans on the kernel that holds its samples as doubles)
+    p->allow_raw = debug_value("no_raw") != 1;
     {
         // blocks of the double-based decimator below which a batch stays on it: two wavefronts per SIMD of the device
-        // (TDM_RAW_MIN_BLOCKS overrides; tests use 0 to put single carriers on the raw-integer kernel)
+        // (tdm_debug_set("raw_min_blocks", n) overrides; tests use 0 to put single carriers on the raw-integer kernel)
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         p->raw_min_blocks = (int64_t)prop.multiProcessorCount * 8;
-        if (const char *e = std::getenv("TDM_RAW_MIN_BLOCKS")) p->raw_min_blocks = std::atoll(e);
+        if (debug_value("raw_min_blocks") >= 0) p->raw_min_blocks = debug_value("raw_min_blocks");
     }
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p->ev0));
@@ -807,6 +882,7 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     HipBackend be;
     be.stream = stream ? (hipStream_t)stream : plan->stream;
     be.timer = &plan->timer;
+    be.device = plan->device;
     if (plan->mode == TDM_MODE_TETRA || plan->mode == TDM_MODE_TETRA_GARDNER) {
         if (pre_shift_hz || freq_offset_hz)
             return fail(TDM_ERR_UNSUPPORTED, "TETRA mode: carrier offsets are estimated, not supplied");
@@ -815,18 +891,16 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
         const TetraParams &tp = plan->tp;
         if (plan->mode == TDM_MODE_TETRA_GARDNER) {
             // matched filter -> HBM -> Gardner loop, one lane per carrier -> decisions (tetra_gardner_kernels.hpp)
-            // (TDM_GARDNER_STAGES: bit mask of the launches to make -- 1 matched filter, 2 loop, 4 decisions; profiling only)
-            static const int stages = [] { const char *e = std::getenv("TDM_GARDNER_STAGES"); return e ? std::atoi(e) : 7; }();
-            // the matched filter and the loop in ONE kernel (the filter output stays in LDS); TDM_GARDNER_FUSED=0 (read at every
-            // call: tests switch it) or a stage mask: the three launches with the filter output in HBM
-            const char *fe = std::getenv("TDM_GARDNER_FUSED");
-            const bool fused = stages == 7 && !(fe && std::atoi(fe) == 0);
+            // the matched filter and the loop in ONE kernel (the filter output stays in LDS); tdm_debug_set("gardner_fused", 0):
+            // the three launches with the filter output in HBM
+            constexpr int stages = 7;
+            const bool fused = debug_value("gardner_fused") != 0;
             bool fused_done = false;
             if (fused && tetra_gardner_fused_available(tp.ntaps, plan->rows)) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream);
             }
-            const bool three = !fused_done;   // (TDM_GARDNER_FUSED=0, a stage mask, no fused kernel for this tap count, or too many carriers for it)
+            const bool three = !fused_done;   // (gardner_fused = 0, no fused kernel for this tap count, or too many carriers for it)
             if (three && (stages & 1)) {
                 HipBackend::Scope s(be, ST_TETRA_MF);
                 if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))
@@ -1830,7 +1904,7 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
     Q.W2 = Q.WM + M;
     Q.in_stride = n_in * (int64_t)fmt_bytes(fmt);
     Q.out_batch = (int64_t)M * pitch;
-    const bool force_direct = std::getenv("TDM_PFB_DIRECT") != nullptr;
+    const bool force_direct = debug_value("pfb_direct") == 1;
     if (!force_direct && D <= 4 * M) {
         const int64_t rounds = (n_out + TB - 1) / TB;
         // rounds per workgroup: `per_cu` workgroups per compute unit are resident (one of k_pfb_fft's 146 KB at M = 400, two of
@@ -1852,14 +1926,14 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
                 const double cost = (double)((wgs + slots - 1) / slots) * (g + 0.3);
                 if (cost < best - 1e-9) { best = cost; G = g; }
             }
-            if (const char *e = std::getenv("TDM_PFB_G")) G = std::max(1, std::atoi(e));   // experiments
+            if (debug_value("pfb_rounds") > 0) G = (int)debug_value("pfb_rounds");   // experiments
             return G;
         };
         if constexpr (M1 == M2 && M1 % 2 == 0 && TB % 2 == 0 && WGS == 1) {
-            // 8-bit wire formats, TDM_PFB_HALFTILE=1: the half-tile kernel, two workgroups per compute unit (pfb_kernels.hpp:
+            // 8-bit wire formats, tdm_debug_set("pfb_halftile", 1): the half-tile kernel, two workgroups per compute unit (pfb_kernels.hpp:
             // correct, measured slower than the full-tile kernel -- 0.335 against 0.237 ms per 32 x 1 Mi samples -- and off)
             const size_t lds2 = pfb_h2_lds_bytes<M1, M2, P, TB>(D);
-            if ((fmt == TDM_CU8 || fmt == TDM_CS8) && lds2 <= 80 * 1024 && std::getenv("TDM_PFB_HALFTILE")) {
+            if ((fmt == TDM_CU8 || fmt == TDM_CS8) && lds2 <= 80 * 1024 && debug_value("pfb_halftile") == 1) {
                 void (*kern)(const void *, cf32v *, int64_t, const PfbParams) =
                     fmt == TDM_CU8 ? k_pfb_h2<M1, M2, P, TB, 0> : k_pfb_h2<M1, M2, P, TB, 1>;
                 Q.G = pick_rounds(2);

@@ -1,6 +1,7 @@
 // TETRA mode: constants, kernel parameters and the launch entry (the kernels live in tetra_kernels.hpp, compiled in
 // tdm_tetra.hip; the rest of the library sees only this header).
 #pragma once
+#include "experiment_guard.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>

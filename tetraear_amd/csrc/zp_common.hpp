@@ -32,6 +32,8 @@
 #define TDM_CPTR(p) (p)
 #endif
 
+#include "experiment_guard.hpp"
+
 namespace tdm {
 
 constexpr int kWave = 64;        // lanes per block (one wavefront)

@@ -67,9 +67,14 @@ class WidebandReceiver:
         if iq.nbytes != self.d_in.nbytes:
             raise ValueError(f"iq holds {iq.nbytes} bytes, receiver needs {self.d_in.nbytes}")
         self.d_in.upload(iq)
-        self.enqueue()
-        self.demod.sync()
-        hard, soft, n_soft, timing, margin = self.demod.download()
+        if self.out is not None:      # (group < streams: the slots' channel buffers hold one sub-batch each)
+            self.enqueue_grouped()
+            self.sync()
+            hard, soft, n_soft, timing, margin = self.download_grouped()
+        else:
+            self.enqueue()
+            self.demod.sync()
+            hard, soft, n_soft, timing, margin = self.demod.download()
         shape = (self.streams, self.M)
         n_sym = np.maximum(n_soft - 1, 0).reshape(shape)
         return hard.reshape(shape + (-1,)), n_sym, timing.reshape(shape), margin.reshape(shape)
@@ -77,6 +82,9 @@ class WidebandReceiver:
     def enqueue(self, slot=0, d_in=None):
         """channeliser and demodulator back to back on the slot's demodulator plan's stream (no host synchronisation);
         `d_in`: another device input buffer than the receiver's own (a capture loop's second read buffer)"""
+        if self.out is not None:
+            raise ValueError("this receiver works in sub-batches of `group` streams (its channel buffers hold one sub-batch): "
+                             "use enqueue_grouped() / download_grouped()")
         no = C.c_int64()
         d_ch, demod = self.slots[slot]
         demod.make_stream_current()
@@ -89,6 +97,9 @@ class WidebandReceiver:
 
     def enqueue_grouped(self, d_in=None):
         """the whole batch as streams / group sub-batches, alternating between the slots (see __init__)"""
+        if self.out is None:
+            raise ValueError("enqueue_grouped() needs a receiver made with group < streams; this one takes the whole batch "
+                             "per call: use enqueue() / demod.download()")
         no = C.c_int64()
         rows_g, ms = self.group * self.M, self.demod.info.max_soft
         in_bytes = self.group * self.n_in * FMT_BYTES[self.fmt]
@@ -111,6 +122,8 @@ class WidebandReceiver:
                 demod.release_stream()
 
     def download_grouped(self):
+        if self.out is None:
+            raise ValueError("download_grouped() needs a receiver made with group < streams")
         rows, ms = self.streams * self.M, self.demod.info.max_soft
         o = self.out
         n_soft = o["n_soft"].download(np.int32, rows)
