@@ -339,6 +339,29 @@ def cpu_baseline_allcore(chunk, budget_s=5.0):
             "sample": f"{procs} processes x {budget_s:.0f} s of {chunk}-sample chunks, C oracle"}
 
 
+def spawn_local_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command on this node -- rank r on device r,
+    rendezvous on 127.0.0.1 (RcclGroup: librccl through ctypes) -- pass rank 0's one JSON line through, fail if any rank
+    fails.  The environment is what torch.distributed.run would have set."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    run_id = f"bench-self-{os.getpid()}"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID=run_id, TDM_RCCL_TOKEN=f"{run_id}|{port}")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit(f"bench: ranks exited with {rcs}")
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,6 +386,10 @@ def main():
                     help="(internal) the short run rocprofv3 counts HBM traffic on: noise input, no output check, no side measurements")
     args = ap.parse_args()
 
+    hook = os.environ.get("TDM_BENCH_TEST_HOOK")
+    if hook:   # (tests/: replaces the device with a stand-in so that the launch logic runs on a CPU-only box; never set in a measurement)
+        import runpy
+        runpy.run_path(hook, init_globals={"bench": sys.modules[__name__]})
     if args.mode == "tetra":
         return main_tetra(args)
     if args.mode == "pfb":
@@ -371,9 +398,16 @@ def main():
         return main_wideband(args)
     if args.mode == "stream":
         return main_stream(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: N local ranks, one per device, spawned here (the driver's torch.distributed.run
+        # line sets WORLD_SIZE and never comes this way)
+        return spawn_local_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # a line that says n_gpus: N must come from N ranks
+        raise SystemExit(f"bench: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to report")
     group, collective = None, "none (single process)"
     if world > 1 or os.environ.get("TDM_FORCE_DIST") == "1":   # the env switch lets a 1-GPU box exercise this path
         # barrier + three 8-byte all-reduces: librccl through ctypes (no tensor framework in the product path).  The choice

@@ -171,3 +171,26 @@ def test_pinned_digests_cover_config_4_weak_and_strong():
             lo, hi = carrier_range(1024, r, world)
             key = bench.digest_key(hi - lo, 262144, "cu8", bench.SAMPLE_RATE, r, False) + f":strong{lo}-{hi}of1024"
             assert bench.expected_digest(key), key
+
+
+@pytest.mark.timeout(240)
+def test_bench_gpus_2_as_a_plain_command_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (round-4 VERDICT: --gpus was parsed and never read, so a driver
+    calling it that way got one rank and n_gpus: 1): the command spawns two local ranks itself, they meet through RcclGroup
+    (stub librccl), and rank 0 prints ONE line that says n_gpus 2 / rccl_ranks 2.  A launcher whose world size contradicts
+    --gpus is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(TDM_RCCL_LIB=STUB, TDM_BENCH_TEST_HOOK=os.path.join(HERE, "bench_fake_device.py"), PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--carriers", "4",
+           "--chunk", "4096", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["carriers_per_gpu"] == 4
+    assert "librccl via ctypes" in d["config"]["collective"]
+    # --gpus 2 under a launcher that started ONE rank: no line, non-zero exit
+    r = subprocess.run(cmd, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=100, cwd=ROOT)
+    assert r.returncode != 0 and "refusing to report" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -167,3 +167,34 @@ def test_a_rank_that_connects_again_gets_the_decision_on_its_newer_socket():
             t.join(40)
             assert not t.is_alive()
         assert all(res[r] == (True, b"payload!") for r in range(world)), res
+
+
+def test_a_late_acknowledgement_does_not_strand_the_job(monkeypatch):
+    """rank 1 reads the decision and returns, but its acknowledgement is slower than rank 0's patience (round-4 ADVICE): rank 0
+    must count the rank as served -- it will never connect again -- instead of waiting for it until the job times out."""
+    import struct
+    import threading
+    import time
+    from tetraear_amd import rccl
+    monkeypatch.setattr(rccl, "_CONN_TIMEOUT_S", 0.5)
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="late")
+    res = {}
+    t0 = threading.Thread(target=lambda: res.__setitem__(0, rccl.rendezvous(0, 2, True, lambda: b"payload!", timeout_s=8.0)))
+    t0.start()
+    base, s = rccl._port_base(port), None
+    for _ in range(200):
+        try:
+            s = socket.create_connection(("127.0.0.1", base), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.02)
+    assert s is not None
+    s.sendall(rccl._token(2) + struct.pack("<iB", 1, 1))
+    assert rccl._recv_exact(s, len(rccl._MAGIC)) == rccl._MAGIC
+    decision, n = struct.unpack("<BI", rccl._recv_exact(s, 5))
+    assert decision == 1 and rccl._recv_exact(s, n) == b"payload!"
+    time.sleep(1.5)             # ... and only now would the acknowledgement go out
+    t0.join(6)
+    assert not t0.is_alive() and res[0] == (True, b"payload!")
+    s.close()

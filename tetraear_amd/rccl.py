@@ -96,6 +96,9 @@ def _recv_exact(sock, n):
     return buf
 
 
+_CONN_TIMEOUT_S = 10.0   # rank 0's patience with one peer's handshake step
+
+
 def _token(world):
     """what identifies this launch to its own ranks: TDM_RCCL_TOKEN if the launcher sets one; else the elastic launcher's
     run id plus the launcher's pid (torch.distributed.run: every rank is its child); the master port and world size always"""
@@ -137,7 +140,11 @@ def rendezvous(rank, world, usable, make_payload, timeout_s=120.0, addr=None, ba
         # handshake broke (before or after our acknowledgement) simply connects again: the newer socket replaces the stale
         # one, and a decision that could not be delivered (send error, no acknowledgement) puts the rank back among the
         # awaited ones instead of leaving it to time out.
-        peers, flags, confirmed = {}, {0: bool(usable)}, set()
+        # unacked: ranks whose decision was SENT without error but whose acknowledgement did not come within the socket
+        # timeout (a peer that closed without acknowledging is different: it never read the decision).  They count as served -- the rank has most likely returned already and will never connect
+        # again, so waiting for it would time the job out while the others hang in ncclCommInitRank -- but if such a rank does
+        # come back before the last rank is served, it is served again.
+        peers, flags, confirmed, unacked = {}, {0: bool(usable)}, set(), set()
         decision, payload = None, b""
         try:
             while len(confirmed) < world - 1:
@@ -148,7 +155,7 @@ def rendezvous(rank, world, usable, make_payload, timeout_s=120.0, addr=None, ba
                     except socket.timeout:
                         raise TimeoutError(f"rccl rendezvous: {world - 1 - len(peers) - len(confirmed)} rank(s) never arrived") from None
                     try:
-                        conn.settimeout(10.0)
+                        conn.settimeout(_CONN_TIMEOUT_S)
                         if _recv_exact(conn, len(token)) != token:
                             conn.close()          # not one of this launch's ranks
                             continue
@@ -157,7 +164,10 @@ def rendezvous(rank, world, usable, make_payload, timeout_s=120.0, addr=None, ba
                     except (OSError, ConnectionError, struct.error):
                         conn.close()
                         continue
-                    if 0 < r < world and r not in confirmed:
+                    if 0 < r < world and (r not in confirmed or r in unacked):
+                        if r in unacked:          # it did not get the decision after all
+                            unacked.discard(r)
+                            confirmed.discard(r)
                         if r in peers:
                             peers[r].close()
                         peers[r] = conn
@@ -170,11 +180,17 @@ def rendezvous(rank, world, usable, make_payload, timeout_s=120.0, addr=None, ba
                 for r, conn in list(peers.items()):
                     try:
                         conn.sendall(struct.pack("<BI", 1 if decision else 0, len(payload)) + payload)
-                        if _recv_exact(conn, 1) != b"K":
-                            raise ConnectionError("no acknowledgement")
-                        confirmed.add(r)
                     except (OSError, ConnectionError):
-                        pass                      # the rank connects again (or the deadline passes)
+                        pass                      # not delivered: the rank connects again (or the deadline passes)
+                    else:
+                        try:
+                            if _recv_exact(conn, 1) == b"K":
+                                confirmed.add(r)
+                        except socket.timeout:
+                            confirmed.add(r)      # sent, the acknowledgement late: served unless it comes back (see above)
+                            unacked.add(r)
+                        except (OSError, ConnectionError):
+                            pass                  # the peer closed without acknowledging: it never read the decision and connects again
                     conn.close()
                     del peers[r]
         finally:
