@@ -242,6 +242,32 @@ TDM_API int tdm_channelise_batch(const void *iq, int32_t in_fmt, int64_t n_in, i
                                  int32_t D, float *out, int64_t out_pitch, int64_t *n_out,
                                  int32_t device_pointers, int32_t device);
 
+/* ---- occupancy gate of the wideband chain (many-carrier form) ------------------------------------
+ * Which channel rows of tdm_channelise_batch's output carry a signal: the decision CaptureThread.run makes before it calls
+ * process() (tetraear/ui/modern.py:1921-2003), per channel row at the channel rate -- Hann-windowed FFT of the row's first
+ * 256 samples, power = 20 log10(|X|/N + 1e-20) (:1926-1934), signal_power / peak_power = mean / max over the bins within
+ * 25 kHz around the centre (:1948-1957), occupied = snr > snr_db and peak_power > min_dbfs and peak_power - signal_power > 3
+ * (:1992-1995; the reference: 15 dB, -70 dBFS) -- with the noise floor taken as the MEDIAN of signal_power over the stream's
+ * M channels (the reference's floor, the bins outside the centre channel, would count neighbouring carriers as noise).
+ * Definition: oracle/pfb_np.py occupancy().
+ *   chan      [n_streams * M][pitch] cf32 channel rows (n_out >= 256 valid samples each), chan_rate their sample rate
+ *   stats     [rows][2] float: signal_power, peak_power in dBFS;  flags [rows] 1 = occupied
+ *   row_list  [rows] int32: the occupied rows (no particular order), n_rows [1] their number
+ *   n_soft    [rows] or NULL: set to 0 for the rows that are NOT occupied (so that a download after
+ *             tdm_process_device_rows reads "no symbols" there)
+ * device_pointers != 0: everything is device memory and the two launches are asynchronous on the current stream
+ * (tdm_set_stream) -- row_list / n_rows then feed tdm_process_device_rows without a host round trip.                      */
+TDM_API int tdm_occupancy_gate(const float *chan, int64_t pitch, int32_t n_streams, int32_t M, int64_t n_out,
+                               double chan_rate, double snr_db, double min_dbfs, float *stats, uint8_t *flags,
+                               int32_t *row_list, int32_t *n_rows, int32_t *n_soft, int32_t device_pointers, int32_t device);
+/* tdm_process_device over the listed rows only (TDM_MODE_TETRA plans): row_list / n_rows are DEVICE memory (the gate's
+ * outputs); row r of the batch is read from iq + r * carrier_stride_samples and written to row r of the outputs exactly as
+ * tdm_process_device would -- rows that are not listed are not touched.  Replaces the reference's "process() only when a
+ * signal is present" (ui/modern.py:2016-2022) for many carriers.                                                          */
+TDM_API int tdm_process_device_rows(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, const int32_t *row_list,
+                                    const int32_t *n_rows, uint8_t *hard, float *soft, int32_t *n_soft,
+                                    int32_t *timing_milli, double *min_margin, void *stream);
+
 /* ---- device memory helpers for callers without a HIP binding (bench, tests) ---------------- */
 TDM_API int tdm_dev_alloc(int32_t device, size_t bytes, void **ptr);
 TDM_API int tdm_dev_free(int32_t device, void *ptr);

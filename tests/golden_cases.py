@@ -46,3 +46,29 @@ def case_c128(c):
 # (constant-envelope input: all phase powers equal to ~1e-16).  Any reordering of the
 # arithmetic may legitimately pick another phase; they are checked phase-agnostically.
 TIMING_DEGENERATE = {"zeros_2400", "dc_2400"}
+
+
+# ---- input-dtype corners of process() (tests/golden/make_golden_dtypes.py -> dtypes.npz): name -> (fs, freq_offset)
+DTYPE_CASES = {
+    "c64_dqpsk_2400_64k": (2.4e6, 0.0), "c64_noise_2400_32k_off": (2.4e6, 1171.875), "c64_noise_1800_20k": (1.8e6, -3515.625),
+    "c64_noise_225_5k": (0.225e6, 500.0), "f64_noise_2400_32k": (2.4e6, 0.0), "f64_noise_2400_32k_off": (2.4e6, 1171.875),
+    "f64_tone_1800_20k": (1.8e6, 0.0), "f32_noise_2400_32k_off": (2.4e6, 1171.875),
+}
+
+
+def dtype_case_input(name):
+    """the array handed to process() in a dtype-corner case (seeded: the generator and the tests build the same input)"""
+    if name == "c64_dqpsk_2400_64k":
+        return synth.cu8_to_c128(synth.dqpsk_cu8(65536, 2.4e6, seed=11)[0]).astype(np.complex64)
+    if name == "c64_noise_2400_32k_off":
+        return synth.cu8_to_c128(synth.noise_cu8(32768, 5150)).astype(np.complex64)
+    if name == "c64_noise_1800_20k":
+        return synth.cu8_to_c128(synth.noise_cu8(20000, 5151)).astype(np.complex64)
+    if name == "c64_noise_225_5k":
+        return synth.cu8_to_c128(synth.noise_cu8(5000, 5152)).astype(np.complex64)
+    rng = np.random.default_rng({"f64_noise_2400_32k": 5160, "f64_noise_2400_32k_off": 5161, "f64_tone_1800_20k": 5162,
+                                 "f32_noise_2400_32k_off": 5163}[name])
+    if name == "f64_tone_1800_20k":
+        return np.cos(2 * np.pi * 4000.0 * np.arange(20000) / 1.8e6) + 0.05 * rng.standard_normal(20000)
+    x = rng.standard_normal(32768)
+    return x.astype(np.float32) if name.startswith("f32") else x

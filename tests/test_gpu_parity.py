@@ -494,3 +494,25 @@ def test_one_plan_serves_ragged_lengths():
     np.testing.assert_array_equal(ha, hb)
     assert len(P._PLANS) == 1
     print(f"second instance, same length: {dt:.3f} ms per process_cu8 call (no plan built)")
+
+
+@pytest.mark.gpu
+def test_process_dtype_corners_match_reference(SP):
+    """process() with complex64, float64 and float32 input against goldens from the imported reference
+    (tests/golden/dtypes.npz): hard decisions identical; soft symbols within 1e-10 of the reference's result for the same
+    samples as complex128 and within 5e-5 of its single-precision result; a real input without offset gives a real
+    `symbols` array, as in the reference."""
+    import os
+    from tests.golden_cases import DTYPE_CASES, GOLDEN, dtype_case_input
+    g = np.load(os.path.join(GOLDEN, "dtypes.npz"))
+    for name, (fs, foff) in DTYPE_CASES.items():
+        x = dtype_case_input(name)
+        p = SP(fs)
+        hard = p.process(x, foff)
+        np.testing.assert_array_equal(hard, g[name + "__hard"], err_msg=name)
+        soft, soft64 = g[name + "__soft"], g[name + "__soft64"]
+        scale = np.max(np.abs(soft64))
+        assert p.symbols.dtype == soft.dtype, (name, p.symbols.dtype, soft.dtype)
+        assert np.max(np.abs(p.symbols - soft64)) <= 1e-10 * scale, name
+        assert np.max(np.abs(p.symbols - soft)) <= 5e-5 * scale, name
+        p.close()

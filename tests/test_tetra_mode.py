@@ -553,3 +553,66 @@ def test_gpu_rrc_matched_filter_alone_equals_definition():
         for r in range(rows):
             ref = tetra_np.matched_filter(x[r].astype(np.complex128), h)
             assert np.max(np.abs(y[r] - ref)) < 2e-6 * np.max(np.abs(ref)), (fs, n, r)
+
+
+def test_occupancy_definition_picks_the_occupied_channels():
+    """CPU: oracle/pfb_np.occupancy (the reference's gate rule per channel row, ui/modern.py:1921-2003, with the median of
+    the channels' in-band power as noise floor) on the channeliser definition's output of a 96-channel stream: exactly the
+    transmitted channels are flagged -- also where two of them are neighbours, whose energy the reference's own floor
+    (the bins outside the centre channel) would have counted as noise."""
+    from oracle import pfb_np
+    M, D, fs = 96, 32, 2.4e6
+    ks = [0, 5, 6, 47, 90, 95]
+    n = D * (pfb_np.OCC_FFT + 8)
+    x, _ = _wideband(n, fs, ks, M, seed0=610)
+    y = pfb_np.channelise(x / 6, M, D)
+    sig, peak, occ = pfb_np.occupancy(y, M, fs / D)
+    assert sorted(np.where(occ)[0]) == ks
+    assert np.min(sig[ks]) - np.median(sig) > 18 and np.max(np.delete(sig, ks)) - np.median(sig) < 8
+    assert pfb_np.occupancy_bins(fs / D) == (128 - 42, 128 + 42)
+
+
+@pytest.mark.gpu
+def test_gpu_occupancy_gate_matches_definition_and_gated_receiver_equals_ungated_rows():
+    """tdm_occupancy_gate on the channeliser's rows: statistics within 0.01 dB of the definition and the same flags; then
+    WidebandReceiver(gated=True) -- channeliser -> gate -> receiver over the listed rows, all on the device -- gives, on every
+    occupied row, bit for bit what the ungated chain gives there (hard decisions, soft symbols, timing, margin), reports no
+    symbols on the others, and the occupied rows are the transmitted channels."""
+    from oracle import pfb_np
+    from tetraear_amd.channeliser import channelise
+    from tetraear_amd.gate import occupancy_gate
+    from tetraear_amd.wideband import WidebandReceiver
+    for M, D, fs, n, ks in ((96, 32, 2.4e6, 65536, [[0, 5, 6, 47, 90, 95], [3, 49]]),
+                            (400, 125, 10e6, 125 * 1500, [[0, 1, 57, 133, 199, 201, 310, 398, 399], [7, 200, 201, 202]])):
+        xs = []
+        for si, kk in enumerate(ks):
+            x, _ = _wideband(n, fs, kk, M, seed0=640 + 20 * si)
+            xs.append((x / (2.0 * np.sqrt(len(kk) + 1.0))).astype(np.complex64))
+        y = np.concatenate([channelise(x, "cf32", M, D) for x in xs])          # [2 M][n_out]
+        sig, peak, occ, rows = occupancy_gate(y, M, fs / D)
+        rsig, rpeak, rocc = pfb_np.occupancy(y, M, fs / D)
+        assert np.max(np.abs(sig - rsig)) < 0.01 and np.max(np.abs(peak - rpeak)) < 0.01
+        np.testing.assert_array_equal(occ, rocc)
+        want = sorted(si * M + k for si, kk in enumerate(ks) for k in kk)
+        assert list(rows) == want and sorted(np.where(occ)[0]) == want
+        # the chain on the device, gated against ungated
+        both = []
+        for gated in (False, True):
+            rx = WidebandReceiver(fs, n, M, D, streams=2, fmt="cf32", gated=gated)
+            rx.d_in.upload(np.concatenate(xs))
+            rx.enqueue()
+            rx.sync()
+            both.append(rx.demod.download())
+            if gated:
+                gs, gp, go = rx.occupancy()
+                np.testing.assert_array_equal(go.reshape(-1), occ)
+            rx.close()
+        (h0, s0, n0, t0, m0), (h1, s1, n1, t1, m1) = both
+        for r in range(2 * M):
+            if r in want:
+                assert n1[r] == n0[r] and n0[r] > 100
+                np.testing.assert_array_equal(h1[r, :n0[r] - 1], h0[r, :n0[r] - 1])
+                np.testing.assert_array_equal(s1[r, :n0[r]], s0[r, :n0[r]])
+                assert t1[r] == t0[r] and m1[r] == m0[r]
+            else:
+                assert n1[r] == 0

@@ -60,6 +60,8 @@ SIGNATURES = {
     "tdm_find_sync": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp, _i32, _i32]),
     "tdm_channelise": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _vp, _P(_i64), _i32, _i32]),
     "tdm_channelise_batch": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _P(_i64), _i32, _i32]),
+    "tdm_occupancy_gate": (C.c_int, [_vp, _i64, _i32, _i32, _i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
+    "tdm_process_device_rows": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_hbm_ceiling": (C.c_int, [_i32, _sz, _i32, _P(_f64)]),
     "tdm_host_register": (C.c_int, [_i32, _vp, _sz]),
     "tdm_host_unregister": (C.c_int, [_i32, _vp]),

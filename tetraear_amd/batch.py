@@ -154,6 +154,14 @@ class BatchDemodulator:
                                           d["foff"].ptr if d["use_foff"] else None, d["hard"].ptr, d["soft"].ptr,
                                           d["n_soft"].ptr, d["bp"].ptr, d["mm"].ptr, None))
 
+    def enqueue_rows(self, row_list_ptr, n_rows_ptr, iq_ptr=None, stride=None):
+        """One pass over the LISTED rows only (TDM_MODE_TETRA; tdm_process_device_rows): row_list / n_rows are device
+        buffers, e.g. the occupancy gate's outputs; rows that are not listed are not touched."""
+        d = self._dev
+        check(self.lib.tdm_process_device_rows(self.handle, iq_ptr if iq_ptr is not None else d["iq"].ptr,
+                                               self.n_samples if stride is None else int(stride), row_list_ptr, n_rows_ptr,
+                                               d["hard"].ptr, d["soft"].ptr, d["n_soft"].ptr, d["bp"].ptr, d["mm"].ptr, None))
+
     def enqueue_rrc_filter(self, y_buf, y_pitch, iq_ptr=None, stride=None):
         """TETRA-mode plans: the RRC matched filter alone over the resident batch (tdm_plan_rrc_filter; asynchronous):
         y_buf = DeviceBuffer of n_carriers x y_pitch complex64"""

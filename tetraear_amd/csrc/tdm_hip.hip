@@ -26,6 +26,7 @@
 #include "pfb_kernels.hpp"
 #include "gate_kernels.hpp"
 #include "detect_kernels.hpp"
+#include "occupancy_kernels.hpp"
 
 using namespace tdm;
 
@@ -872,11 +873,13 @@ int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info)
     return TDM_OK;
 }
 
-int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, const double *pre_shift_hz,
-                       const double *freq_offset_hz, uint8_t *hard, double *soft, int32_t *n_soft,
-                       int32_t *best_phase, double *min_margin, void *stream)
+static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, const double *pre_shift_hz,
+                               const double *freq_offset_hz, uint8_t *hard, double *soft, int32_t *n_soft,
+                               int32_t *best_phase, double *min_margin, void *stream, const int32_t *row_list, const int32_t *n_rows)
 {
     if (!plan || !iq || !hard || !soft || !n_soft) return fail(TDM_ERR_INVALID, "null argument");
+    if (row_list && plan->mode != TDM_MODE_TETRA)
+        return fail(TDM_ERR_UNSUPPORTED, "a row list is taken by TDM_MODE_TETRA plans (the feed-forward receiver: one workgroup per carrier)");
     if (carrier_stride_samples < 0) return fail(TDM_ERR_INVALID, "negative carrier stride");
     HIP_TRY(hipSetDevice(plan->device));
     HipBackend be;
@@ -921,7 +924,7 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
             // one kernel: matched filter, timing, Farrow, carrier-offset estimate and decisions; one workgroup per carrier
             HipBackend::Scope s(be, ST_TETRA);
             if (!tetra_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, hard, n_soft, best_phase,
-                              min_margin, be.stream))
+                              min_margin, be.stream, row_list, n_rows))
                 return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
         }
         if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
@@ -942,6 +945,23 @@ int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_sa
     run_ref(be, v.h, plan->rows, plan->fmt, B, io);
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
     return TDM_OK;
+}
+
+int tdm_process_device(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, const double *pre_shift_hz,
+                       const double *freq_offset_hz, uint8_t *hard, double *soft, int32_t *n_soft,
+                       int32_t *best_phase, double *min_margin, void *stream)
+{
+    return process_device_impl(plan, iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase,
+                               min_margin, stream, nullptr, nullptr);
+}
+
+int tdm_process_device_rows(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, const int32_t *row_list,
+                            const int32_t *n_rows, uint8_t *hard, float *soft, int32_t *n_soft, int32_t *timing_milli,
+                            double *min_margin, void *stream)
+{
+    if (!row_list || !n_rows) return fail(TDM_ERR_INVALID, "null row list");
+    return process_device_impl(plan, iq, carrier_stride_samples, nullptr, nullptr, hard, (double *)soft, n_soft, timing_milli,
+                               min_margin, stream, row_list, n_rows);
 }
 
 int tdm_plan_rrc_filter(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, float *y, int64_t y_pitch, void *stream)
@@ -2062,6 +2082,69 @@ int tdm_channelise_batch(const void *iq, int32_t in_fmt, int64_t n_in, int32_t n
     }
     if (rc) return rc;
     if (!device_pointers) HIP_TRY(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+    return TDM_OK;
+}
+
+int tdm_occupancy_gate(const float *chan, int64_t pitch, int32_t n_streams, int32_t M, int64_t n_out, double chan_rate,
+                       double snr_db, double min_dbfs, float *stats, uint8_t *flags, int32_t *row_list, int32_t *n_rows,
+                       int32_t *n_soft, int32_t device_pointers, int32_t device)
+{
+    if (!chan || !stats || !flags || !row_list || !n_rows || n_streams < 1 || M < 4 || M > kOccMaxM || !(chan_rate > 0))
+        return fail(TDM_ERR_INVALID, "bad argument");
+    if (n_out < kOccFft || pitch < kOccFft)
+        return fail(TDM_ERR_UNSUPPORTED, "the occupancy gate looks at the first 256 samples of every channel row");
+    int rc = use_device(device);
+    if (rc) return rc;
+    const int64_t rows = (int64_t)n_streams * M;
+    if (rows > (int64_t(1) << 30)) return fail(TDM_ERR_INVALID, "too many rows");
+    // the 25 kHz around the centre in bins of chan_rate / 256 (ui/modern.py:1948-1953)
+    const int bandwidth_bins = (int)(25000.0 / (chan_rate / kOccFft));
+    OccArgs A{};
+    A.bin_lo = std::max(0, kOccFft / 2 - bandwidth_bins / 2);
+    A.bin_hi = std::min(kOccFft, kOccFft / 2 + bandwidth_bins / 2);
+    if (A.bin_hi <= A.bin_lo) return fail(TDM_ERR_INVALID, "channel rate too high for a 25 kHz band of 256-point bins");
+    DevBuf dch, dst, dfl, dli, dn, dns;
+    hipStream_t st = device_pointers ? g_cur_stream : nullptr;
+    A.chan = (const float2 *)chan;
+    A.pitch = pitch;
+    A.rows = (int32_t)rows;
+    A.stats = (float2 *)stats;
+    OccListArgs L{};
+    L.flags = flags;
+    L.row_list = row_list;
+    L.n_rows = n_rows;
+    L.n_soft = n_soft;
+    if (!device_pointers) {
+        if ((rc = dch.alloc((size_t)rows * kOccFft * 8)) || (rc = dst.alloc((size_t)rows * 8)) || (rc = dfl.alloc((size_t)rows)) ||
+            (rc = dli.alloc((size_t)rows * 4)) || (rc = dn.alloc(4)) || (n_soft && (rc = dns.alloc((size_t)rows * 4))))
+            return rc;
+        HIP_TRY(hipMemcpy2D(dch.p, kOccFft * 8, chan, pitch * 8, kOccFft * 8, rows, hipMemcpyHostToDevice));
+        if (n_soft) HIP_TRY(hipMemcpy(dns.p, n_soft, (size_t)rows * 4, hipMemcpyHostToDevice));
+        A.chan = dch.as<float2>();
+        A.pitch = kOccFft;
+        A.stats = dst.as<float2>();
+        L.flags = dfl.as<uint8_t>();
+        L.row_list = dli.as<int32_t>();
+        L.n_rows = dn.as<int32_t>();
+        L.n_soft = n_soft ? dns.as<int32_t>() : nullptr;
+    }
+    L.stats = A.stats;
+    L.M = M;
+    L.snr_db = (float)snr_db;
+    L.min_dbfs = (float)min_dbfs;
+    L.peak_db = 3.0f;
+    HIP_TRY(hipMemsetAsync(L.n_rows, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_occ_spectrum, dim3((unsigned)((rows + kOccRowsPerWg - 1) / kOccRowsPerWg)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_occ_list, dim3((unsigned)n_streams), dim3(256), 0, st, L);
+    HIP_TRY(hipGetLastError());
+    if (!device_pointers) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(stats, dst.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(flags, dfl.p, (size_t)rows, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(row_list, dli.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(n_rows, dn.p, 4, hipMemcpyDeviceToHost));
+        if (n_soft) HIP_TRY(hipMemcpy(n_soft, dns.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    }
     return TDM_OK;
 }
 

@@ -153,7 +153,8 @@ template <int NT>
 __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fused(const float2 *__restrict__ x, int64_t in_stride,
                                                               const TetraParams P, float2 *__restrict__ soft,
                                                               uint8_t *__restrict__ hard, int32_t *n_soft,
-                                                              int32_t *timing_milli, double *min_margin)
+                                                              int32_t *timing_milli, double *min_margin,
+                                                              const int32_t *__restrict__ row_list, const int32_t *__restrict__ n_rows)
 {
     static_assert(kRrcPerThread == 8 && kRrcThreads % 64 == 0 && kTimingBlock == 256, "a wavefront owns two timing sub-blocks of a tile");
     static_assert(kRing % kTimingBlock == 0 && kRing - kRrcTile - kTimingBlock * (2 * kTimingHalfWin + 1) / 2 >= kTimingBlock / 2, "ring too short");
@@ -180,7 +181,13 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     __shared__ float delta_s;
     __shared__ float sc_s;        // power-of-two scale of the differential products (formed in the first round)
     __shared__ int slow_s;        // a symbol took the direct path: the final passes run from the stored soft symbols
-    const int row = blockIdx.x;
+    // row_list (the wideband chain's occupancy gate, occupancy_kernels.hpp): workgroup i takes row row_list[i] of the batch
+    // -- input row, output rows and all -- and the workgroups past the list's length leave at once
+    int row = blockIdx.x;
+    if (row_list) {
+        if (row >= *n_rows) return;
+        row = row_list[row];
+    }
     const int tid = threadIdx.x;
     const int n = P.n;
     const double sps = P.sps;

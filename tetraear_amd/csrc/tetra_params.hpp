@@ -53,8 +53,11 @@ struct TetraParams {
 #ifdef TDM_TETRA_TIMING
 void tetra_timing_dump();
 #endif
+// row_list / n_rows (device, or null): the launch covers the rows listed -- workgroup i takes row row_list[i], workgroups
+// past *n_rows leave at once -- instead of all `rows`
 bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, uint8_t *hard,
-                  int32_t *n_soft, int32_t *timing_milli, double *min_margin, hipStream_t stream);
+                  int32_t *n_soft, int32_t *timing_milli, double *min_margin, hipStream_t stream, const int32_t *row_list = nullptr,
+                  const int32_t *n_rows = nullptr);
 
 // TDM_MODE_TETRA_GARDNER (tetra_gardner_kernels.hpp): the three launches, each on its own so that the caller can time them.
 // y: [rows][y_pitch] cf32 matched-filter output (y_pitch even, >= tp.n); false when no kernel is instantiated for tp.ntaps

@@ -140,12 +140,22 @@ class SignalProcessor:
         if len(samples) == 0:
             self.symbols = np.array([], dtype=complex)
             return np.array([], dtype=np.uint8)
+        # Input dtypes (the reference follows its input's dtype through scipy.signal.decimate, processor.py:254, which casts
+        # the SOS to x.dtype): complex128 -- what pyrtlsdr hands over -- is the reference's own arithmetic, term for term.
+        # complex64 / float32 input the reference decimates in SINGLE precision (everything behind the decimator is double
+        # again); here every dtype is computed in fp64: the result is the reference's result for the same samples handed
+        # over as complex128, which its own single-precision pass approximates to 1e-5 (hard decisions equal on the
+        # goldens of tests/golden/dtypes.npz, soft within 5e-5).  A REAL array stays real in the reference when
+        # freq_offset == 0: `symbols` is then a float64 array here too.
         a = np.asarray(samples)
         if a.dtype == np.complex64:
             fmt, x = FMT_CF32, np.ascontiguousarray(a)
         else:
             fmt, x = FMT_CF64, np.ascontiguousarray(a, dtype=np.complex128)
-        return self._run(x, fmt, len(x), freq_offset)
+        hard = self._run(x, fmt, len(x), freq_offset)
+        if not np.iscomplexobj(a) and freq_offset == 0:
+            self.symbols = np.ascontiguousarray(self.symbols.real)
+        return hard
 
     def process_cu8(self, iq_bytes, freq_offset=0):
         """process() fed with raw RTL-SDR bytes (interleaved uint8 I,Q) instead of the complex128

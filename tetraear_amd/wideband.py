@@ -21,7 +21,8 @@ class WidebandReceiver:
     """`streams` wideband streams of `n_in` samples at `sample_rate` -> M channels each, spaced
     sample_rate/M and decimated by D (channel rate sample_rate/D), all demodulated per call."""
 
-    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0, slots=1, group=None, mode=MODE_TETRA):
+    def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0, slots=1, group=None, mode=MODE_TETRA,
+                 gated=False, snr_db=15.0, min_dbfs=-70.0):
         """mode: MODE_TETRA (feed-forward timing, the default) or MODE_TETRA_GARDNER (Gardner detector + loop) for the channels'
         demodulation.
 
@@ -37,6 +38,12 @@ class WidebandReceiver:
         self.lib = _lib.load()
         self.fmt = _FMT_OF[fmt]
         self.device = device
+        # gated: the reference demodulates only when its gate sees a signal (ui/modern.py:1921-2022).  For a channeliser's
+        # rows: tdm_occupancy_gate decides on the device which rows are occupied and the receiver is launched over those
+        # rows only (tdm_process_device_rows); the other rows report no symbols.  (TDM_MODE_TETRA, group == streams.)
+        self.gated, self.snr_db, self.min_dbfs = bool(gated), float(snr_db), float(min_dbfs)
+        if self.gated and (mode != MODE_TETRA or group):
+            raise ValueError("gated: the feed-forward receiver (MODE_TETRA) over the whole batch")
         self.sample_rate, self.n_in, self.M, self.D, self.streams = float(sample_rate), int(n_in), int(M), int(D), int(streams)
         self.n_out = (self.n_in + self.D - 1) // self.D
         self.pitch = aligned_pitch(self.n_out)
@@ -52,6 +59,10 @@ class WidebandReceiver:
             if self.group == self.streams:
                 demod.alloc_device_io()
             self.slots.append((d_ch, demod))
+            if self.gated:
+                rows = self.streams * self.M
+                demod.occ = {"stats": DeviceBuffer(device, rows * 8), "flags": DeviceBuffer(device, rows),
+                             "rows": DeviceBuffer(device, rows * 4), "n": DeviceBuffer(device, 4)}
         self.d_ch, self.demod = self.slots[0]
         self.out = None
         if self.group != self.streams:
@@ -91,7 +102,14 @@ class WidebandReceiver:
         try:
             check(self.lib.tdm_channelise_batch((d_in or self.d_in).ptr, self.fmt, self.n_in, self.streams, self.M, self.D,
                                                 d_ch.ptr, self.pitch, C.byref(no), 1, self.device))
-            demod.enqueue(iq_ptr=d_ch.ptr, stride=self.pitch)
+            if self.gated:
+                o = demod.occ
+                check(self.lib.tdm_occupancy_gate(d_ch.ptr, self.pitch, self.streams, self.M, self.n_out, self.sample_rate / self.D,
+                                                  self.snr_db, self.min_dbfs, o["stats"].ptr, o["flags"].ptr, o["rows"].ptr,
+                                                  o["n"].ptr, demod._dev["n_soft"].ptr, 1, self.device))
+                demod.enqueue_rows(o["rows"].ptr, o["n"].ptr, iq_ptr=d_ch.ptr, stride=self.pitch)
+            else:
+                demod.enqueue(iq_ptr=d_ch.ptr, stride=self.pitch)
         finally:
             demod.release_stream()
 
@@ -131,6 +149,14 @@ class WidebandReceiver:
         soft = o["soft"].download(np.complex64, rows * ms).reshape(rows, ms)
         return hard, soft, n_soft, o["bp"].download(np.int32, rows), o["mm"].download(np.float64, rows)
 
+    def occupancy(self, slot=0):
+        """(gated receivers, after a sync) the gate's outputs of the slot's last batch: signal_power and peak_power in dBFS
+        [streams][M], occupied [streams][M] bool"""
+        o = self.slots[slot][1].occ
+        rows, shape = self.streams * self.M, (self.streams, self.M)
+        st = o["stats"].download(np.float32, rows * 2).reshape(rows, 2)
+        return st[:, 0].reshape(shape), st[:, 1].reshape(shape), o["flags"].download(np.uint8, rows).astype(bool).reshape(shape)
+
     def sync(self):
         for _, demod in self.slots:
             demod.sync()
@@ -141,6 +167,8 @@ class WidebandReceiver:
 
     def close(self):
         for d_ch, demod in self.slots:
+            for b in getattr(demod, "occ", {}).values():
+                b.free()
             demod.close()
             d_ch.free()
         self.slots = []
