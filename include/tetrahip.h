@@ -101,8 +101,6 @@ TDM_API int tdm_last_error(char *buf, size_t buflen);
  *   "no_raw"          1: reference-mode cu8 plans created from now on never take the raw-byte decimator       (default 0)
  *   "raw_min_blocks"  >= 0: decimator blocks below which a batch stays on the double-based kernel, for plans
  *                     created from now on                                                                   (default -1: 8 per CU)
- *   "row_walk"        low-rate stage of reference mode: 0 one workgroup per chunk and a finish launch, 1 the row-walking
- *                     kernel (carries + stage + finish in one persistent launch; bit-identical, measured slower)  (default 0)
  *   "gardner_fused"   0: TDM_MODE_TETRA_GARDNER as three launches (matched filter -> HBM -> loop -> decisions)  (default 1)
  *   "pfb_direct"      1: channeliser plans created from now on use the direct-DFT kernel                     (default 0)
  *   "pfb_rounds"      > 0: rounds per channeliser workgroup, for plans created from now on                  (default 0: computed)

@@ -161,8 +161,6 @@ void run_group(int nt, F fn)
     for (auto &x : th) x.join();
 }
 
-static bool g_row_walk = false;   // tests: the low-rate stage in its row-walking form
-
 struct EmuBackend {
     template <int K, int NSEC, int L, int EDGE, class Loader>
     void zp_block(const ZpParams &P, Loader ld, int nb, int rows)
@@ -206,19 +204,6 @@ struct EmuBackend {
                     EmuWgComm cm{g, t};
                     lp2_body(P, src, cm, c, row);
                 });
-    }
-    // the row-walking form (lp2_row_body): one "workgroup" takes a whole row through carries, low-rate stage and finish
-    bool lp2_row_walk(int) { return g_row_walk; }
-    template <class Src>
-    void lp2_row(const Lp2Params &P, const Src &src, const FinishArgs &fa, int rows)
-    {
-        const Lp2RowOut out{fa.soft, fa.hard, fa.n_soft, fa.best_phase, fa.min_margin, fa.max_soft};
-        for (int row = 0; row < rows; ++row)
-            run_group(kLp2Lanes, [&](int t, Group *g) {
-                EmuWgComm cm{g, t};
-                EmuBlockComm bc{g, t};
-                lp2_row_body(P, src, out, cm, bc, row);
-            });
     }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
@@ -331,8 +316,6 @@ int64_t emu_tetra_tap_operands(const float *taps, int ntaps, uint32_t *out)
 void emu_allow_parallel_form(int on) { g_allow_pz = on != 0; }
 // tests: 0 keeps cu8 plans on the kernel that holds its samples as doubles
 void emu_allow_raw_integer(int on) { g_allow_raw = on != 0; }
-// tests: 1 runs the low-rate stage in its row-walking form (one workgroup per row: carries, stage, finish)
-void emu_row_walk(int on) { g_row_walk = on != 0; }
 
 // whole pipeline == tdm_process with host pointers
 int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq, int64_t stride,

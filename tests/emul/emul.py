@@ -43,19 +43,6 @@ def process(sample_rate, iq, fmt, n, rows=1, stride=None, pre_shift=None, freq_o
     return hard, soft, n_soft, bp, mm
 
 
-class row_walk:
-    """`with emul.row_walk(): ...` -- the low-rate stage in its row-walking form (lp2_row_body: one workgroup per row
-    forms the carries, walks the chunks and finishes the row)."""
-
-    def __enter__(self):
-        lib().emu_row_walk(1)
-        return self
-
-    def __exit__(self, *exc):
-        lib().emu_row_walk(0)
-        return False
-
-
 def zp_stage(kind, x, q=10, bandwidth=25000.0, fs=240000.0):
     L = lib()
     x = np.ascontiguousarray(x, dtype=np.complex128)

@@ -163,41 +163,3 @@ def test_emul_random_lengths_and_rates_vs_oracle():
         if ns:
             assert np.max(np.abs(soft[0, :ns] - ref.symbols)) <= 1e-10 * (np.max(np.abs(ref.symbols)) or 1.0), (fs, n, f)
 
-
-ROW_CASES = ["kat_2400_f0", "kat_2400_f1171", "dqpsk_2400_128k_off", "dqpsk_1800_64k", "rate_2048k", "rate_225k", "rate_900k", "rate_10000k",
-             "edge_2400_n300", "edge_2400_n4097", "edge_2400_n65537", "edge_225_n5000", "mc8_k3", "gauss_c128", "zeros_2400"]
-
-
-@pytest.mark.parametrize("name", [n for n in ROW_CASES if n in CASES])
-def test_emul_row_walk_equals_chunk_form(name, gold_process):
-    """The row-walking low-rate kernel (one workgroup per row: block carries, chunks with the next chunk's loads in
-    flight, finish) against the golden vectors, and bit for bit against the form with one workgroup per chunk and
-    separate carry / finish launches: same arithmetic, same order."""
-    c = CASES[name]
-    args = dict(freq_offset=[c["foff"]])
-    if c["kind"] == "c128":
-        x, fmt = case_c128(c), "cf64"
-    else:
-        x, fmt = case_cu8(c), "cu8"
-        if "pre_shift" in c:
-            args["pre_shift"] = [c["pre_shift"]]
-    a = emul.process(c["fs"], x, fmt, c["n"], **args)
-    with emul.row_walk():
-        b = emul.process(c["fs"], x, fmt, c["n"], **args)
-    check(name, b[0], b[1], b[2], gold_process)
-    for u, v in zip(a, b):
-        np.testing.assert_array_equal(u, v)
-
-
-def test_emul_row_walk_multirow():
-    """three rows of one shared stream with their own shifts, row-walking form against the chunk form"""
-    from tetraear_amd import synth
-    n = 30000
-    u8 = synth.noise_cu8(n, 77)
-    shifts = [-25000.0, 0.0, 37500.0]
-    foffs = [0.0, 1171.875, -500.0]
-    a = emul.process(2.4e6, u8, "cu8", n, rows=3, stride=0, pre_shift=shifts, freq_offset=foffs)
-    with emul.row_walk():
-        b = emul.process(2.4e6, u8, "cu8", n, rows=3, stride=0, pre_shift=shifts, freq_offset=foffs)
-    for u, v in zip(a, b):
-        np.testing.assert_array_equal(u, v)

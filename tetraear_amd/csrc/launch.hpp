@@ -20,12 +20,6 @@ void launch_pz_raw(const ZpParams &P, const void *iq, int64_t stride, int b_tail
 // low-rate stage in one kernel (lp2_kernels.hpp)
 template <class Src>
 void launch_lp2(const Lp2Params &P, const Src &src, int rows, hipStream_t st);
-// ... in its row-walking form (carries + low-rate stage + finish in one persistent kernel); slots = workgroups of it the
-// device holds at once (lp2_row_slots, cached per device)
-template <class Src>
-void launch_lp2_row(const Lp2Params &P, const Src &src, const FinishArgs &fa, int rows, int slots, hipStream_t st);
-template <class Src>
-int lp2_row_slots(int device);
 
 #ifdef TDM_ZP_TIMING
 void zp_timing_dump();

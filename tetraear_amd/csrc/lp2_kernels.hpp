@@ -44,10 +44,6 @@ extern __device__ unsigned long long g_lp2_dbg[16];
 #define TDM_SCHED_FENCE() do { } while (0)
 #endif
 
-// (TDM_OPAQUE_V, pz_kernels.hpp: a value the compiler must take as new wherever it stands.  Inside the row-walking kernel's
-// chunk loop everything that depends only on the thread -- staging addresses, table rows -- is otherwise hoisted out of the
-// loop and kept alive across the whole row: hundreds of spilled registers.)
-
 namespace tdm {
 
 // Staging area: one 16-byte slot per position of the workgroup's span, swizzled so that both access patterns are free of
@@ -66,8 +62,7 @@ struct Lp2Lds {
     static constexpr int kStage = 2 * kSlots;
     // small area (doubles): [0,256) wave totals and the causal state at the end of the row, [256, 256 + 40*32) power partials of the groups
     static constexpr int oTot = 0, oPow = 2 * (kLp2Lanes / 16) * kLp2Pairs * 4, kPowGroups = 39;
-    static constexpr int oNco = oPow + (kPowGroups + 1) * kMaxSps;   // the NCO's step phasor when it is formed once per row (lp2_row_body)
-    static constexpr int kSmall = oNco + 2;
+    static constexpr int kSmall = oPow + (kPowGroups + 1) * kMaxSps;
 };
 
 // ---- sample sources --------------------------------------------------------------------------------------------
@@ -78,7 +73,6 @@ struct Lp2SrcPlain {   // c128 rows already at the low rate (no decimation: k_co
     static constexpr double fs_out = 0.0;
     TDM_HD double foff(int) const { return 0.0; }
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(x + (int64_t)row * row_stride * 2); }
-    TDM_HD void row_carries(int, int) const {}
     struct Pref {};
     template <class Comm>
     TDM_HD void prefetch_words(const Lp2Params &, int, Comm &, Pref &) const {}
@@ -96,13 +90,6 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     static constexpr bool kFix = true;
     TDM_HD double foff(int row) const { return freq_offset ? freq_offset[row] : 0.0; }
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(dec.y0 + (int64_t)row * dec.n_out * 2); }
-    // the row-walking kernel forms the decimator's block carries of its row itself (thread = (block, component)): what
-    // the carry launch k_pz_carry does for all rows
-    TDM_HD void row_carries(int row, int tid) const
-    {
-        if (!dec.pform) return;
-        for (int k = tid; k < 2 * dec.nb; k += kLp2Lanes) pz_carry_body<PzLayout::kMaxPairs>(dec, row, k >> 1, k & 1);
-    }
     // The decimator's carry responses (y = y0 + T1.Gf + T2.Hb), added to the staged samples in place.  For the La
     // consecutive outputs of a group they are, per pole pair and direction, a second-order recurrence at the decimated
     // rate seeded by two table rows.  They decay from the block's ends, so only the groups near a block boundary need them,
@@ -146,15 +133,14 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     TDM_HD void prefetch_words(const Lp2Params &P, int chunk, Comm &cm, Pref &o) const
     {
         const int32_t *it = P.items + (size_t)chunk * P.items_stride;
-        int k = cm.tid();
-        TDM_OPAQUE_V(k);
+        const int k = cm.tid();
         o.w0 = it[2 + 2 * k];
         o.w1 = it[3 + 2 * k];
         o.mine = k < it[0];
     }
     TDM_HD void prefetch_operands(const Lp2Params &P, int row, Pref &o) const
     {
-        if (o.mine) item_operands(P, row, o.w0, o.w1, o.sd, o.cy);
+        if (!kLp2Lean && o.mine) item_operands(P, row, o.w0, o.w1, o.sd, o.cy);   // (lean build: requested where they are used)
     }
     // The decimator's carry responses (y = y0 + T1.Gf + T2.Hb), added to the staged samples in place.  For the La
     // consecutive outputs of a group they are, per pole pair and direction, a second-order recurrence at the decimated
@@ -222,7 +208,15 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
         constexpr int ND = PzLayout::kMaxPairs;
         const int32_t *it = P.items + (size_t)chunk * P.items_stride;
         const int cnt1 = it[0], cnt2 = it[1];
-        if (pf.mine) run_item(P, stage, pf.w0, pf.sd, pf.cy);   // (operands requested while the samples were staged)
+        if (kLp2Lean) {
+            if (pf.mine) {
+                f64x2 sdv[2 * ND], cyv[2 * ND];
+                item_operands(P, row, pf.w0, pf.w1, sdv, cyv);
+                run_item(P, stage, pf.w0, sdv, cyv);
+            }
+        } else if (pf.mine) {
+            run_item(P, stage, pf.w0, pf.sd, pf.cy);   // (operands requested while the samples were staged)
+        }
 #pragma unroll 1
         for (int k = cm.tid() + kLp2Lanes; k < cnt1; k += kLp2Lanes) {
             f64x2 sdv[2 * ND], cyv[2 * ND];
@@ -245,9 +239,7 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
 };
 
 // What a thread has in flight for a chunk before the chunk's arithmetic starts: its La samples (coalesced: sample
-// i * 64 + lane of the wavefront's run) and the operands of its first carry-response item.  lp2_body issues them at
-// the top of the chunk; the row-walking kernel (lp2_row_body) issues the NEXT chunk's while the current chunk's output
-// is still on its way out, so that the round trips pass behind the stores.
+// i * 64 + lane of the wavefront's run) and the operands of its first carry-response item.
 template <class Src>
 struct Lp2Loads {
     f64x2 v[kLp2La];
@@ -264,9 +256,7 @@ template <class Src, class Comm>
 TDM_HD void lp2_issue_samples(const Lp2Params &P, const Src &src, Comm &cm, int chunk, int row, Lp2Loads<Src> &L)
 {
     constexpr int La = kLp2La;
-    int tid = cm.tid();
-    TDM_OPAQUE_V(tid);
-    const int lane = tid & 63, wave = tid >> 6;
+    const int tid = cm.tid(), lane = tid & 63, wave = tid >> 6;
     const int64_t jc = (int64_t)chunk * P.U - P.H - P.off;   // position of lane 0's first sample
     const f64x2 *rowp = src.raw_row(row);
     const int64_t jw = jc + (int64_t)wave * (kWave * La);
@@ -287,17 +277,13 @@ TDM_HD void lp2_issue_samples(const Lp2Params &P, const Src &src, Comm &cm, int 
 }
 
 // the chunk's arithmetic: the loaded samples to LDS, carry responses, NCO, channel filter; ends with the filter output in
-// the staging area (behind a barrier).  nco_w: the NCO's step phasor in LDS (formed by the caller)
+// the staging area (behind a barrier).  nco_w: the NCO's step phasor in LDS
 template <class Src, class Comm>
 TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk, int row, Lp2Loads<Src> &L, const double *nco_w)
 {
     constexpr int La = kLp2La, NP = kLp2Pairs;
-    int tid = cm.tid();
-    TDM_OPAQUE_V(tid);
-    const int lane = tid & 63, wave = tid >> 6;
+    const int tid = cm.tid(), lane = tid & 63, wave = tid >> 6;
     const double *cst = P.cst, *lane_m = P.lane_m;
-    TDM_OPAQUE_SPTR(cst);
-    TDM_OPAQUE_SPTR(lane_m);
     const int64_t n = P.n;
     const int edge = P.edge;
     const int64_t jc = (int64_t)chunk * P.U - P.H - P.off;   // position of lane 0's first sample
@@ -374,6 +360,12 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     const bool has_head = wg_edge && (t_head >= 0 && t_head < kLp2Lanes);
     const bool has_tail = wg_edge && (n + edge - 1 - jc >= 0 && t_tail < kLp2Lanes && t_l1 >= 0);
     double e0r = 0, e0i = 0, xlr = 0, xli = 0;
+    if (kLp2Lean && !wg_edge) {
+        // (lean build: the rotated samples go back to the lane's own slots and are read again for pass 2, so that they do
+        // not sit in registers across the scans)
+#pragma unroll
+        for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{yr[i], yi[i]};
+    }
     if (wg_edge) {
     // a chunk that holds an end of the row: publish the finished samples; the odd extension (scipy odd_ext: 2 x[0] - x[-j],
     // 2 x[n-1] - x[2n-2-j]) of the lanes around the end reads them from there.  (Interior chunks -- six of the eight of a
@@ -399,6 +391,10 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
             }
         }
     }
+    if (kLp2Lean && !inside) {   // (only positions outside the row changed: nobody reads those slots through Y())
+#pragma unroll
+        for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{yr[i], yi[i]};
+    }
     if (has_head && tid == t_head) {
         const f64x2 a = Y(0), b = Y(edge);
         e0r = 2 * a.x - b.x;
@@ -417,18 +413,23 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     for (int i = 0; i < La; ++i) { or_[i] = yr[i]; oi[i] = yi[i]; }
     (void)e0r; (void)e0i; (void)xlr; (void)xli; (void)has_head; (void)lane;
 #else
-    // (requested here, used by the scans: the latency overlaps pass 1)
-    double lmf[NP][4], lmb[NP][4];   // C^(La (k+1)), k = lane's distance to the previous / next row of 16 lanes (scan)
-    {
+    // C^(La (k+1)), k = lane's distance to the previous / next row of 16 lanes: what the scans' last step multiplies with.
+    // kLp2Lean (eight-sample lanes, 128 registers): requested inside each direction's scan, not here
+    double lmf[NP][4], lmb[NP][4];
+    auto load_lm = [&](auto dir_c) __attribute__((always_inline)) {
+        constexpr int dir = decltype(dir_c)::value;
         const int r = lane & 15;
-        const f64x2 *tf = (const f64x2 *)lane_m + (size_t)r * NP * 2;
-        const f64x2 *tb = (const f64x2 *)lane_m + (size_t)(15 - r) * NP * 2;
+        const f64x2 *t = (const f64x2 *)lane_m + (size_t)(dir == 0 ? r : 15 - r) * NP * 2;
+        double(*lm)[4] = dir == 0 ? lmf : lmb;
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
-            const f64x2 a0 = tf[s * 2], a1 = tf[s * 2 + 1], c0 = tb[s * 2], c1 = tb[s * 2 + 1];
-            lmf[s][0] = a0.x; lmf[s][1] = a0.y; lmf[s][2] = a1.x; lmf[s][3] = a1.y;
-            lmb[s][0] = c0.x; lmb[s][1] = c0.y; lmb[s][2] = c1.x; lmb[s][3] = c1.y;
+            const f64x2 a0 = t[s * 2], a1 = t[s * 2 + 1];
+            lm[s][0] = a0.x; lm[s][1] = a0.y; lm[s][2] = a1.x; lm[s][3] = a1.y;
         }
+    };
+    if (!kLp2Lean) {   // (requested here, used by the scans: the latency overlaps pass 1)
+        load_lm(std::integral_constant<int, 0>{});
+        load_lm(std::integral_constant<int, 1>{});
     }
     // ---------------- pass 1: recurrences from zero state, lane end states ----------------
     double zr[NP][2], zq[NP][2];   // causal end state (w[La-1], w[La-2]), re / im
@@ -512,6 +513,7 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
         double pr[NP][2], pq[NP][2];             // state entering the row
 #pragma unroll
         for (int s = 0; s < NP; ++s) { pr[s][0] = 0; pr[s][1] = 0; pq[s][0] = 0; pq[s][1] = 0; }
+        if (kLp2Lean) load_lm(dir_c);
         double mrow[NP][4];
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
@@ -565,7 +567,16 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     };
     using D0 = std::integral_constant<int, 0>;
     using D1 = std::integral_constant<int, 1>;
-    if (!has_tail) {
+    if (!has_tail && kLp2Lean) {
+        // (lean build: one direction start to end, then the other -- a barrier more, sixteen registers fewer)
+        scan_rows(D0{});
+        cm.sync();
+        scan_apply(D0{});
+        TDM_SCHED_FENCE();
+        scan_rows(D1{});
+        cm.sync();
+        scan_apply(D1{});
+    } else if (!has_tail) {
         scan_rows(D0{});
         TDM_SCHED_FENCE();   // (one direction after the other: interleaved, their temporaries overflow the register file)
         scan_rows(D1{});
@@ -597,6 +608,14 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     }
     LP2_T(3);
     // ---------------- pass 2: recurrences from the true start states, outputs accumulated ----------------
+    if (kLp2Lean) {
+#pragma unroll
+        for (int i = 0; i < La; ++i) {
+            const f64x2 v = stage[lp2_slot(tid * La + i)];
+            yr[i] = v.x;
+            yi[i] = v.y;
+        }
+    }
     double or_[La], oi[La];
     {
         const double dx = P.dx;
@@ -642,8 +661,7 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
 template <class Comm>
 TDM_HD void lp2_store(const Lp2Params &P, Comm &cm, int chunk, int row)
 {
-    int tid = cm.tid();
-    TDM_OPAQUE_V(tid);
+    const int tid = cm.tid();
     const int64_t n = P.n;
     const int64_t jc = (int64_t)chunk * P.U - P.H - P.off;
     f64x2 *stage = (f64x2 *)cm.stage();
@@ -714,100 +732,6 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     }
     lp2_compute(P, src, cm, chunk, row, L, nco_w);
     lp2_store(P, cm, chunk, row);
-}
-
-// ---- the row-walking form: ONE workgroup takes a whole row through the stage, chunk by chunk, and finishes it ----------------
-// (batches with at least as many rows as the device holds workgroups of this kernel: every compute unit is busy with
-// whole rows).  What it changes against one workgroup per chunk + two more launches:
-//   * the decimator's block carries (pz_carry_body, the launch between the decimator and this stage) are formed by
-//     the row's own workgroup in front of its first chunk;
-//   * chunk c + 1's loads (samples and item operands) are issued when chunk c's filter output has left the registers, and
-//     their round trips pass behind chunk c's stores: the stage-in wait -- 30 % of a chunk's time when a workgroup
-//     starts cold -- is hidden;
-//   * extract_symbols' phase pick and demodulate_dqpsk (finish_body: processor.py:168-219, 102-166) run in the same
-//     workgroup behind the last chunk, on phase-major rows it wrote itself moments ago.
-// The arithmetic of a chunk is lp2_compute / lp2_store, unchanged: results are bit-identical to the three-launch path.
-//   BComm: the block-communication object of finish_body (reductions through LDS) on the same workgroup.
-#ifndef TDM_LP2_ROW_PREFETCH
-#define TDM_LP2_ROW_PREFETCH 1   // 0 (experiment): every chunk's loads at the top of the chunk, as the one-chunk kernel
-#endif
-
-// what the finish stage of a row needs beyond the low-rate stage's own parameters
-struct Lp2RowOut {
-    double *soft;          // [rows][max_soft] c128
-    uint8_t *hard;         // [rows][max_soft]
-    int32_t *n_soft;       // [rows]
-    int32_t *best_phase;   // [rows] or null
-    double *min_margin;    // [rows] or null
-    int32_t max_soft;
-};
-
-// extract_symbols' phase pick + demodulate_dqpsk of one row (finish_body) on the low-rate stage's own output; a function
-// of its own (not inlined): it runs once per row with nothing of the chunk loop alive
-template <class BComm>
-TDM_NOINLINE void lp2_row_finish(int64_t n, int sps, const double *partials, int n_chunks, const double *zt, int64_t zt_k,
-                                 const Lp2RowOut &out, BComm &bc, int row)
-{
-    FinishArgs fa{};
-    fa.n = n;
-    fa.row_stride = n;
-    fa.sps = sps;
-    fa.do_extract = 1;
-    fa.do_demod = 1;
-    fa.max_soft = out.max_soft;
-    fa.soft = out.soft;
-    fa.hard = out.hard;
-    fa.n_soft = out.n_soft;
-    fa.best_phase = out.best_phase;
-    fa.min_margin = out.min_margin;
-    fa.partials = partials;
-    fa.n_pblk = n_chunks;
-    fa.zt = zt;
-    fa.zt_k = zt_k;
-    finish_body(fa, bc, row);
-}
-
-template <class Src, class Comm, class BComm>
-TDM_HD void lp2_row_body(const Lp2Params &P, const Src &src, const Lp2RowOut &out, Comm &cm, BComm &bc, int row)
-{
-    const int tid = cm.tid();
-    double *nco_w = cm.small() + Lp2Lds::oNco;
-    if (Src::kFix) {
-        src.row_carries(row, tid);            // (reads the decimator's block end states, writes Gf / Hb of this row)
-        if ((tid >> 6) == kLp2Waves - 1) {    // the NCO's step phasor, once per row
-            const double f = src.foff(row);
-            if (f != 0.0) {
-                double wre, wim;
-                NcoRunT<1>::step_phasor(f, src.fs_out, wre, wim);
-                if ((tid & 63) == 0) { nco_w[0] = wre; nco_w[1] = wim; }
-            }
-        }
-        cm.sync();                            // the row's carries visible to the items' operand loads
-    }
-    Lp2Loads<Src> L;
-    const int nc = P.n_chunks;
-#if TDM_LP2_ROW_PREFETCH
-    lp2_issue_words(P, src, cm, 0, L);
-    lp2_issue_samples(P, src, cm, 0, row, L);
-#endif
-#pragma unroll 1
-    for (int c = 0; c < nc; ++c) {
-#if !TDM_LP2_ROW_PREFETCH
-        lp2_issue_words(P, src, cm, c, L);
-        lp2_issue_samples(P, src, cm, c, row, L);
-#endif
-        lp2_compute(P, src, cm, c, row, L, nco_w);
-#if TDM_LP2_ROW_PREFETCH
-        if (c + 1 < nc) {
-            lp2_issue_words(P, src, cm, c + 1, L);
-            lp2_issue_samples(P, src, cm, c + 1, row, L);
-        }
-#endif
-        lp2_store(P, cm, c, row);
-    }
-    cm.sync();                                // the row's phase-major output and its chunks' power sums are complete
-    lp2_row_finish(P.n, P.sps, P.partials, P.n_chunks, P.zt, P.zt_k, out, bc, row);
-    cm.sync();                                // (the small LDS area is the next row's again)
 }
 
 }  // namespace tdm

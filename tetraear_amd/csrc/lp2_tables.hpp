@@ -13,9 +13,14 @@
 namespace tdm {
 
 // -DTDM_LP2_LA=8: eight-sample lanes in eight wavefronts (the same 4096-position span and 64 KB of staging, twice the
-// threads: 16 wavefronts per compute unit if the kernel fits 128 VGPRs).  Measured on MI355X (round 3): results equal
-// (CPU lock-step emulation, oracle-pinned bench digest), but 90 VGPRs spill at the 128 cap (304 B of scratch per lane) and
-// the per-lane fixed work -- scans, item operands -- doubles: 0.658 ms against 0.331 ms.  Kept as a build switch, off.
+// threads: 16 wavefronts per compute unit if the kernel fits 128 VGPRs).  Results equal (CPU lock-step emulation, the
+// bench batch's digest).  Measured on MI355X: round 3, 81 spilled VGPRs (288 B of scratch per lane): 0.658 ms against 0.331;
+// round 5 found what made it THAT slow -- not the doubled per-lane work (1.31x the instructions per sample) but the spills
+// themselves: ~0.5 MB of scratch traffic per chunk against 128 KB of samples, from a 75 MB scratch footprint that no cache
+// holds -- and trimmed them (kLp2Lean below: the rotated samples wait in LDS between the filter passes, per-lane scan
+// matrices and item operands requested where they are used, the two scan directions one after the other): 29 spills
+// 0.404 ms, 18 spills 0.365 ms.  Still behind the sixteen-sample lanes' 0.330 ms (at zero spills the trend points to
+// ~0.30: twice the wavefronts do not pay for 1.3x the instructions and a sixth barrier).  Kept as a build switch, off.
 #ifndef TDM_LP2_LA
 #define TDM_LP2_LA 16
 #endif
@@ -36,6 +41,12 @@ constexpr bool kLp2InlineCarry = true;
 #else
 constexpr bool kLp2InlineCarry = false;
 #endif
+// lean register use (eight-sample lanes: 128 registers per lane, four wavefronts per SIMD): the rotated samples wait in LDS
+// between the two filter passes and the scans' per-lane matrices are requested where they are used
+#ifndef TDM_LP2_LEAN
+#define TDM_LP2_LEAN (TDM_LP2_LA == 8)
+#endif
+constexpr bool kLp2Lean = TDM_LP2_LEAN;
 constexpr int kLp2Pairs = 2;
 constexpr int kLp2D = 2 * kLp2Pairs;
 // what a chunk may ignore of its neighbours: the states are O(10) per unit input, so the neglected part is below 1e-20 of

@@ -14,8 +14,6 @@
 //                                           double* partials, int n_pblk);
 //   void finish(const FinishArgs&, int rows);
 //   template<class Src> void lp2_finish(const Lp2Params&, const Src&, const FinishArgs&, int rows);   (low-rate kernel, then finish)
-//   bool lp2_row_walk(int rows);    does a batch of this many rows run the row-walking low-rate kernel (lp2_row_body)?
-//   template<class Src> void lp2_row(const Lp2Params&, const Src&, const FinishArgs&, int rows);   (carries + low-rate stage + finish, one kernel)
 #pragma once
 #include "ref_plan.hpp"
 #include "zp_kernels.hpp"
@@ -83,11 +81,9 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     const bool use_raw = h.raw_S > 0 && FMT == FMT_CU8 && !SHIFT && (int64_t)rows * h.dec.p.nb >= h.raw_min_blocks;
     // (the one-kernel low-rate stage forms the block carries inside its carry-response items: no carry launch)
     const bool inline_carry = h.lp2.ok && kLp2InlineCarry;
-    // (large batches: one workgroup per ROW walks the low-rate stage and forms its row's carries and its decisions itself)
-    const bool row_walk = h.lp2.ok && be.lp2_row_walk(rows);
     if (use_raw) {
         run_pz_raw(be, h, B.dec_raw_params, io.iq, io.carrier_stride, rows);
-        if (!inline_carry && !row_walk) be.template zp_carry<2, 4>(B.dec_raw_params, h.dec_raw.p.nb, rows);
+        if (!inline_carry) be.template zp_carry<2, 4>(B.dec_raw_params, h.dec_raw.p.nb, rows);
     } else if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
         if (h.pz_S) {
@@ -96,7 +92,7 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         } else {
             be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
         }
-        if (!(inline_carry && h.pz_S) && !row_walk) be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
+        if (!(inline_carry && h.pz_S)) be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
         if (!h.lpf)  // (n_dec <= 15) nothing downstream finishes the decimator output: do it here
             be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
     } else {
@@ -126,13 +122,13 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         fa.zt_k = B.lp2.zt_k;
         if (use_raw) {
             Lp2SrcDec src{B.dec_raw_params, io.freq_offset, h.rate_dec, inline_carry ? 1 : 0};
-            row_walk ? be.lp2_row(L, src, fa, rows) : be.lp2_finish(L, src, fa, rows);
+            be.lp2_finish(L, src, fa, rows);
         } else if (h.decimated) {
             Lp2SrcDec src{B.dec_params, io.freq_offset, h.rate_dec, (inline_carry && h.pz_S) ? 1 : 0};
-            row_walk ? be.lp2_row(L, src, fa, rows) : be.lp2_finish(L, src, fa, rows);
+            be.lp2_finish(L, src, fa, rows);
         } else {
             Lp2SrcPlain src{B.y, h.n_dec};
-            row_walk ? be.lp2_row(L, src, fa, rows) : be.lp2_finish(L, src, fa, rows);
+            be.lp2_finish(L, src, fa, rows);
         }
         return;
     }

@@ -47,7 +47,6 @@ struct DebugSwitch { const char *key; std::atomic<long long> value; long long df
 static DebugSwitch g_debug[] = {
     {"no_raw", {0}, 0},                  // 1: cu8 plans made from now on never take the raw-integer decimator
     {"raw_min_blocks", {-1}, -1},        // >= 0: blocks below which a batch stays on the double-based decimator (plans made from now on)
-    {"row_walk", {0}, 0},                // low-rate stage: 0 one workgroup per chunk + finish launch, 1 the row-walking kernel (measured slower)
     {"gardner_fused", {1}, 1},           // 0: Gardner mode as three launches (matched filter -> HBM -> loop -> decisions)
     {"pfb_direct", {0}, 0},              // 1: channeliser plans made from now on use the direct-DFT kernel
     {"pfb_rounds", {0}, 0},              // > 0: rounds per channeliser workgroup (plans made from now on)
@@ -310,27 +309,6 @@ struct HipBackend {
     {
         lp2(P, src, rows);
         finish(fa, rows);
-    }
-    // The row-walking form of the low-rate stage (lp2_row_body: carries, stage and finish in one persistent kernel, a
-    // workgroup per row).  Measured on MI355X, 1024 x 262 144 (round 5): 0.49 ms (0.62 with the next chunk's loads in flight
-    // across the stores: 288 spilled registers) against 0.33 + 0.016 + 0.030 ms for one workgroup per chunk with its carry
-    // and finish launches -- 512 persistent workgroups walk their rows in step, so the chip's load, arithmetic and store
-    // phases coincide instead of overlapping, and each row's carries and finish are serial stretches of its own
-    // workgroup.  Off unless tdm_debug_set("row_walk", 1) asks for it (results are bit-identical).
-    bool lp2_row_walk(int rows)
-    {
-        const long long mode = debug_value("row_walk");
-        if (mode == 0) return false;
-        const int slots = lp2_row_slots<Lp2SrcDec>(device);
-        if (slots <= 0) return false;
-        (void)rows;
-        return mode == 1;
-    }
-    template <class Src>
-    void lp2_row(const Lp2Params &P, const Src &src, const FinishArgs &fa, int rows)
-    {
-        Scope s(*this, ST_LPF_BLOCK);
-        launch_lp2_row<Src>(P, src, fa, rows, lp2_row_slots<Src>(device), stream);
     }
     template <int K, int NSEC>
     void zp_carry(const ZpParams &P, int nb, int rows)
@@ -699,12 +677,6 @@ int tdm_debug_set(const char *key, int64_t value)
 
 int tdm_debug_get(const char *key, int64_t *value)
 {
-    if (key && value && std::strcmp(key, "lp2_row_slots") == 0) {   // (read-only: workgroups of the row-walking kernel the current device holds)
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        *value = lp2_row_slots<Lp2SrcDec>(dev);
-        return TDM_OK;
-    }
     DebugSwitch *d = debug_find(key);
     if (!d || !value) return fail(TDM_ERR_INVALID, std::string("tdm_debug_get: unknown switch '") + (key ? key : "(null)") + "'");
     *value = d->value.load(std::memory_order_relaxed);

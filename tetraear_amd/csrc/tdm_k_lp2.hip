@@ -55,48 +55,6 @@ void launch_lp2(const Lp2Params &P, const Src &src, int rows, hipStream_t st)
 {
     hipLaunchKernelGGL((k_lp2<Src>), dim3(P.n_chunks, rows), dim3(kLp2Lanes), 0, st, P, src);
 }
-// the row-walking form (lp2_row_body): one persistent workgroup per resident slot, each taking whole rows through the
-// carries, the low-rate stage and the finish
-template <class Src>
-__global__ __launch_bounds__(kLp2Lanes, kLp2Waves / 2) void k_lp2_row(const Lp2Params P, const Src src, const Lp2RowOut out, int rows)
-{
-    static_assert(kLp2Lanes == kFinishThreads, "finish_body runs on the low-rate stage's workgroup");
-    __shared__ __attribute__((aligned(16))) double stg[Lp2Lds::kStage];
-    __shared__ __attribute__((aligned(16))) double sml[Lp2Lds::kSmall];
-    WgComm cm;
-    cm.stg = stg;
-    cm.sml = sml;
-    static_assert(Lp2Lds::kSmall >= 8 + kFinishThreads, "finish_body's reduction slots");
-    BlockComm bc{sml, sml + 8};
-#pragma unroll 1
-    for (int row = (int)blockIdx.x; row < rows; row += (int)gridDim.x) lp2_row_body(P, src, out, cm, bc, row);
-}
-
-template <class Src>
-int lp2_row_slots(int device)
-{
-    static int cached[16] = {0};
-    if (device >= 0 && device < 16 && cached[device]) return cached[device];
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_lp2_row<Src>, kLp2Lanes, 0) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    const int slots = per_cu * cus;
-    if (device >= 0 && device < 16) cached[device] = slots;
-    return slots;
-}
-template int lp2_row_slots<Lp2SrcDec>(int);
-template int lp2_row_slots<Lp2SrcPlain>(int);
-
-template <class Src>
-void launch_lp2_row(const Lp2Params &P, const Src &src, const FinishArgs &fa, int rows, int slots, hipStream_t st)
-{
-    const int grid = rows < slots ? rows : slots;
-    const Lp2RowOut out{fa.soft, fa.hard, fa.n_soft, fa.best_phase, fa.min_margin, fa.max_soft};
-    hipLaunchKernelGGL((k_lp2_row<Src>), dim3(grid), dim3(kLp2Lanes), 0, st, P, src, out, rows);
-}
-template void launch_lp2_row<Lp2SrcDec>(const Lp2Params &, const Lp2SrcDec &, const FinishArgs &, int, int, hipStream_t);
-template void launch_lp2_row<Lp2SrcPlain>(const Lp2Params &, const Lp2SrcPlain &, const FinishArgs &, int, int, hipStream_t);
-
 template void launch_lp2<Lp2SrcDec>(const Lp2Params &, const Lp2SrcDec &, int, hipStream_t);
 template void launch_lp2<Lp2SrcPlain>(const Lp2Params &, const Lp2SrcPlain &, int, hipStream_t);
 
