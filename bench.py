@@ -378,6 +378,9 @@ def main():
     ap.add_argument("--shared", action="store_true",
                     help="BASELINE config 3: all carriers read ONE shared wideband stream, each shifted to baseband by its "
                          "own offset on load (process(frequency_shift(x, f_k)) per carrier)")
+    ap.add_argument("--exact-shift", action="store_true",
+                    help="--shared: the input-rate shift reproduces the reference's rounding of its phase sample by sample (the "
+                         "library's default) instead of the plan option fast_pre_shift (ideal phase ramp, exactly anchored per lane)")
     ap.add_argument("--rate", type=float, default=SAMPLE_RATE, help="sample rate (experiments; metric config is 2.4e6)")
     ap.add_argument("--total-carriers", type=int, default=0,
                     help="strong scaling: this many carriers in total, block-partitioned over the ranks (BASELINE config 4: 1024)")
@@ -441,6 +444,9 @@ def main():
     bd.sync()
     plan_create_ms = (time.perf_counter() - t_plan) * 1e3
     bd.alloc_device_io(shared_input=args.shared)
+    fast_shift = args.shared and not args.exact_shift
+    if fast_shift:
+        bd.set_fast_pre_shift()
     gen_workers = max(1, min(64, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     if args.pmc_child:
         # (the counters do not care what the bytes say: uniform noise, made in a second instead of the job's 1024 streams)
@@ -508,6 +514,11 @@ def main():
     if args.zero_foff or args.pmc_child:
         want = None
     mismatch = want is not None and digest != want
+    fast_shift_report = None
+    if fast_shift:
+        # the guard of the fast pre-shift: no carrier's smallest decision margin within reach of the phase rounding it skips
+        # (1e-8 rad is 100x that rounding), and -- below -- the digest pinned to the ORACLE's exact-phase decisions
+        fast_shift_report = {"min_margin_rad": float(np.min(mm)), "guard_rad": 1e-8, "carriers_below_guard": int(np.sum(mm < 1e-8))}
     output_check = {"key": dkey, "sha256": digest,
                     "status": "matches oracle-pinned digest" if want == digest else
                               ("not compared" if (args.zero_foff or args.pmc_child) else
@@ -540,7 +551,7 @@ def main():
         engine = 2 if (args.shared and bd.info.dec_engine == 3) else bd.info.dec_engine
         # --shared adds, per input sample, the conversion (4 flop) and the input-rate NCO that reproduces the reference's own
         # rounding of its phase (NcoRunT: Markstein quotient 10, phase 1, phasor advance 6, correction 7, rotation 6: ~35 flop)
-        exec_flop = {3: EXECUTED_FLOP_PER_INPUT_SAMPLE, 2: 105.0, 1: 266.0}.get(engine, EXECUTED_FLOP_PER_INPUT_SAMPLE) + (39.0 if args.shared else 0.0)
+        exec_flop = {3: EXECUTED_FLOP_PER_INPUT_SAMPLE, 2: 105.0, 1: 266.0}.get(engine, EXECUTED_FLOP_PER_INPUT_SAMPLE) + ((16.0 if fast_shift else 39.0) if args.shared else 0.0)
         executed_tf = samples_per_launch * exec_flop / (k1_ms * 1e-3) / 1e12
         irreducible_tf = samples_per_launch * IRREDUCIBLE_FLOP_PER_INPUT_SAMPLE / (k1_ms * 1e-3) / 1e12
         ceil = hbm_ceiling(local_rank) if (world == 1 and not args.pmc_child) else {}
@@ -574,6 +585,9 @@ def main():
                        "collective": collective},
             "realtime_carriers": value * 1e6 / sym_rate_per_carrier,
             "output_check": output_check,
+            "pre_shift": (None if not args.shared else
+                          ({"phase": "ideal ramp from an exactly anchored sample per lane (plan option fast_pre_shift)", **fast_shift_report}
+                           if fast_shift else {"phase": "the reference's rounding of theta reproduced sample by sample"})),
             "rccl_ranks": world if group is not None else 0,
             "plan_create_ms": plan_create_ms,
             "settle_steps": settle_steps,   # untimed passes before the warm-up (clock ramp after idle)

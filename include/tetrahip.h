@@ -114,6 +114,17 @@ TDM_API int tdm_debug_get(const char *key, int64_t *value);
 TDM_API int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, int32_t in_fmt,
                     int32_t mode, int32_t device, tdm_plan **out);
 TDM_API int tdm_plan_destroy(tdm_plan *plan);
+/* Per-plan options (no counterpart in the reference).
+ *   "fast_pre_shift"  (TDM_MODE_REFERENCE, default 0) 1: the input-rate pre-shift of tdm_process* (pre_shift_hz: the
+ *       frequency_shift(x, f_k) of processor.py:85-100 fused into the decimator's load) runs its phase as the IDEAL ramp
+ *       from an exactly anchored first sample per lane, instead of reproducing the reference's own rounding of
+ *       theta_j = fl(ci * fl(j / fs)) sample by sample (a third of that kernel's arithmetic).  The two phases differ by the
+ *       reference's rounding error of theta: at most 6e-11 rad at 787.5 kHz x 0.1 s.  Soft symbols then agree with the
+ *       reference to 1e-9 instead of 1e-10 (north_star: 1e-5); a HARD decision can differ only where its margin to a
+ *       threshold is below that, which the per-carrier min_margin output reports: a caller that needs the reference's
+ *       decision there re-runs the carriers with min_margin < 1e-8 on a plan without the option
+ *       (tetraear_amd.batch.BatchDemodulator.process does). */
+TDM_API int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value);
 TDM_API int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
 /* Serve another chunk length with the same plan (TDM_MODE_REFERENCE): the reference designs its filters inside every
  * process() call (processor.py:78, :254), so its callers read whatever lengths they like (ui/modern.py:1912 128 Ki,

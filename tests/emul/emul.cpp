@@ -301,7 +301,7 @@ static void small_dft_host(const float *in, float *out)
     }
 }
 
-static bool g_allow_pz = true, g_allow_raw = true;
+static bool g_allow_pz = true, g_allow_raw = true, g_fast_shift = false;
 
 extern "C" {
 
@@ -316,6 +316,8 @@ int64_t emu_tetra_tap_operands(const float *taps, int ntaps, uint32_t *out)
 void emu_allow_parallel_form(int on) { g_allow_pz = on != 0; }
 // tests: 0 keeps cu8 plans on the kernel that holds its samples as doubles
 void emu_allow_raw_integer(int on) { g_allow_raw = on != 0; }
+// tests: 1 = the plan option "fast_pre_shift" (the input-rate shift's phase as the ideal ramp)
+void emu_fast_pre_shift(int on) { g_fast_shift = on != 0; }
 
 // whole pipeline == tdm_process with host pointers
 int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq, int64_t stride,
@@ -362,7 +364,7 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
     B.z = z.data();
     std::vector<double> partials((size_t)rows * (h.n_dec / kPowThreads + 16) * kMaxSps, nan);
     B.partials = partials.data();
-    RefIO io{iq, stride, pre_shift, freq_offset, hard, soft, n_soft, best_phase, min_margin};
+    RefIO io{iq, stride, pre_shift, freq_offset, hard, soft, n_soft, best_phase, min_margin, g_fast_shift ? 1 : 0};
     EmuBackend be;
     run_ref(be, h, rows, fmt, B, io);
     return 0;
@@ -386,7 +388,7 @@ int emu_zp_stage(int kind, const double *x, int64_t n, int q, double bandwidth, 
             hz.t = h.dec;
             hz.bind(1);
             h.dec.p = hz.t.p;
-            RawLoaderRT<false> lr{x, n, nullptr, fs, FMT_CF64};
+            RawLoaderRT<false> lr{x, n, nullptr, fs, FMT_CF64, 0};
             run_pz_block(be, h, hz.t.p, lr, 1);
         } else {
             hz.t = build_zp_tables(desc_from_sos(s), n, kEdgeSos, kLDec, n_out, q);

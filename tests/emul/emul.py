@@ -43,6 +43,18 @@ def process(sample_rate, iq, fmt, n, rows=1, stride=None, pre_shift=None, freq_o
     return hard, soft, n_soft, bp, mm
 
 
+class fast_pre_shift:
+    """`with emul.fast_pre_shift(): ...` -- the plan option of the same name (the input-rate shift's phase as the ideal ramp)"""
+
+    def __enter__(self):
+        lib().emu_fast_pre_shift(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().emu_fast_pre_shift(0)
+        return False
+
+
 def zp_stage(kind, x, q=10, bandwidth=25000.0, fs=240000.0):
     L = lib()
     x = np.ascontiguousarray(x, dtype=np.complex128)

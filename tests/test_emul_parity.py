@@ -163,3 +163,31 @@ def test_emul_random_lengths_and_rates_vs_oracle():
         if ns:
             assert np.max(np.abs(soft[0, :ns] - ref.symbols)) <= 1e-10 * (np.max(np.abs(ref.symbols)) or 1.0), (fs, n, f)
 
+
+
+def test_emul_fast_pre_shift_against_exact_and_oracle():
+    """Plan option "fast_pre_shift": the input-rate shift's phase as the ideal ramp from an exactly anchored sample per lane,
+    against the path that reproduces the reference's rounding of theta sample by sample, and against the oracle's
+    process(frequency_shift(x, f_k)): hard decisions equal, soft symbols within 1e-9 (exact path: 1e-10)."""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    n = 60000
+    u8 = synth.noise_cu8(n, 4243)
+    x = synth.cu8_to_c128(u8)
+    shifts = [-787500.0, 12500.0, 612500.0]
+    foffs = [0.0, 1171.875, -500.0]
+    a = emul.process(2.4e6, u8, "cu8", n, rows=3, stride=0, pre_shift=shifts, freq_offset=foffs)
+    with emul.fast_pre_shift():
+        b = emul.process(2.4e6, u8, "cu8", n, rows=3, stride=0, pre_shift=shifts, freq_offset=foffs)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])
+    for r in range(3):
+        o = OracleSignalProcessor(2.4e6)
+        ref = o.process(o.frequency_shift(x, shifts[r]), foffs[r])
+        ns = int(b[2][r])
+        np.testing.assert_array_equal(b[0][r, :ns - 1], ref)
+        scale = np.max(np.abs(o.symbols))
+        assert np.max(np.abs(b[1][r, :ns] - o.symbols)) <= 1e-9 * scale
+        assert np.max(np.abs(a[1][r, :ns] - o.symbols)) <= 1e-10 * scale
+        assert np.max(np.abs(a[1][r, :ns] - b[1][r, :ns])) > 0      # (it IS another phase)

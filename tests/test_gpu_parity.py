@@ -516,3 +516,57 @@ def test_process_dtype_corners_match_reference(SP):
         assert np.max(np.abs(p.symbols - soft64)) <= 1e-10 * scale, name
         assert np.max(np.abs(p.symbols - soft)) <= 5e-5 * scale, name
         p.close()
+
+
+@pytest.mark.gpu
+def test_fast_pre_shift_config3_and_its_guard():
+    """Plan option "fast_pre_shift" on BASELINE config 3 (64 carriers out of one 2.4 MS/s stream, shifts up to 787.5 kHz) and on
+    bench.py --shared's own workload: hard decisions and timing phase equal to the oracle's p.process(p.frequency_shift(x,
+    f_k)) on EVERY carrier, soft symbols within 1e-9 (the exact-phase path: 1e-10), no carrier's smallest margin below the
+    1e-8 rad guard -- and the guard itself: with the threshold raised above every margin, process() re-runs the batch with
+    the exact phase and returns that path's outputs bit for bit."""
+    import bench
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    from tetraear_amd.batch import BatchDemodulator
+    n = 262144
+    offs = [(k - 31.5) * 25000.0 for k in range(64)]
+    u8, _ = synth.multicarrier_cu8(n, 2.4e6, offs, seed0=100)
+    exact = BatchDemodulator(2.4e6, n, 64, "cu8")
+    h0, s0, bp0, mm0 = exact.process(u8, pre_shifts=offs, shared_input=True)
+    exact.close()
+    bd = BatchDemodulator(2.4e6, n, 64, "cu8").set_fast_pre_shift()
+    hards, softs, bp, mm = bd.process(u8, pre_shifts=offs, shared_input=True)
+    assert getattr(bd, "exact_reruns", 0) == 0 and float(np.min(mm)) >= 1e-8
+    x = synth.cu8_to_c128(u8)
+    worst = 0.0
+    for k in range(64):
+        o = OracleSignalProcessor(2.4e6)
+        ref = o.process(o.frequency_shift(x, offs[k]))
+        assert bp[k] == o.best_phase, k
+        np.testing.assert_array_equal(hards[k], ref, err_msg=f"carrier {k}")
+        worst = max(worst, float(np.max(np.abs(softs[k] - o.symbols)) / np.max(np.abs(o.symbols))))
+    assert 1e-13 < worst <= 1e-9, worst
+    # the guard: every carrier "too close" -> the exact path's outputs
+    bd.FAST_SHIFT_MARGIN = 10.0
+    h1, s1, bp1, mm1 = bd.process(u8, pre_shifts=offs, shared_input=True)
+    assert bd.exact_reruns == 1
+    for k in range(64):
+        np.testing.assert_array_equal(h1[k], h0[k])
+        np.testing.assert_array_equal(s1[k], s0[k])
+    np.testing.assert_array_equal(mm1, mm0)
+    bd.close()
+    # bench.py --shared's workload through the device path with the option: the digest pinned to the oracle
+    carriers = 64
+    iq, _ = bench.make_batch(1, n, "cu8", 0)
+    pre = bench.shared_offsets(carriers)
+    bd = BatchDemodulator(2.4e6, n, carriers, "cu8").set_fast_pre_shift()
+    bd.alloc_device_io(shared_input=True)
+    bd.upload(iq, freq_offsets=None, pre_shifts=pre)
+    bd.enqueue()
+    bd.sync()
+    hard, soft, n_soft, bpd, mmd = bd.download()
+    bd.close()
+    want = bench.expected_digest(bench.digest_key(carriers, n, "cu8", 2.4e6, 0, True))
+    assert want is not None and bench.output_digest(hard, n_soft, bpd) == want
+    assert float(np.min(mmd)) >= 1e-8

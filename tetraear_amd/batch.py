@@ -64,6 +64,16 @@ class BatchDemodulator:
         self.mode = mode
         self.soft_dtype = np.complex64 if mode in (_lib.MODE_TETRA, _lib.MODE_TETRA_GARDNER) else np.complex128
 
+    FAST_SHIFT_MARGIN = 1e-8   # rad: below it a decision made with the fast pre-shift is re-made with the exact one
+
+    def set_fast_pre_shift(self, on=True):
+        """tdm_plan_option "fast_pre_shift": the input-rate pre-shift's phase as the ideal ramp (a third less arithmetic in
+        the decimator of a channelised call); `process` then re-runs, with the exact phase, a batch in which some carrier's
+        smallest decision margin is below FAST_SHIFT_MARGIN, so its hard decisions are the reference's either way."""
+        check(self.lib.tdm_plan_option(self.handle, b"fast_pre_shift", 1 if on else 0))
+        self.fast_pre_shift = bool(on)
+        return self
+
     def resize(self, n_samples):
         """Serve another chunk length with this plan (tdm_plan_resize): tables of a new length are built once (a fraction of
         a millisecond), a length seen before is a look-up; `info` then describes the new length.  Device I/O buffers made
@@ -93,6 +103,15 @@ class BatchDemodulator:
         mm = np.zeros(rows, dtype=np.float64)
         check(self.lib.tdm_process(self.handle, ptr(iq), 0 if shared_input else self.n_samples, ptr(ps), ptr(fo),
                                    ptr(hard), ptr(soft), ptr(n_soft), ptr(bp), ptr(mm)))
+        if getattr(self, "fast_pre_shift", False) and ps is not None and np.any(mm < self.FAST_SHIFT_MARGIN):
+            # a decision this close to a threshold is the reference's only with the reference's own phase rounding
+            check(self.lib.tdm_plan_option(self.handle, b"fast_pre_shift", 0))
+            try:
+                check(self.lib.tdm_process(self.handle, ptr(iq), 0 if shared_input else self.n_samples, ptr(ps), ptr(fo),
+                                           ptr(hard), ptr(soft), ptr(n_soft), ptr(bp), ptr(mm)))
+            finally:
+                check(self.lib.tdm_plan_option(self.handle, b"fast_pre_shift", 1))
+            self.exact_reruns = getattr(self, "exact_reruns", 0) + 1
         hards = [hard[r, :max(int(n_soft[r]) - 1, 0)].copy() for r in range(rows)]
         softs = [soft[r, :int(n_soft[r])].copy() for r in range(rows)]
         return hards, softs, bp, mm

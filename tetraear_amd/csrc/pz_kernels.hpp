@@ -72,6 +72,12 @@ struct RawLoaderRT {
     const double *pre_shift;   // per row [Hz] or null: frequency_shift of the stream on load (processor.py:85-100)
     double fs;
     int32_t fmt;
+    // fast_shift != 0: the pre-shift's phase as the IDEAL ramp from an exactly anchored first sample of the lane (8
+    // instructions per sample) instead of the reference's own rounding of theta_j = fl(ci * fl(j / fs)) reproduced sample
+    // by sample (29).  The two differ by the reference's rounding of theta: up to 6e-11 rad at 787.5 kHz x 0.1 s -- soft
+    // symbols within 1e-9 instead of 1e-10, and a hard decision can differ only where its margin is below that (the
+    // per-carrier min_margin output says so; tetrahip.h tdm_plan_option "fast_pre_shift").
+    int32_t fast_shift;
 
     TDM_HD int bytes() const { return (fmt == FMT_CU8 || fmt == FMT_CS8) ? 2 : (fmt == FMT_CF32 ? 8 : 16); }
     TDM_HD const void *row_ptr(int row) const { return (const char *)iq + (int64_t)row * row_stride * bytes(); }
@@ -175,7 +181,15 @@ struct RawLoaderRT {
             // frequency_shift of the shared stream with a running phasor over the lane's consecutive samples; the
             // anchor's (out-of-line) sincos runs before the samples occupy the register file
             NcoRunT<1> nco;
-            if (SHIFT && f != 0.0) nco.init(k, f, fs);
+            if (SHIFT && f != 0.0) {
+                if (fast_shift) {
+                    const phasor a = nco_phasor(k, f, fs);   // (the anchor is exact: the reference's own theta_k)
+                    nco.ar = a.c;
+                    nco.ai = a.s;
+                } else {
+                    nco.init(k, f, fs);
+                }
+            }
             switch (fmt) {
             case FMT_CU8: fast8<L, FMT_CU8>(p, xr, xi); break;
             case FMT_CS8: fast8<L, FMT_CS8>(p, xr, xi); break;
@@ -198,7 +212,21 @@ struct RawLoaderRT {
                 }
             } break;
             }
-            if (SHIFT && f != 0.0) {
+            if (SHIFT && f != 0.0 && fast_shift) {
+                // ideal ramp: p_{i+1} = p_i W, W = exp(i ci / fs), from the lane's exactly anchored first sample
+                double wr, wi;
+                sincos(-(2.0 * M_PI) * f / fs, &wi, &wr);
+                double c = nco.ar, sn = nco.ai;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const double a = xr[i], b = xi[i];
+                    xr[i] = a * c - b * sn;
+                    xi[i] = a * sn + b * c;
+                    const double nc = c * wr - sn * wi, ns = c * wi + sn * wr;
+                    c = nc;
+                    sn = ns;
+                }
+            } else if (SHIFT && f != 0.0) {
 #pragma unroll
                 for (int i = 0; i < L; ++i) {
                     double c = nco.ar, sn = nco.ai;

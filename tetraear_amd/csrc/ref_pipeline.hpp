@@ -43,6 +43,7 @@ struct RefIO {
     int32_t *n_soft;
     int32_t *best_phase;
     double *min_margin;
+    int32_t fast_shift = 0;   // pre_shift as the ideal phase ramp (RawLoaderRT::fast_shift)
 };
 
 // parallel-form decimator: one kernel per decimation factor, wire format as a run-time switch
@@ -87,7 +88,7 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     } else if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
         if (h.pz_S) {
-            RawLoaderRT<SHIFT> lr{io.iq, io.carrier_stride, SHIFT ? io.pre_shift : nullptr, h.sample_rate, FMT};
+            RawLoaderRT<SHIFT> lr{io.iq, io.carrier_stride, SHIFT ? io.pre_shift : nullptr, h.sample_rate, FMT, io.fast_shift};
             run_pz_block(be, h, B.dec_params, lr, rows);
         } else {
             be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);

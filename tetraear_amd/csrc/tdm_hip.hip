@@ -415,6 +415,7 @@ struct tdm_plan {
     int rows = 0, fmt = 0, mode = 0, device = 0;
     double sample_rate = 0.0;
     bool allow_raw = true;
+    int32_t fast_pre_shift = 0;   // tdm_plan_option "fast_pre_shift"
     int64_t raw_min_blocks = 0;
     std::map<int64_t, std::unique_ptr<Variant>> variants;
     Variant *cur = nullptr;
@@ -426,8 +427,9 @@ struct tdm_plan {
     // TETRA mode
     TetraParams tp{};
     uint32_t *d_tapops = nullptr;   // TetraParams::tap_ops
-    float2 *d_gy = nullptr;         // TDM_MODE_TETRA_GARDNER: matched-filter output
+    float2 *d_gy = nullptr;         // TDM_MODE_TETRA_GARDNER, three-launch path only: matched-filter output (allocated the first time that path runs)
     int64_t gy_pitch = 0;
+    int gardner_fused_ok = -1;      // does the fused Gardner kernel serve this plan (tap count, carriers, device)?  -1: not asked yet
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -760,9 +762,9 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             p->variants[n_samples] = std::move(v);
         }
         if (mode == TDM_MODE_TETRA_GARDNER) {
-            // the matched-filter output goes through HBM in this mode: [rows][pitch] cf32, rows 16-byte aligned
+            // the matched-filter output of the three-launch path: [rows][pitch] cf32, rows 16-byte aligned; about 1 GB at 4096 x 32 768, so only a plan that ever takes the
+            // three launches allocates it (the default fused kernel keeps the filter output in LDS)
             p->gy_pitch = (n_samples + 1) & ~(int64_t)1;
-            HIP_TRY(hipMalloc((void **)&p->d_gy, (size_t)n_carriers * p->gy_pitch * sizeof(float2)));
         }
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&p->ev0));
@@ -801,6 +803,17 @@ int tdm_plan_resize(tdm_plan *plan, int64_t n_samples)
     if (plan->cur && plan->cur->h.n == n_samples) return TDM_OK;
     HIP_TRY(hipSetDevice(plan->device));
     return plan_select(plan, plan->sample_rate, n_samples);
+}
+
+int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value)
+{
+    if (!plan || !key) return fail(TDM_ERR_INVALID, "null argument");
+    if (std::strcmp(key, "fast_pre_shift") == 0) {
+        if (plan->mode != TDM_MODE_REFERENCE) return fail(TDM_ERR_UNSUPPORTED, "fast_pre_shift is a reference-mode option");
+        plan->fast_pre_shift = value ? 1 : 0;
+        return TDM_OK;
+    }
+    return fail(TDM_ERR_INVALID, std::string("tdm_plan_option: unknown option '") + key + "'");
 }
 
 int tdm_plan_destroy(tdm_plan *plan)
@@ -871,11 +884,15 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
             constexpr int stages = 7;
             const bool fused = debug_value("gardner_fused") != 0;
             bool fused_done = false;
-            if (fused && tetra_gardner_fused_available(tp.ntaps, plan->rows)) {
+            // (whether the fused kernel serves this plan depends on the plan alone: asked once -- two HIP queries -- not per call)
+            if (plan->gardner_fused_ok < 0) plan->gardner_fused_ok = tetra_gardner_fused_available(tp.ntaps, plan->rows) ? 1 : 0;
+            if (fused && plan->gardner_fused_ok) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream);
             }
             const bool three = !fused_done;   // (gardner_fused = 0, no fused kernel for this tap count, or too many carriers for it)
+            if (three && !plan->d_gy)
+                HIP_TRY(hipMalloc((void **)&plan->d_gy, (size_t)plan->rows * plan->gy_pitch * sizeof(float2)));
             if (three && (stages & 1)) {
                 HipBackend::Scope s(be, ST_TETRA_MF);
                 if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))
@@ -913,7 +930,7 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
     B.lp2 = v.lp2;
     B.dec_raw_params = v.dec_raw;
     B.lp2_raw = v.lp2_raw;
-    RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin};
+    RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin, plan->fast_pre_shift};
     run_ref(be, v.h, plan->rows, plan->fmt, B, io);
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
     return TDM_OK;
@@ -1474,7 +1491,7 @@ int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, do
             RefPlanHost h;
             h.q = t.p.out_stride;
             h.dec.p.nb = t.p.nb;
-            RawLoaderRT<false> lr{dx.p, n, nullptr, fs, FMT_CF64};
+            RawLoaderRT<false> lr{dx.p, n, nullptr, fs, FMT_CF64, 0};
             run_pz_block(be, h, dz.params, lr, 1);
         } else {
             be.zp_block<2, 4, kLDec, kEdgeSos>(dz.params, ld, t.p.nb, 1);
