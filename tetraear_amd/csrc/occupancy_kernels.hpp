@@ -28,6 +28,7 @@ struct OccArgs {
     int32_t rows;
     int32_t bin_lo, bin_hi;  // fftshifted bins [bin_lo, bin_hi) = the 25 kHz around the centre
     float2 *stats;           // [rows] (signal_power, peak_power) in dBFS
+    int32_t *n_rows;         // the list kernel's counter, put to zero here (the launch before it on the stream)
 };
 
 // power spectrum statistics of every row: 256-point FFT as 16 x 16 (register-resident 16-point transforms, one exchange
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void k_occ_spectrum(const OccArgs A)
     __shared__ cf32v tw[kOccFft];
     __shared__ float win[kOccFft];
     const int tid = threadIdx.x, rl = tid >> 4, t = tid & 15;
+    if (blockIdx.x == 0 && tid == 0) *A.n_rows = 0;
     {
         float s, c;
         __sincosf(6.283185307179586f * (float)tid / (float)kOccFft, &s, &c);
@@ -96,23 +98,31 @@ struct OccListArgs {
     int32_t *n_soft;         // [rows] or null: set to 0 for rows that are NOT occupied (the receiver skips them)
 };
 
-// one workgroup per stream: noise floor = median of the channels' signal_power, the rule, the row list
-__global__ __launch_bounds__(256) void k_occ_list(const OccListArgs A)
+// one workgroup per stream: noise floor = median of the channels' signal_power (bitonic sort of the M values, padded with
+// +inf to 1024, in LDS: with one workgroup per stream every wavefront has its SIMD to itself, so it is the instruction
+// COUNT that matters -- ranking every channel against every other took 30 us, the sort 3), the rule, the row list
+__global__ __launch_bounds__(512) void k_occ_list(const OccListArgs A)
 {
-    __shared__ float sig[kOccMaxM], sorted[kOccMaxM];
+    __shared__ float sorted[kOccMaxM];
     const int M = A.M, s = blockIdx.x, tid = threadIdx.x;
     const float2 *st = A.stats + (int64_t)s * M;
-    for (int k = tid; k < M; k += 256) sig[k] = st[k].x;
+    for (int k = tid; k < kOccMaxM; k += 512) sorted[k] = k < M ? st[k].x : __builtin_inff();
     __syncthreads();
-    for (int k = tid; k < M; k += 256) {
-        const float v = sig[k];
-        int r = 0;
-        for (int j = 0; j < M; ++j) r += (sig[j] < v) || (sig[j] == v && j < k);
-        sorted[r] = v;
+    for (int size = 2; size <= kOccMaxM; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            // thread t handles the pair (i, i + stride), i = the t-th index with bit `stride` clear
+            const int i = 2 * tid - (tid & (stride - 1));
+            const bool up = (i & size) == 0;
+            const float a = sorted[i], b = sorted[i + stride];
+            if ((a > b) == up) {
+                sorted[i] = b;
+                sorted[i + stride] = a;
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
     const float floor_db = (M & 1) ? sorted[M / 2] : 0.5f * (sorted[M / 2 - 1] + sorted[M / 2]);
-    for (int k = tid; k < M; k += 256) {
+    for (int k = tid; k < M; k += 512) {
         const float2 v = st[k];
         const bool occ = (v.x - floor_db > A.snr_db) && (v.y > A.min_dbfs) && (v.y - v.x > A.peak_db);
         const int row = s * M + k;

@@ -2122,9 +2122,9 @@ int tdm_occupancy_gate(const float *chan, int64_t pitch, int32_t n_streams, int3
     L.snr_db = (float)snr_db;
     L.min_dbfs = (float)min_dbfs;
     L.peak_db = 3.0f;
-    HIP_TRY(hipMemsetAsync(L.n_rows, 0, sizeof(int32_t), st));
+    A.n_rows = L.n_rows;
     hipLaunchKernelGGL(k_occ_spectrum, dim3((unsigned)((rows + kOccRowsPerWg - 1) / kOccRowsPerWg)), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_occ_list, dim3((unsigned)n_streams), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(k_occ_list, dim3((unsigned)n_streams), dim3(512), 0, st, L);
     HIP_TRY(hipGetLastError());
     if (!device_pointers) {
         HIP_TRY(hipDeviceSynchronize());
