@@ -513,7 +513,6 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
         double pr[NP][2], pq[NP][2];             // state entering the row
 #pragma unroll
         for (int s = 0; s < NP; ++s) { pr[s][0] = 0; pr[s][1] = 0; pq[s][0] = 0; pq[s][1] = 0; }
-        if (kLp2Lean) load_lm(dir_c);
         double mrow[NP][4];
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
@@ -536,6 +535,10 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
             }
         }
         LP2_T(9 + 4 * dir);
+        if (kLp2Lean) {
+            TDM_SCHED_FENCE();
+            load_lm(dir_c);
+        }
         // every lane: true inclusive state = in-row value + C^(La (position in the row + 1)) * (state entering the row)
 #pragma unroll
         for (int s = 0; s < NP; ++s) {

@@ -19,8 +19,9 @@ namespace tdm {
 // themselves: ~0.5 MB of scratch traffic per chunk against 128 KB of samples, from a 75 MB scratch footprint that no cache
 // holds -- and trimmed them (kLp2Lean below: the rotated samples wait in LDS between the filter passes, per-lane scan
 // matrices and item operands requested where they are used, the two scan directions one after the other): 29 spills
-// 0.404 ms, 18 spills 0.365 ms.  Still behind the sixteen-sample lanes' 0.330 ms (at zero spills the trend points to
-// ~0.30: twice the wavefronts do not pay for 1.3x the instructions and a sixth barrier).  Kept as a build switch, off.
+// 0.404 ms, 18 spills 0.365 ms, 4 spills 0.341 ms -- level with the sixteen-sample lanes' 0.330-0.334 ms: twice the
+// wavefronts per compute unit buy exactly the 1.31x instructions per sample that the shorter lanes cost (scans, NCO
+// anchor and item operands are per lane).  Kept as a build switch, off.
 #ifndef TDM_LP2_LA
 #define TDM_LP2_LA 16
 #endif
