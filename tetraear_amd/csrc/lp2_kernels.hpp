@@ -338,7 +338,25 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     if (any_sig && Src::kFix) {
 #endif
         const double f = src.foff(row);
-        if (f != 0.0) {
+        if (f != 0.0 && kLp2FastNco) {
+            // the lane's first phasor from the workgroup's tables (lp2_body): anchor x W^(64 La wave) x W^(La lane), then one
+            // complex multiplication by W per sample
+            const double *t = nco_w;
+            const double a0r = t[2], a0i = t[3], b0r = t[4 + 2 * wave], b0i = t[5 + 2 * wave];
+            const double m0r = a0r * b0r - a0i * b0i, m0i = a0r * b0i + a0i * b0r;
+            const double l0r = t[16 + 2 * lane], l0i = t[17 + 2 * lane];
+            double c = m0r * l0r - m0i * l0i, sn = m0r * l0i + m0i * l0r;
+            const double wr = t[0], wi = t[1];
+#pragma unroll
+            for (int i = 0; i < La; ++i) {
+                const double a = yr[i], b = yi[i];
+                yr[i] = a * c - b * sn;
+                yi[i] = a * sn + b * c;
+                const double nc = c * wr - sn * wi, ns = c * wi + sn * wr;
+                c = nc;
+                sn = ns;
+            }
+        } else if (f != 0.0) {
             NcoRunT<1> nco;
             nco.init_with(js, f, src.fs_out, nco_w[0], nco_w[1]);
 #pragma unroll
@@ -725,7 +743,34 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     // last wavefront (the one with the fewest items) forms it and leaves it in LDS for all lanes (round 2: every lane's
     // own sincos, 120 instructions in each of the four wavefronts)
     double *nco_w = cm.small() + Lp2Lds::oPow + 16;     // (the power partials' area is free until the output stage)
-    if (Src::kFix && (cm.tid() >> 6) == kLp2Waves - 1) {
+    if (Src::kFix && kLp2FastNco) {
+        // frequency_shift(samples, freq_offset) at the low rate (processor.py:260-261) as the ideal phase ramp from ONE exactly
+        // anchored sample per workgroup: exp(i theta_j) = A0 W^(j - jc), A0 = the reference's own exp(i theta_jc)
+        // (nco_phasor: theta = fl(ci fl(j / fs))), W = exp(i ci / fs).  The reference's theta_j differs from the ramp by its
+        // own rounding -- at most 1.5e-13 rad at 1.2 kHz x 0.11 s, the level of the filters' arithmetic noise (reproducing it
+        // sample by sample, NcoRunT, cost 25 instructions per sample and a sincos per lane: 600 of this kernel's 2947
+        // instructions per lane; TDM_LP2_FAST_NCO=0 builds that).  Two wavefronts form the tables while the samples are on
+        // their way: [0,1] W, [2,3] A0, [4 + 2 w] W^(64 La w) per wavefront, [16 + 2 l] W^(La l) per lane.
+        const int wave = cm.tid() >> 6, lane = cm.tid() & 63;
+        const double f = src.foff(row);
+        if (f != 0.0 && wave >= kLp2Waves - 2) {
+            const double dth = -(2.0 * M_PI) * f / src.fs_out;
+            double sn, c;
+            if (wave == kLp2Waves - 1) {
+                sincos((double)(kLp2La * lane) * dth, &sn, &c);
+                nco_w[16 + 2 * lane] = c;
+                nco_w[17 + 2 * lane] = sn;
+                sincos(dth, &sn, &c);
+                if (lane == 0) { nco_w[0] = c; nco_w[1] = sn; }
+            } else {
+                sincos((double)(kWave * kLp2La * (lane < kLp2Waves ? lane : 0)) * dth, &sn, &c);
+                if (lane < kLp2Waves) { nco_w[4 + 2 * lane] = c; nco_w[5 + 2 * lane] = sn; }
+                const int64_t jc = (int64_t)chunk * P.U - P.H - P.off;
+                const phasor a = nco_phasor(jc, f, src.fs_out);
+                if (lane == 0) { nco_w[2] = a.c; nco_w[3] = a.s; }
+            }
+        }
+    } else if (Src::kFix && (cm.tid() >> 6) == kLp2Waves - 1) {
         const double f = src.foff(row);
         if (f != 0.0) {
             double wre, wim;

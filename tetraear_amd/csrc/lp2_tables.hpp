@@ -48,6 +48,13 @@ constexpr bool kLp2InlineCarry = false;
 #define TDM_LP2_LEAN (TDM_LP2_LA == 8)
 #endif
 constexpr bool kLp2Lean = TDM_LP2_LEAN;
+// the low-rate frequency shift as the ideal phase ramp from one exactly anchored sample per workgroup (lp2_kernels.hpp
+// lp2_body); 0: the reference's rounding of theta reproduced sample by sample (rounds 1-4)
+#ifndef TDM_LP2_FAST_NCO
+#define TDM_LP2_FAST_NCO 1
+#endif
+constexpr bool kLp2FastNco = TDM_LP2_FAST_NCO != 0;
+static_assert(!kLp2FastNco || TDM_LP2_WAVES >= 2, "two wavefronts form the NCO's tables");
 constexpr int kLp2Pairs = 2;
 constexpr int kLp2D = 2 * kLp2Pairs;
 // what a chunk may ignore of its neighbours: the states are O(10) per unit input, so the neglected part is below 1e-20 of

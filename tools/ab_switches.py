@@ -26,7 +26,8 @@ chunk = int(args[2]) if len(args) > 2 else 262144
 nd = min(rows, 16)
 base = np.stack([synth.dqpsk_cu8(chunk, 2.4e6, seed=1000 + i)[0] for i in range(nd)])
 iq = np.concatenate([base[i % nd] for i in range(rows)])
-foff = ((np.arange(rows) % 7) - 3) * 390.625
+import os
+foff = ((np.arange(rows) % 7) - 3) * 390.625 * (0.0 if os.environ.get('ZERO_FOFF') else 1.0)
 lib = _lib.load()
 ref = None
 ok = True
