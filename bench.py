@@ -1014,6 +1014,7 @@ def leg_gardner(rows, base, chk, steps):
     ms = bd.time_end() / steps
     st = bd.stage_times()
     hard, soft, n_soft, tm, mm = bd.download()
+    halves = int(bd.info.gardner_segments)
     bd.close()
     nsym = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
     check = {"status": "no pinned decisions for this workload"}
@@ -1030,7 +1031,10 @@ def leg_gardner(rows, base, chk, steps):
         check = {"against": "oracle/tetra_np.py demod_gardner (fp64 loop), pinned by tests/golden/make_bench_checks.py",
                  "worst_fraction_of_differing_decisions": worst, "rows_equal_their_prototype": bool(same),
                  "status": "decisions match the definition's loop (<= 1e-3 differing, count within one)" if (ok and same) else "DIFFERS from the definition"}
-    return {"what": "TDM_MODE_TETRA_GARDNER: matched filter (producer wavefronts) -> LDS ring -> Gardner TED + PI loop + Farrow, four lanes per carrier, one kernel -> decisions (2 launches)",
+    return {"what": "TDM_MODE_TETRA_GARDNER: matched filter (producer wavefronts) -> LDS ring -> Gardner TED + PI loop + Farrow, four lanes per carrier, one kernel -> decisions"
+                    + (" (2 launches)" if halves == 1 else "; every carrier's chunk as two independently started loops (the second warms up over "
+                       "512 symbols before the seam), joined by a copy of the second half's symbols (3 launches)"),
+            "loops_per_carrier": halves,
 
             "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s", "steps": steps, "stage_ms_per_launch": st,
             "output_check": check}

@@ -161,12 +161,28 @@ def _farrow1(y, t):
     return ((c3 * mu + c2) * mu + c1) * mu + y0
 
 
-def demod_gardner(x, sample_rate, bn_t=0.01, zeta=0.7071):
-    """Gardner TED (e_k = Re{(s_k - s_{k-1}) conj(s_{k-1/2})}, normalised by the running symbol power) -> PI loop
-    (noise bandwidth bn_t symbol rates, damping zeta) -> period-controlled Farrow interpolation of the matched-filter
-    output; then the same differential detection, 4th-power carrier-offset estimate and quadrant slicer as demod().
-    Returns (hard, derotated d_k, info with the symbol instants `t`)."""
-    x = np.asarray(x, dtype=np.complex128)
+GARDNER_WARMUP_SYMBOLS = 512
+
+
+def gardner_segments(n, sample_rate, ntaps=None):
+    """Geometry of the two-halves form of the Gardner receiver (the library's rule, tdm_hip.hip): each half is n_v samples
+    long -- half the chunk plus an overlap that holds 512 warm-up symbols of the second half's loop -- the second starts
+    seg_off samples into the chunk, and the seam lies `margin` samples before the first half's end (clear of its matched
+    filter's edge).  Returns None when the chunk is too short for two halves (n_v + 8 overlaps > n)."""
+    sps = sample_rate / SYMBOL_RATE
+    if ntaps is None:
+        ntaps = len(rrc_taps(sps))
+    margin = (ntaps - 1) // 2 + 4 * int(np.ceil(sps)) + 8
+    ov = ((int(np.ceil(GARDNER_WARMUP_SYMBOLS * sps)) + margin + 1) // 2 + 1) & ~1
+    n_v = ((n // 2 + ov) + 1) & ~1
+    if n_v + 8 * ov > n:
+        return None
+    seg_off = n - n_v
+    return dict(n_v=n_v, seg_off=seg_off, seam_a=n_v - margin, seam_b=n_v - margin - seg_off)
+
+
+def _gardner_loop(x, sample_rate, bn_t, zeta):
+    """one loop over one stretch of samples: symbols and their instants"""
     sps = sample_rate / SYMBOL_RATE
     y = matched_filter(x, rrc_taps(sps))
     n = len(y)
@@ -195,8 +211,40 @@ def demod_gardner(x, sample_rate, bn_t=0.01, zeta=0.7071):
         s.append(sk)
         prev = sk
         t += sps * (1.0 - v)     # (a late strobe makes e positive: shorten the period)
-    s = np.array(s)
-    ts = np.array(ts)
+    return np.array(s), np.array(ts)
+
+
+def demod_gardner(x, sample_rate, bn_t=0.01, zeta=0.7071, segments=1):
+    """Gardner TED (e_k = Re{(s_k - s_{k-1}) conj(s_{k-1/2})}, normalised by the running symbol power) -> PI loop
+    (noise bandwidth bn_t symbol rates, damping zeta) -> period-controlled Farrow interpolation of the matched-filter
+    output; then the same differential detection, 4th-power carrier-offset estimate and quadrant slicer as demod().
+    Returns (hard, derotated d_k, info with the symbol instants `t`).
+
+    segments = 2 (what the library does for batches that would leave most of the device idle, tdm_plan_info.gardner_segments):
+    the chunk as TWO independently started loops over samples [0, n_v) and [n - n_v, n) (gardner_segments: n_v = half the
+    chunk plus an overlap of 512 warm-up symbols), joined at a seam near the overlap's end: the first loop's symbols whose
+    instant's whole part lies before the seam, then the second loop's from the symbol that is the first loop's first one at
+    or behind the seam (their instants relative to the seam differ by a whole number of symbol periods, 0 unless the two
+    loops place a symbol on different sides of the seam).  The loop is a contraction, so the second loop runs onto the
+    first one's trajectory during its warm-up; the chunk's second half starts as every chunk does -- stateless."""
+    x = np.asarray(x, dtype=np.complex128)
+    sps = sample_rate / SYMBOL_RATE
+    geo = gardner_segments(len(x), sample_rate) if segments == 2 else None
+    if geo is None:
+        s, ts = _gardner_loop(x, sample_rate, bn_t, zeta)
+    else:
+        sa, ta = _gardner_loop(x[:geo["n_v"]], sample_rate, bn_t, zeta)
+        sb, tb = _gardner_loop(x[geo["seg_off"]:], sample_rate, bn_t, zeta)
+        ia = np.nonzero(np.floor(ta) >= geo["seam_a"])[0]
+        ib = np.nonzero(np.floor(tb) >= geo["seam_b"])[0]
+        ka = int(ia[0]) if len(ia) else len(sa)
+        jb = int(ib[0]) if len(ib) else len(sb)
+        rel_a = (ta[ka] - geo["seam_a"]) if ka < len(sa) else 0.0
+        rel_b = (tb[jb] - geo["seam_b"]) if jb < len(sb) else 0.0
+        d = int(np.rint(np.float32(rel_b - rel_a) / np.float32(sps)))
+        jb = min(max(jb - d, 0), len(sb))
+        s = np.concatenate([sa[:ka], sb[jb:]])
+        ts = np.concatenate([ta[:ka], tb[jb:] + geo["seg_off"]])
     d = s[1:] * np.conj(s[:-1])
     if len(d) == 0:
         return np.zeros(0, np.uint8), d, dict(t=ts)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert L.tdm_version() == 100
+    assert L.tdm_version() == 101
 
 
 def test_design_matches_scipy_tables(gold_design):
@@ -86,3 +86,19 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "liboracle" not in txt and "libtdm_emul" not in txt, f
+
+
+def test_ctypes_plan_info_has_the_headers_layout(tmp_path):
+    """The host side's mirror of tdm_plan_info against the header itself (gcc: size and the offset of every field)."""
+    import ctypes
+    import subprocess
+    fields = [f[0] for f in _lib.PlanInfo._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tetrahip.h"\nint main(void){printf("%zu", sizeof(tdm_plan_info));'
+                   + "".join('printf(" %%zu", offsetof(tdm_plan_info, %s));' % f for f in fields) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_lib.PlanInfo)
+    assert got[1:] == [getattr(_lib.PlanInfo, f).offset for f in fields]

@@ -70,6 +70,31 @@ def test_feed_forward_matches_or_beats_gardner(snr_db):
         print("   %.2f %6.0f  %.5f %.5f  %.4f %.4f" % r)
 
 
+def test_definition_in_two_halves_joins_to_the_whole_chunks_symbols():
+    """oracle/tetra_np.demod_gardner(segments=2) -- what the library does for batches that leave the device idle -- against
+    the whole-chunk loop: the same symbols before the seam, the same count (the halves' instants differ by whole symbol
+    periods at the seam), the same decisions behind it once the second loop has converged, no error against what was sent;
+    chunks too short for two warm-ups have no two-halves form."""
+    assert tetra_np.gardner_segments(4096, 72000.0) is None
+    for fs, n, ppm in ((72000.0, 32768, 60.0), (72000.0, 30001, -120.0), (90000.0, 40960, 0.0)):
+        geo = tetra_np.gardner_segments(n, fs)
+        sps = fs / 18000.0
+        assert geo["seg_off"] + geo["n_v"] == n and geo["seam_b"] >= tetra_np.GARDNER_WARMUP_SYMBOLS * sps - 2      # (n_v is even: one sample of rounding)
+        x, dib = _gardner_case(n, fs, 77, 0.3, 120.0, 20.0, ppm)
+        x = x.astype(np.complex128)
+        h1, s1, i1 = tetra_np.demod_gardner(x, fs)
+        h2, s2, i2 = tetra_np.demod_gardner(x, fs, segments=2)
+        assert abs(len(s2) - len(s1)) <= 1
+        k_seam = int(geo["seam_a"] / sps) - 40
+        np.testing.assert_array_equal(i2["t"][:k_seam], i1["t"][:k_seam])        # (the second return value is derotated by the chunk's estimate)
+        np.testing.assert_allclose(np.abs(s2[:k_seam - 1]), np.abs(s1[:k_seam - 1]), rtol=1e-12)
+        m = min(len(h1), len(h2))
+        assert np.mean(h1[:m] != h2[:m]) <= 1e-3
+        assert np.max(np.abs(i2["t"][:m] - i1["t"][:m])) < 0.1 * sps          # one lattice of instants: no symbol lost or doubled
+        best = min(int(np.sum(h2[300:m - 8] != dib[lag + 300:lag + m - 8])) for lag in range(40) if len(dib) - lag >= m)
+        assert best == 0, (fs, n, best)
+
+
 # ---- the device's Gardner receiver (TDM_MODE_TETRA_GARDNER) against the same definition ------------------------------
 def _gardner_case(n, fs, seed, toff, coff, snr_db, rate_ppm=0.0):
     """a carrier whose symbol clock runs rate_ppm fast (the loop has to track a ramp, and the carriers of a wavefront drift
@@ -82,15 +107,17 @@ def _gardner_case(n, fs, seed, toff, coff, snr_db, rate_ppm=0.0):
     return (x * np.exp(2j * np.pi * coff * np.arange(n) / fs)).astype(np.complex64), dib
 
 
-def _check_against_definition(x, fs, hard, soft, dib, skip=300):
-    ref_hard, _, info = tetra_np.demod_gardner(x.astype(np.complex128), fs)
+def _check_against_definition(x, fs, hard, soft, dib, skip=300, segments=1):
+    """segments: tdm_plan_info.gardner_segments of the plan that made `hard` (2: every chunk as two independently started
+    loops joined at a seam -- the definition is then evaluated the same way)"""
+    ref_hard, _, info = tetra_np.demod_gardner(x.astype(np.complex128), fs, segments=segments)
     # the loop runs in fp32 on the device (instants in fp64): symbol count within one of the definition's at the end of
     # the chunk, decisions equal wherever the definition itself is not within rounding of a boundary
     assert abs(len(soft) - len(info["t"])) <= 1, (len(soft), len(info["t"]))
     m = min(len(hard), len(ref_hard))
     assert m > 0.9 * len(x) / (fs / 18000.0) - 20
     assert np.mean(hard[:m] != ref_hard[:m]) <= 1e-3, float(np.mean(hard[:m] != ref_hard[:m]))
-    best = min(int(np.sum(hard[skip:m - 8] != dib[lag + skip:lag + m - 8])) for lag in range(40) if len(dib) - lag >= m)
+    best = min((int(np.sum(hard[skip:m - 8] != dib[lag + skip:lag + m - 8])) for lag in range(40) if len(dib) - lag >= m), default=-1)
     return best
 
 
@@ -105,10 +132,11 @@ def test_gpu_gardner_receiver_matches_definition_and_transmitted():
         rows = 3
         sig = [_gardner_case(n, fs, 40 + 7 * r, 0.13 * r - 0.2, (-120.0, 0.0, 90.0)[r], 20.0, ppm) for r in range(rows)]
         bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+        seg = bd.info.gardner_segments
         hards, softs, timing, margin = bd.process(np.concatenate([s[0] for s in sig]))
         bd.close()
         for r in range(rows):
-            errs = _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1])
+            errs = _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1], segments=seg)
             assert errs == 0, (fs, n, r, errs)
             assert 0.0 < margin[r] < 0.8
 
@@ -124,10 +152,11 @@ def test_gpu_gardner_receiver_many_carriers_share_a_wavefront():
     sig = [_gardner_case(n, fs, 500 + r, ((r * 37) % 100) / 100.0 - 0.5, float((r * 53) % 240 - 120), 18.0, float((r % 9) - 4) * 100.0)
            for r in range(rows)]
     bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+    seg = bd.info.gardner_segments
     hards, softs, timing, margin = bd.process(np.concatenate([s[0] for s in sig]))
     bd.close()
     for r in range(0, rows, 3):
-        _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1])
+        _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1], segments=seg)
     # every carrier (also the ones not compared with the slow fp64 loop): error-free against what was sent, after acquisition
     for r in range(rows):
         m = len(hards[r])
@@ -148,13 +177,14 @@ def test_gpu_gardner_carriers_of_a_wavefront_more_than_three_chunks_apart():
     sig = [_gardner_case(n, fs, 900 + r, 0.1 * (r % 5) - 0.2, float((r * 31) % 200 - 100), 25.0, (3000.0 if r % 4 == 1 else 0.0) if r % 2 else -10000.0)
            for r in range(rows)]
     bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+    seg = bd.info.gardner_segments
     hards, softs, timing, margin = bd.process(np.concatenate([s[0] for s in sig]))
     bd.close()
     counts = [len(s) for s in softs]
     assert max(counts) - min(counts) >= 55, counts      # (1 % of 6144 symbols: the groups really are that far apart)
     assert max(counts) > n / (fs / 18000.0) + 10, counts    # (the fast carriers: more symbols than the nominal count)
     for r in range(rows):
-        errs = _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1], skip=600)
+        errs = _check_against_definition(sig[r][0], fs, hards[r], softs[r], sig[r][1], skip=600, segments=seg)
         assert errs == 0 or r % 4 != 3, (r, errs)           # (r % 4 == 3: the carriers on time)
 
 
@@ -251,3 +281,47 @@ def test_gpu_gardner_more_carriers_than_one_round_of_workgroups():
             assert len(s1[r]) == len(s0[r]) and len(h1[r]) > 0.9 * n / (fs / 18000.0) - 10, (fs, r)
             assert np.array_equal(h1[r], h0[r]), (fs, r)
             assert np.array_equal(h1[r], h1[r % distinct]), (fs, r)      # (and its prototype row)
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_two_halves_per_carrier_against_whole_chunks():
+    """tdm_plan_info.gardner_segments == 2 (batches that would leave most of the device idle, chunks long enough): every
+    carrier's chunk as two independently started loops joined at a seam.  Against the same definition evaluated in two
+    halves (decisions, counts), against what was sent (no error behind the seam either), and against the device's own
+    whole-chunk path (tdm_debug_set gardner_segments 0): the same symbol count, decisions equal up to 1e-3 of them, soft
+    symbols equal bit for bit before the seam and within 15 % right behind it (the second loop is 512 symbols into its run
+    there: a few per cent of a symbol of timing error left, shrinking with the loop's time constant) -- at 4 and 5 samples
+    per symbol, with rows that are and are not a multiple of the loop wavefront's sixteen carriers.  Whole chunks stay where
+    the rule says so: chunks too short for two warm-ups, batches that fill the device by themselves."""
+    from tetraear_amd._lib import MODE_TETRA_GARDNER, debug_option
+    from tetraear_amd.batch import BatchDemodulator
+    for fs, n, rows in ((72000.0, 4096, 8), (72000.0, 32768, 4112)):
+        bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+        assert bd.info.gardner_segments == 1, (fs, n, rows)
+        bd.close()
+    for fs, n, rows in ((72000.0, 32768, 32), (72000.0, 30001, 21), (90000.0, 40960, 16)):
+        sig = [_gardner_case(n, fs, 1500 + r, 0.07 * r - 0.4, float((r * 29) % 200 - 100), 20.0, float((r % 5) - 2) * 60.0) for r in range(rows)]
+        iq = np.concatenate([s[0] for s in sig])
+        bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+        assert bd.info.gardner_segments == 2
+        h2, s2, t2, m2 = bd.process(iq)
+        bd.close()
+        with debug_option("gardner_segments", 0):
+            bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+            assert bd.info.gardner_segments == 1
+            h1, s1, t1, m1 = bd.process(iq)
+            bd.close()
+        geo = tetra_np.gardner_segments(n, fs)
+        k_seam = int(geo["seam_a"] / (fs / 18000.0))
+        for r in range(rows):
+            assert abs(len(s2[r]) - len(s1[r])) <= 1, (fs, r, len(s2[r]), len(s1[r]))
+            m = min(len(h1[r]), len(h2[r]))
+            assert np.mean(h1[r][:m] != h2[r][:m]) <= 1e-3, (fs, r)
+            np.testing.assert_array_equal(s2[r][:k_seam - 40], s1[r][:k_seam - 40])
+            scale = float(np.max(np.abs(s1[r])))
+            assert float(np.max(np.abs(s2[r][:m] - s1[r][:m]))) <= 0.15 * scale, (fs, r)
+            assert float(np.max(np.abs(s2[r][m - 500:m] - s1[r][m - 500:m]))) <= 0.02 * scale, (fs, r)
+            assert t2[r] == t1[r]
+            if r % 4 == 0:
+                errs = _check_against_definition(sig[r][0], fs, h2[r], s2[r], sig[r][1], segments=2)
+                assert errs == 0, (fs, r, errs)

@@ -25,7 +25,8 @@ class PlanInfo(C.Structure):
     _fields_ = [("sample_rate", C.c_double), ("rate_dec", C.c_double), ("n_samples", C.c_int64),
                 ("n_dec", C.c_int64), ("n_carriers", C.c_int32), ("q", C.c_int32), ("sps", C.c_int32),
                 ("phase_step", C.c_int32), ("max_soft", C.c_int32), ("lpf_applied", C.c_int32),
-                ("in_fmt", C.c_int32), ("mode", C.c_int32), ("device", C.c_int32), ("dec_engine", C.c_int32)]
+                ("in_fmt", C.c_int32), ("mode", C.c_int32), ("device", C.c_int32), ("dec_engine", C.c_int32),
+                ("gardner_segments", C.c_int32)]
 
 
 _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t

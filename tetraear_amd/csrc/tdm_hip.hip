@@ -51,6 +51,7 @@ static DebugSwitch g_debug[] = {
     {"pfb_direct", {0}, 0},              // 1: channeliser plans made from now on use the direct-DFT kernel
     {"pfb_rounds", {0}, 0},              // > 0: rounds per channeliser workgroup (plans made from now on)
     {"pfb_halftile", {0}, 0},
+    {"gardner_segments", {1}, 1},        // 0: TDM_MODE_TETRA_GARDNER plans used from now on walk whole chunks (no two halves per carrier)
 };
 static DebugSwitch *debug_find(const char *key)
 {
@@ -430,6 +431,13 @@ struct tdm_plan {
     float2 *d_gy = nullptr;         // TDM_MODE_TETRA_GARDNER, three-launch path only: matched-filter output (allocated the first time that path runs)
     int64_t gy_pitch = 0;
     int gardner_fused_ok = -1;      // does the fused Gardner kernel serve this plan (tap count, carriers, device)?  -1: not asked yet
+    // two segments per carrier (GardnerSeg): geometry and temporaries, made the first time the plan runs that way
+    int gardner_seg = -1;           // -1: not decided yet, 0: whole chunks, 1: two halves
+    GardnerSeg gseg{};
+    TetraParams gtp{};              // the plan's parameters with a half's length and row capacity
+    float2 *d_gsoft = nullptr;      // [2 rows][gtp.max_soft] the halves' symbols
+    int32_t *d_gint = nullptr;      // [3][2 rows]: symbol counts, timing, seam indices
+    float *d_gts = nullptr;         // [2 rows] seam instants
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -636,7 +644,7 @@ static void plan_free(tdm_plan *p)
     p->variants.clear();
     for (auto &kv : p->d_shared)
         if (kv.second.second) (void)hipFree(kv.second.second);
-    void *ptrs[] = {p->d_work, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp, p->d_tapops, p->d_gy};
+    void *ptrs[] = {p->d_work, p->d_gsoft, p->d_gint, p->d_gts, p->d_iq, p->d_pre, p->d_foff, p->d_soft, p->d_margin, p->d_hard, p->d_nsoft, p->d_bp, p->d_tapops, p->d_gy};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -710,6 +718,7 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             return fail(TDM_ERR_UNSUPPORTED, "TETRA mode chunk length must be 64..131072 samples");
         std::vector<double> h = tetra_rrc_taps(sps);
         if ((int)h.size() > kRrcMaxTaps) return fail(TDM_ERR_UNSUPPORTED, "too many RRC taps");
+        const int ntaps_design = (int)h.size();   // (before the padding to an instantiated length)
         {
             // the matched-filter kernel is instantiated for these (odd) lengths: centre the taps in the next one up,
             // zeros either side (same filter, same alignment), so that every rate in the 2..8 samples/symbol contract runs
@@ -762,6 +771,42 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             p->variants[n_samples] = std::move(v);
         }
         if (mode == TDM_MODE_TETRA_GARDNER) {
+            p->rows = n_carriers;
+            p->device = device;
+            p->gardner_fused_ok = (debug_value("gardner_fused") != 0 && tetra_gardner_fused_available(tp.ntaps, n_carriers)) ? 1 : 0;
+        // Two segments per carrier when the launch would otherwise leave most of the chip idle (one loop wavefront per
+        // sixteen carriers: at most one workgroup per compute unit) and the chunk is long enough for the second half's
+        // 512 warm-up symbols to be a small part of it; tdm_debug_set("gardner_segments", 0) keeps whole chunks
+        {
+            int cus = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+            const int warm = 512;
+            const int margin = (ntaps_design - 1) / 2 + 4 * (int)std::ceil(tp.sps) + 8;   // (oracle/tetra_np.py gardner_segments)
+            const int ov = (((int)std::ceil(warm * tp.sps) + margin + 1) / 2 + 1) & ~1;
+            const int n_v = ((tp.n / 2 + ov) + 1) & ~1;
+            const bool fits = (int64_t)(p->rows + 15) / 16 <= cus && n_v + 8 * ov <= tp.n && p->gardner_fused_ok == 1 &&
+                          tetra_gardner_fused_per_cu(tp.ntaps) >= 2;   // (both halves' workgroups resident at once)
+            p->gardner_seg = (fits && debug_value("gardner_segments") != 0) ? 1 : 0;
+            if (p->gardner_seg) {
+                const int R = p->rows;
+                GardnerSeg &S = p->gseg;
+                S.rows_phys = R;
+                S.seg_off = tp.n - n_v;
+                S.seam_a = n_v - margin;
+                S.seam_b = S.seam_a - S.seg_off;
+                S.k_mid_a = (int)(0.5 * (double)tp.n / tp.sps);
+                p->gtp = tp;
+                p->gtp.n = n_v;
+                p->gtp.max_soft = (int32_t)(1.02 * (double)n_v / tp.sps) + 8;
+                const bool direct = R % 16 == 0;   // (first halves straight into the caller's rows: GardnerSeg::soft_a)
+                HIP_TRY(hipMalloc((void **)&p->d_gsoft, (size_t)(direct ? 1 : 2) * R * p->gtp.max_soft * sizeof(float2)));
+                S.pitch_a = direct ? tp.max_soft : 0;
+                HIP_TRY(hipMalloc((void **)&p->d_gint, (size_t)3 * 2 * R * sizeof(int32_t)));
+                HIP_TRY(hipMalloc((void **)&p->d_gts, (size_t)2 * R * sizeof(float)));
+                S.k_seam = p->d_gint + 4 * R;
+                S.t_seam = p->d_gts;
+            }
+        }
             // the matched-filter output of the three-launch path: [rows][pitch] cf32, rows 16-byte aligned; about 1 GB at 4096 x 32 768, so only a plan that ever takes the
             // three launches allocates it (the default fused kernel keeps the filter output in LDS)
             p->gy_pitch = (n_samples + 1) & ~(int64_t)1;
@@ -850,6 +895,7 @@ int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info)
     info->in_fmt = plan->fmt;
     info->mode = plan->mode;
     info->device = plan->device;
+    info->gardner_segments = plan->mode == TDM_MODE_TETRA_GARDNER ? (plan->gardner_seg == 1 ? 2 : 1) : 0;
     if (plan->mode == TDM_MODE_REFERENCE && h.decimated) {
         // (the rule of run_ref_fmt; a call with an input-rate pre-shift stays on the double-based kernel)
         const bool raw = h.raw_S > 0 && plan->fmt == TDM_CU8 && (int64_t)plan->rows * h.dec.p.nb >= h.raw_min_blocks;
@@ -884,9 +930,30 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
             constexpr int stages = 7;
             const bool fused = debug_value("gardner_fused") != 0;
             bool fused_done = false;
-            // (whether the fused kernel serves this plan depends on the plan alone: asked once -- two HIP queries -- not per call)
-            if (plan->gardner_fused_ok < 0) plan->gardner_fused_ok = tetra_gardner_fused_available(tp.ntaps, plan->rows) ? 1 : 0;
-            if (fused && plan->gardner_fused_ok) {
+            // (whether the fused kernel serves this plan, and whether as two halves per carrier, was settled when the plan was made)
+            if (fused && plan->gardner_fused_ok && plan->gardner_seg == 1) {
+                const int R = plan->rows;
+                GardnerSeg S = plan->gseg;
+                S.soft_a = S.pitch_a ? (float2 *)soft : nullptr;
+                {
+                    HipBackend::Scope s(be, ST_TETRA_LOOP);
+                    fused_done = tetra_gardner_fused_launch(plan->gtp, 2 * R, (const float2 *)iq, carrier_stride_samples, plan->d_gsoft,
+                                                            plan->d_gint, plan->d_gint + 2 * R, be.stream, &S);
+                }
+                if (fused_done) {
+                    // decisions, with the halves joined first (the second halves' rows: behind the first halves' in the temporary
+                    // unless those went straight to the caller's rows)
+                    HipBackend::Scope s(be, ST_TETRA_DECIDE);
+                    if (!S.soft_a)   // (carrier counts that are no multiple of sixteen: the first halves come out of the temporary too)
+                        HIP_TRY(hipMemcpy2DAsync(soft, (size_t)tp.max_soft * sizeof(float2), plan->d_gsoft, (size_t)plan->gtp.max_soft * sizeof(float2),
+                                                 (size_t)plan->gtp.max_soft * sizeof(float2), R, hipMemcpyDeviceToDevice, be.stream));
+                    tetra_decide_launch(tp, R, (float2 *)soft, n_soft, hard, min_margin, be.stream, &S,
+                                        plan->d_gsoft + (S.soft_a ? 0 : (size_t)R * plan->gtp.max_soft), plan->gtp.max_soft, plan->d_gint,
+                                        plan->d_gint + 2 * R, best_phase);
+                    if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
+                    return TDM_OK;
+                }
+            } else if (fused && plan->gardner_fused_ok) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream);
             }
@@ -904,7 +971,7 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
             }
             if (stages & 4) {
                 HipBackend::Scope s(be, ST_TETRA_DECIDE);
-                tetra_decide_launch(tp, plan->rows, (const float2 *)soft, n_soft, hard, min_margin, be.stream);
+                tetra_decide_launch(tp, plan->rows, (float2 *)soft, n_soft, hard, min_margin, be.stream);
             }
             if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
             return TDM_OK;

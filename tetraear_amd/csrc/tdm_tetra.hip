@@ -57,7 +57,7 @@ void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y,
 {
     const GardnerConsts G = gardner_gains();
     hipLaunchKernelGGL(k_tetra_gardner<0>, dim3((unsigned)((rows + kGQuads - 1) / kGQuads)), dim3(64), 0, stream, y, y_pitch, tp, G, rows,
-                       soft, n_soft, timing_milli);
+                       soft, n_soft, timing_milli, GardnerSeg{});
 }
 
 static const void *gardner_fused_kernel(int ntaps)
@@ -81,26 +81,41 @@ bool tetra_gardner_fused_available(int ntaps, int rows)
     if (!fn) return false;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return true;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * (1 + kGProducers), 0) != hipSuccess || per_cu < 1) return true;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kGWaves, 0) != hipSuccess || per_cu < 1) return true;
     return per_cu >= 2 || (int64_t)(rows + kGQuads - 1) / kGQuads <= (int64_t)cus * per_cu;
 }
 
-bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
-                                int32_t *timing_milli, hipStream_t stream)
+int tetra_gardner_fused_per_cu(int ntaps)
 {
+    const void *fn = gardner_fused_kernel(ntaps);
+    int per_cu = 0;
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kGWaves, 0) != hipSuccess) return 0;
+    return per_cu;
+}
+
+bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
+                                int32_t *timing_milli, hipStream_t stream, const GardnerSeg *seg)
+{
+    const GardnerSeg S = seg ? *seg : GardnerSeg{};
     const GardnerConsts G = gardner_gains();
-    const dim3 grid((unsigned)((rows + kGQuads - 1) / kGQuads)), block(64 * (1 + kGProducers));
+    const dim3 grid((unsigned)((rows + kGQuads - 1) / kGQuads)), block(64 * kGWaves);
     switch (tp.ntaps) {
-#define TDM_GF_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_gardner<NT>), grid, block, 0, stream, x, in_stride, tp, G, rows, soft, n_soft, timing_milli); return true;
+#define TDM_GF_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_gardner<NT>), grid, block, 0, stream, x, in_stride, tp, G, rows, soft, n_soft, timing_milli, S); return true;
         TDM_GF_CASE(17) TDM_GF_CASE(25) TDM_GF_CASE(33) TDM_GF_CASE(35) TDM_GF_CASE(41) TDM_GF_CASE(49) TDM_GF_CASE(57) TDM_GF_CASE(65)
 #undef TDM_GF_CASE
     default: return false;
     }
 }
 
-void tetra_decide_launch(const TetraParams &tp, int rows, const float2 *soft, const int32_t *n_soft, uint8_t *hard, double *min_margin,
-                         hipStream_t stream)
+void tetra_decide_launch(const TetraParams &tp, int rows, float2 *soft, int32_t *n_soft, uint8_t *hard, double *min_margin,
+                         hipStream_t stream, const GardnerSeg *seg, const float2 *soft_b, int cap_b, const int32_t *n_v,
+                         const int32_t *timing_v, int32_t *timing_milli)
 {
+    if (seg) {
+        const GardnerJoin J{soft_b, cap_b, n_v, timing_v, timing_milli, (float)tp.sps};
+        const dim3 grid((unsigned)((cap_b + kJoinTile - 1) / kJoinTile), (unsigned)rows);
+        hipLaunchKernelGGL(k_tetra_gardner_join, grid, dim3(256), 0, stream, soft, (int)tp.max_soft, n_soft, *seg, J);
+    }
     hipLaunchKernelGGL(k_tetra_decide, dim3((unsigned)rows), dim3(256), 0, stream, soft, (int)tp.max_soft, n_soft, hard, min_margin);
 }
 

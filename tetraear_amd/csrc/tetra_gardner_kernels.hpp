@@ -197,6 +197,14 @@ template <bool FUSED> struct GardnerRing {
     static constexpr int chunks = FUSED ? 8 : kGChunks, slots = chunks * kGChunk, pitch = slots + 3;
 };
 constexpr int kGProducers = 2;               // matched-filter wavefronts of the fused kernel: eight carriers each
+// TDM_GARDNER_PLACE=1: the fused kernel's workgroup has FOUR wavefronts -- one per SIMD -- of which one leaves at once; which
+// SIMD's wavefront runs the loop depends on the parity of the workgroup's slot on its compute unit (HW_ID.TG_ID), so that the
+// two workgroups of a compute unit put their loops on DIFFERENT SIMDs (0 and 2) and their producers together on the other
+// two: a loop wavefront then has its SIMD to itself also when two workgroups share the unit
+#ifndef TDM_GARDNER_PLACE
+#define TDM_GARDNER_PLACE 1   // (measured: 4096 carriers 1.229 -> 1.204 ms, 8192 carriers 1.607 -> 1.418 ms)
+#endif
+constexpr int kGWaves = TDM_GARDNER_PLACE ? 4 : 1 + kGProducers;   // wavefronts a fused workgroup is launched with
 constexpr int kGQuota = 2;                   // chunks a producer makes between two hand-overs (a block of 16 symbols uses sps / 4)
 template <int NT> struct GardnerWindow {     // a producer's input window per carrier and chunk
     static constexpr int H = (NT - 1) / 2, W = kGChunk + NT - 1, pairs = W / 2;
@@ -231,11 +239,17 @@ constexpr int kQuadSymbolPair = 0x44;        // [0, 1, 0, 1]
 // ONE workgroup barrier per block (no polling): the producers publish how many chunks are complete, the loop how far it has
 // moved on; every wavefront passes the same barriers and leaves after the one at which `done` was set.
 template <int NT>
-__global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_gardner(const float2 *__restrict__ y, int64_t y_pitch, const TetraParams P,
+__global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(const float2 *__restrict__ y, int64_t y_pitch, const TetraParams P,
                                                       const GardnerConsts G, int rows, float2 *__restrict__ soft,
-                                                      int32_t *__restrict__ n_soft, int32_t *__restrict__ timing_milli)
+                                                      int32_t *__restrict__ n_soft, int32_t *__restrict__ timing_milli, const GardnerSeg S)
 {
     constexpr bool FUSED = NT > 0;
+    // input row of (virtual) carrier v: second halves start seg_off samples into their carrier's row
+    auto row_in = [&](int v) {
+        v = min(v, rows - 1);
+        const int h = (S.seg_off > 0 && v >= S.rows_phys) ? 1 : 0;
+        return y + (int64_t)(v - h * S.rows_phys) * y_pitch + h * S.seg_off;
+    };
     constexpr int kGRing = GardnerRing<FUSED>::slots, kGPitch = GardnerRing<FUSED>::pitch;
     __shared__ float2 ring[kGQuads * kGPitch];      // sample g of a carrier in slot g mod kGRing of its row (33 KB; fused: 66 KB)
     __shared__ __attribute__((aligned(16))) float2 xwin[FUSED ? kGProducers * 8 * GardnerWindow<FUSED ? NT : 1>::pitch : 1];
@@ -249,9 +263,23 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
     typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (a clamped pair at the end of an odd-length row starts on an odd sample)
     const int lane = threadIdx.x & 63;
     if constexpr (FUSED) {
-        for (int t = threadIdx.x; t < NT + 1; t += 64 * (1 + kGProducers)) taps_s[t] = t < NT ? P.taps[t] : 0.f;
+        for (int t = threadIdx.x; t < NT + 1; t += 64 * kGWaves) taps_s[t] = t < NT ? P.taps[t] : 0.f;
+#if TDM_GARDNER_PLACE
+        // roles by SIMD (see kGWaves): 0 the loop, 1 and 2 the producers, 3 leaves
+        __shared__ int sh_simd[4];
+        const int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID, all 32 bits
+        const int simd = (hw >> 4) & 3, slot = (hw >> 16) & 1;
+        if (lane == 0) sh_simd[threadIdx.x >> 6] = simd;
+        __syncthreads();
+        const bool spread = ((1 << sh_simd[0]) | (1 << sh_simd[1]) | (1 << sh_simd[2]) | (1 << sh_simd[3])) == 15;
+        const int widx = (int)threadIdx.x >> 6;
+        const int rel = spread ? ((simd - 2 * slot) & 3) : widx;            // 0: the loop's SIMD, 2: the one that leaves
+        const int wave = __builtin_amdgcn_readfirstlane(rel == 0 ? 0 : (rel == 1 ? 1 : (rel == 3 ? 2 : 3)));
+        if (wave == 3) return;
+#else
         __syncthreads();
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#endif
         if (wave > 0) {
             // ---- a producer: carriers 8 (wave - 1) .. + 7 of the workgroup; lane = (carrier j, group of eight outputs gI)
             typedef GardnerWindow<FUSED ? NT : 1> GW;
@@ -264,7 +292,7 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
                 const int f = min(lane + 64 * k, 8 * GW::pairs - 1);
                 xcar[k] = f / GW::pairs;
                 xpr[k] = f - xcar[k] * GW::pairs;
-                xrow[k] = y + (int64_t)min((int)blockIdx.x * kGQuads + car0 + xcar[k], rows - 1) * y_pitch + 2 * xpr[k] - GW::H;
+                xrow[k] = row_in((int)blockIdx.x * kGQuads + car0 + xcar[k]) + 2 * xpr[k] - GW::H;
             }
             float2 *myring = ring + (car0 + j) * kGPitch;
             // the window of the NEXT chunk is requested while this chunk's arithmetic runs (a chunk's 2 us of load latency
@@ -366,8 +394,13 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
     const float *my = (const float *)(ring + quad * kGPitch) + c;      // component c of slot i: my[2 i]
     // soft symbols: the workgroup's rows from a scalar base, a lane's position in them as a 32-bit byte offset that also
     // counts the carrier's symbols (k = (off - off0) / 8)
-    char *const wg_soft = (char *)(soft + (int64_t)blockIdx.x * kGQuads * P.max_soft);
-    const uint32_t off0 = (uint32_t)quad * (uint32_t)P.max_soft * 8u + 4u * (uint32_t)c;
+    // (two halves per carrier, GardnerSeg::soft_a: a wavefront of first halves writes into the caller's rows, one of second
+    //  halves into the temporary, which then holds the second halves only)
+    const bool wg_a = S.seg_off > 0 && S.soft_a && (int)blockIdx.x * kGQuads < S.rows_phys;
+    const int wg_row0 = (int)blockIdx.x * kGQuads - ((S.seg_off > 0 && S.soft_a && !wg_a) ? S.rows_phys : 0);
+    const uint32_t soft_pitch = wg_a ? (uint32_t)S.pitch_a : (uint32_t)P.max_soft;
+    char *const wg_soft = (char *)((wg_a ? S.soft_a : soft) + (int64_t)wg_row0 * soft_pitch);
+    const uint32_t off0 = (uint32_t)quad * soft_pitch * 8u + 4u * (uint32_t)c;
     uint32_t off = off0;
     // ---- cooperative chunk moves: chunk cn = samples [64 cn, 64 cn + 64) of every carrier of the wavefront.  One 16-byte load
     // fetches two samples; lanes 0..31 serve carrier 2 q, lanes 32..63 carrier 2 q + 1 (rows are 16-byte aligned: even pitch)
@@ -377,7 +410,7 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
     float2 *dst0[kGQuads / 2];                     // ... and its slots in their ring rows
 #pragma unroll
     for (int q = 0; q < kGQuads / 2; ++q) {
-        src[q] = y + (int64_t)min((int)blockIdx.x * kGQuads + 2 * q + half, rows - 1) * y_pitch + 2 * l32;
+        src[q] = row_in((int)blockIdx.x * kGQuads + 2 * q + half) + 2 * l32;
         dst0[q] = ring + (2 * q + half) * kGPitch + 2 * l32;
     }
     // (a chunk that ends inside the row -- all but the last one or two -- moves without clamps and masks: a ring move is
@@ -436,7 +469,11 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
     int m_mid = 0;
     float mu_mid = 0.f;                             // the instant of the chunk's middle symbol
     const int m_end = n - 3;                        // t <= n - 3  <=>  m < n - 3 or (m == n - 3 and mu == 0)
-    const int k_mid = (int)(0.5 * (double)n / sps);
+    const bool first_half = S.seg_off > 0 && row < S.rows_phys;
+    const int k_mid = first_half ? S.k_mid_a : (int)(0.5 * (double)n / sps);
+    const int seam = S.seg_off > 0 ? (first_half ? S.seam_a : S.seam_b) : 0x7fffffff;
+    int k_seam_rec = -1;                            // the first symbol at or behind the seam: its index and its instant
+    float t_seam_rec = 0.f;
     // a carrier takes its strobes in a turn when m < hi_v: see the block loop
     int hi_v = -0x7fffffff;
     // Software pipeline over the symbols: the strobe positions of the NEXT symbol are known as soon as this symbol's error is
@@ -516,6 +553,7 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
         if (SLOW) {
             const int k = (int)((off - off0) >> 3) + T;
             if (k == k_mid) { m_mid = m; mu_mid = mu; }
+            if (k_seam_rec < 0 && m >= seam) { k_seam_rec = k; t_seam_rec = (float)(m - seam) + mu; }
             if (k + 1 >= P.max_soft) hi_v = -0x7fffffff;     // the row is full
         }
         prev = val;
@@ -549,7 +587,8 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
         // m + 2 < 64 (c0 + 4) -- and m is inside the chunk: per turn ONE comparison, m < hi_v; one that has run ahead of the
         // wavefront's slowest carrier by more than three chunks waits for the ring to move on
         hi_v = (active && (c0 == 0 || m - back >= kGChunk * c0)) ? min(kGChunk * (c0 + kGChunks) - 2, m_end + (corner ? 1 : 0)) : -0x7fffffff;
-        const bool near = (k <= k_mid && k_mid < k + kGBlock) || k + kGBlock > P.max_soft;
+        const bool near = (k <= k_mid && k_mid < k + kGBlock) || k + kGBlock > P.max_soft ||
+                          (k_seam_rec < 0 && m + kGBlock * back >= seam);     // (the block that may cross the seam)
         // The block's turns run with the active carriers' lanes enabled and NO per-lane decision while every one of them can
         // take its strobes (one wavefront-uniform branch per turn: carriers of a wavefront move in step unless their clocks
         // differ by more than three chunks); what is left of the block when one cannot is done lane by lane.
@@ -614,7 +653,54 @@ __global__ __launch_bounds__(NT > 0 ? 64 * (1 + kGProducers) : 64) void k_tetra_
             const double u = ((double)m_mid + (double)mu_mid) / sps;
             timing_milli[row] = (int32_t)rint((u - rint(u)) * 1000.0);
         }
+        if (S.seg_off > 0) {
+            S.k_seam[row] = k_seam_rec < 0 ? k : k_seam_rec;
+            S.t_seam[row] = t_seam_rec;
+        }
     }
+}
+
+// ---- two halves per carrier (GardnerSeg): the join.  The first half's symbols before the seam already lie in the carrier's
+// row; the second half's follow from the symbol that IS the first half's first one behind the seam (the recorded instants say
+// which: they differ by a whole number of symbol periods, 0 unless the two loops place a symbol on different sides of the
+// seam).  A bulk copy of its own ahead of k_tetra_decide (grid: tiles of kJoinTile symbols x carriers), 0.05 ms for 4096
+// carriers.  Measured alternatives, join + decisions together (separate launches: 0.121 ms): the copy at the head of a deciding
+// workgroup 0.157, its stores among that workgroup's loads 0.170 (every wait for a load becomes a wait for the stores'
+// acknowledgements as well: one counter), behind its decisions 0.220 (a second latency chain), as workgroups of their own in
+// the deciding launch, which then reads the two halves where they lie, 0.152.
+struct GardnerJoin {
+    const float2 *b;          // [rows][cap_b] the second halves' symbols
+    int32_t cap_b;
+    const int32_t *n_v;       // [2 rows] the halves' symbol counts
+    const int32_t *timing_v;  // [2 rows]
+    int32_t *timing_milli;    // [rows] or null
+    float sps;
+};
+constexpr int kJoinPer = 8, kJoinTile = 256 * kJoinPer;
+__global__ __launch_bounds__(256) void k_tetra_gardner_join(float2 *__restrict__ soft, int max_soft, int32_t *__restrict__ n_soft,
+                                                            const GardnerSeg S, const GardnerJoin J)
+{
+    const int row = blockIdx.y, tid = threadIdx.x;
+    const int R = S.rows_phys;
+    const int nB = J.n_v[R + row];
+    const int kA = min(S.k_seam[row], J.n_v[row]);
+    const int d = (int)rintf((S.t_seam[R + row] - S.t_seam[row]) / J.sps);
+    const int jB = min(max(S.k_seam[R + row] - d, 0), nB);
+    const int ns = min(kA + (nB - jB), max_soft);
+    if (blockIdx.x == 0 && tid == 0) {
+        n_soft[row] = ns;
+        if (J.timing_milli) J.timing_milli[row] = J.timing_v[row];
+    }
+    const float2 *__restrict__ B = J.b + (int64_t)row * J.cap_b + jB - kA;      // symbol i >= kA at B[i]
+    float2 *__restrict__ sr = soft + (int64_t)row * max_soft;
+    const int i0 = kA + blockIdx.x * kJoinTile + tid;
+    if (i0 >= ns) return;
+    float2 v[kJoinPer];
+#pragma unroll
+    for (int j = 0; j < kJoinPer; ++j) v[j] = B[min(i0 + 256 * j, ns - 1)];
+#pragma unroll
+    for (int j = 0; j < kJoinPer; ++j)
+        if (i0 + 256 * j < ns) sr[i0 + 256 * j] = v[j];
 }
 
 // ---- decisions (the same detection as demod(): d_k = s_k conj(s_{k-1}), delta = arg(-sum d^4) / 4, quadrant of d e^{-i delta})

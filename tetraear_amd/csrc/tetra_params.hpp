@@ -66,10 +66,37 @@ void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y,
                                int32_t *timing_milli, hipStream_t stream);
 // the matched filter and the loop in ONE kernel (the filter output stays in LDS); false when not instantiated for tp.ntaps
 // (the caller then makes the three launches)
+int tetra_gardner_fused_per_cu(int ntaps);                 // workgroups of the fused kernel a compute unit holds (0: not instantiated)
 bool tetra_gardner_fused_available(int ntaps, int rows);   // instantiated for the tap count, and not slower than the three launches at this size
+// seg (tetra_gardner_kernels.hpp GardnerSeg, or null): the carriers as two virtual carriers each (tp.n = a half's length,
+// rows = 2 x the physical carriers, outputs into the caller's temporaries); tetra_decide_launch joins them afterwards
+// Two segments per carrier (rounds of 4096 carriers or fewer: one loop wavefront per compute unit leaves seven eighths of the
+// chip idle, and the loop's time is symbols x instructions whatever shares the unit).  The loop filter is a contraction: a
+// second loop started anywhere converges onto the first one's trajectory with the loop's time constant (~75 symbols at 1 %
+// noise bandwidth), so a carrier's chunk is walked as TWO virtual carriers -- samples [0, n_v) and [n - n_v, n), n_v = n / 2
+// plus an overlap of 512 warm-up symbols -- and the two symbol streams are joined at a seam near the overlap's end, where the
+// second loop has converged and the first is still clear of its segment's end: each half records the index and the instant of
+// its first symbol at or behind the seam, and k_tetra_stitch joins them (the instants tell whether both mean the same symbol).
+struct GardnerSeg {
+    int32_t rows_phys;        // physical carriers; the kernel's `rows` counts the virtual ones (2 rows_phys), first halves first
+    int32_t seg_off;          // samples from a carrier's first sample to its second half's first (0: no segments)
+    int32_t seam_a, seam_b;   // the seam in the first / the second half's own sample coordinates
+    int32_t k_mid_a;          // the PHYSICAL chunk's middle symbol (an index of the first half; timing_milli comes from it)
+    int32_t *k_seam;          // [rows] index of the half's first symbol at or behind the seam (its symbol count if none)
+    float *t_seam;            // [rows] that symbol's instant relative to the seam, samples
+    // first halves write straight into the caller's rows (their symbols before the seam are final where they land); only the
+    // second halves go through a temporary.  Needs rows_phys % 16 == 0 (a loop wavefront's sixteen carriers all of one kind);
+    // null: both halves into the temporary, [2 rows_phys][max_soft]
+    float2 *soft_a;           // [rows_phys][pitch_a]
+    int32_t pitch_a;
+};
+
 bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
-                                int32_t *timing_milli, hipStream_t stream);
-void tetra_decide_launch(const TetraParams &tp, int rows, const float2 *soft, const int32_t *n_soft, uint8_t *hard, double *min_margin,
-                         hipStream_t stream);
+                                int32_t *timing_milli, hipStream_t stream, const GardnerSeg *seg = nullptr);
+// seg != null: the carriers' two halves are joined first (k_tetra_decide): soft_b [rows][cap_b] the second halves' symbols,
+// n_v / timing_v [2 rows] the halves' counts and timing; soft / n_soft / timing_milli receive the joined carrier
+void tetra_decide_launch(const TetraParams &tp, int rows, float2 *soft, int32_t *n_soft, uint8_t *hard, double *min_margin,
+                         hipStream_t stream, const GardnerSeg *seg = nullptr, const float2 *soft_b = nullptr, int cap_b = 0,
+                         const int32_t *n_v = nullptr, const int32_t *timing_v = nullptr, int32_t *timing_milli = nullptr);
 
 }  // namespace tdm

@@ -14,6 +14,10 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 base = bench.tetra_rows()
 fs = float(sys.argv[3]) if len(sys.argv) > 3 else bench.TETRA_FS
+import os
+if "GSEG" in os.environ:      # two halves per carrier on/off (tdm_debug_set)
+    from tetraear_amd import _lib
+    _lib.load().tdm_debug_set(b"gardner_segments", int(os.environ["GSEG"]))
 bd = BatchDemodulator(fs, bench.TETRA_N, rows, "cf32", mode=MODE_TETRA_GARDNER)
 bd.alloc_device_io()
 bd.upload(np.concatenate([base[i % 8] for i in range(rows)]))
@@ -24,4 +28,8 @@ bd.time_begin()
 for _ in range(steps):
     bd.enqueue()
 print(bd.time_end() / steps, bd.stage_times())
+out = bd.download()
+import hashlib
+print('n_soft', out[2][:8], 'sha', hashlib.sha256(out[0].tobytes()).hexdigest()[:12])
+np.savez(sys.argv[4], hard=out[0][:64], soft=out[1][:64], n_soft=out[2][:64], bp=out[3][:64]) if len(sys.argv) > 4 else None
 bd.close()
