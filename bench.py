@@ -1005,7 +1005,7 @@ def leg_gardner(rows, base, chk, steps):
     bd = BatchDemodulator(TETRA_FS, TETRA_N, rows, "cf32", mode=MODE_TETRA_GARDNER)
     bd.alloc_device_io()
     bd.upload(np.concatenate([base[i % TETRA_DISTINCT] for i in range(rows)]))
-    for _ in range(3):
+    for _ in range(max(3, steps)):      # (the loop kernel is clock-bound: as many untimed passes as timed ones, so the clocks have settled)
         bd.enqueue()
     bd.sync()
     bd.time_begin()

@@ -1,7 +1,8 @@
 """Randomised sweep of TDM_MODE_TETRA_GARDNER on the GPU: random chunk lengths, sample rates (3..8 samples/symbol), row
 strides, timing / carrier / symbol-clock offsets at 15..25 dB; decisions against the fp64 definition's loop
-(oracle/tetra_np.demod_gardner: decisions may differ where the definition's own derotated product lies within 0.1 rad of a quadrant boundary -- an fp32 loop against an fp64 one at 15 dB --, at most 2e-3 of them; count within one) and error-free against the transmitted dibits
-after acquisition; also the stand-alone RRC filter against the definition."""
+(oracle/tetra_np.demod_gardner: decisions may differ where the definition's own derotated product lies within 0.1 rad of a quadrant boundary -- an fp32 loop against an fp64 one at 15 dB --, at most 2e-3 of them; count within one
+-- evaluated as two halves where the plan runs two halves, tdm_plan_info.gardner_segments); also the stand-alone RRC filter
+against the definition."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -11,11 +12,11 @@ from tetraear_amd._lib import MODE_TETRA_GARDNER, check, ptr
 from tetraear_amd.batch import BatchDemodulator
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
-t0 = time.time(); bad = 0; cnt = 0; worst = 0.0
+t0 = time.time(); bad = 0; cnt = 0; worst = 0.0; halves = {}
 while time.time() - t0 < budget:
     fs = float(rng.choice([54000.0, 72000.0, 75000.0, 80000.0, 90000.0, 108000.0, 144000.0]))
-    n = int(rng.integers(3000, 20000))
-    rows = int(rng.integers(1, 4))
+    n = int(rng.integers(3000, 20000)) if rng.random() < 0.5 else int(rng.integers(20000, 70000))   # (the longer ones run as two halves per carrier)
+    rows = int(rng.integers(1, 4)) if rng.random() < 0.7 else int(rng.integers(15, 35))
     pitch = n + int(rng.integers(0, 9))
     xs, dibs = [], []
     for r in range(rows):
@@ -36,7 +37,8 @@ while time.time() - t0 < budget:
     for r in range(rows):
         cnt += 1
         h = hard[r, :max(ns[r] - 1, 0)]
-        rh, rdd, info = tetra_np.demod_gardner(xs[r].astype(np.complex128), fs)
+        rh, rdd, info = tetra_np.demod_gardner(xs[r].astype(np.complex128), fs, segments=bd.info.gardner_segments)
+        halves[bd.info.gardner_segments] = halves.get(bd.info.gardner_segments, 0) + 1
         m = min(len(h), len(rh))
         diff = np.flatnonzero(h[:m] != rh[:m])
         frac = len(diff) / m if m else 1.0
@@ -50,4 +52,4 @@ while time.time() - t0 < budget:
         if not ok:
             bad += 1; print("MISMATCH", fs, n, rows, pitch, ns[r], len(info["t"]), frac, mf_err)
     bd.close()
-print(f"{cnt} carriers, {bad} mismatches, worst fraction of differing decisions {worst:.2e}")
+print(f"{cnt} carriers ({halves.get(2, 0)} of them as two halves), {bad} mismatches, worst fraction of differing decisions {worst:.2e}")
