@@ -1032,8 +1032,8 @@ def leg_gardner(rows, base, chk, steps):
                  "worst_fraction_of_differing_decisions": worst, "rows_equal_their_prototype": bool(same),
                  "status": "decisions match the definition's loop (<= 1e-3 differing, count within one)" if (ok and same) else "DIFFERS from the definition"}
     return {"what": "TDM_MODE_TETRA_GARDNER: matched filter (producer wavefronts) -> LDS ring -> Gardner TED + PI loop + Farrow, four lanes per carrier, one kernel -> decisions"
-                    + (" (2 launches)" if halves == 1 else "; every carrier's chunk as two independently started loops (the second warms up over "
-                       "512 symbols before the seam), joined by a copy of the second half's symbols (3 launches)"),
+                    + (" (2 launches)" if halves == 1 else "; every carrier's chunk as %d independently started loops (each later one starts at a feed-forward "
+                       "timing estimate and warms up over 384 symbols before the seam it takes over at), joined by a copy of the later pieces' symbols (3 launches)" % halves),
             "loops_per_carrier": halves,
 
             "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s", "steps": steps, "stage_ms_per_launch": st,

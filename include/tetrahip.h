@@ -86,10 +86,10 @@ typedef struct tdm_plan_info {
     int32_t device;
     int32_t dec_engine;   /* decimator kernel the next call runs: 0 none, 1 cascade engine, 2 parallel form on doubles,
                              3 parallel form on the raw bytes (cu8 batches of at least 8 blocks per CU) */
-    int32_t gardner_segments; /* TDM_MODE_TETRA_GARDNER: 2 when every carrier's chunk is walked as two independently started
-                             loops joined at a seam (batches that would otherwise leave most of the device idle, chunks long
-                             enough for the second loop's 512 warm-up symbols; oracle/tetra_np.py demod_gardner(segments=2)),
-                             else 1; 0 in the other modes */
+    int32_t gardner_segments; /* TDM_MODE_TETRA_GARDNER: the number of independently started loops every carrier's chunk is
+                             walked as, joined at seams (2, 4 or 8 for batches that would otherwise leave most of the device
+                             idle, chunks long enough for a loop's 384 warm-up symbols; oracle/tetra_np.py
+                             demod_gardner(segments=K)), else 1; 0 in the other modes */
 } tdm_plan_info;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -106,8 +106,9 @@ TDM_API int tdm_last_error(char *buf, size_t buflen);
  *   "raw_min_blocks"  >= 0: decimator blocks below which a batch stays on the double-based kernel, for plans
  *                     created from now on                                                                   (default -1: 8 per CU)
  *   "gardner_fused"   0: TDM_MODE_TETRA_GARDNER as three launches (matched filter -> HBM -> loop -> decisions)  (default 1)
- *   "gardner_segments" 0: TDM_MODE_TETRA_GARDNER plans first used from now on walk every carrier's chunk in one piece instead of
- *                     as two halves joined at a seam (the default for batches that leave the device mostly idle)  (default 1)
+ *   "gardner_segments" 0: TDM_MODE_TETRA_GARDNER plans created from now on walk every carrier's chunk in one piece instead of
+ *                     as 2, 4 or 8 independently started pieces joined at seams (the default for batches that leave the
+ *                     device mostly idle); K > 1: at most K pieces                                          (default 1)
  *   "pfb_direct"      1: channeliser plans created from now on use the direct-DFT kernel                     (default 0)
  *   "pfb_rounds"      > 0: rounds per channeliser workgroup, for plans created from now on                  (default 0: computed)
  *   "pfb_halftile"    1: half-tile channeliser kernel for 8-bit formats, plans created from now on          (default 0) */

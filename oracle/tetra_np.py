@@ -161,30 +161,46 @@ def _farrow1(y, t):
     return ((c3 * mu + c2) * mu + c1) * mu + y0
 
 
-GARDNER_WARMUP_SYMBOLS = 512
+GARDNER_WARMUP_SYMBOLS = 384
+GARDNER_INIT_SAMPLES = 512      # what a piece's first instant is estimated from (the device's ring of filter outputs)
 
 
-def gardner_segments(n, sample_rate, ntaps=None):
-    """Geometry of the two-halves form of the Gardner receiver (the library's rule, tdm_hip.hip): each half is n_v samples
-    long -- half the chunk plus an overlap that holds 512 warm-up symbols of the second half's loop -- the second starts
-    seg_off samples into the chunk, and the seam lies `margin` samples before the first half's end (clear of its matched
-    filter's edge).  Returns None when the chunk is too short for two halves (n_v + 8 overlaps > n)."""
+GARDNER_MAX_PIECES = 8
+
+
+def gardner_segments(n, sample_rate, ntaps=None, pieces=2):
+    """Geometry of the Gardner receiver run as `pieces` independently started loops per chunk (the library's, tdm_hip.hip):
+    every piece is n_v samples long, piece p starts p * seg_step samples into the chunk (the last one ends with it); the
+    seam between pieces p and p + 1 lies `margin` samples before piece p's end (clear of its matched filter's edge), and
+    n_v is such that a piece has run for GARDNER_WARMUP_SYMBOLS (384) when it reaches the seam it takes over at:
+    in a piece's own coordinates  seam_out = n_v - margin  (none for the last piece),  seam_in = seam_out - seg_step  (none
+    for the first).  Returns None when the chunk is too short (a piece's own part, n / pieces, shorter than 1.9 warm-ups)."""
     sps = sample_rate / SYMBOL_RATE
     if ntaps is None:
         ntaps = len(rrc_taps(sps))
-    margin = (ntaps - 1) // 2 + 4 * int(np.ceil(sps)) + 8
-    ov = ((int(np.ceil(GARDNER_WARMUP_SYMBOLS * sps)) + margin + 1) // 2 + 1) & ~1
-    n_v = ((n // 2 + ov) + 1) & ~1
-    if n_v + 8 * ov > n:
+    K = int(pieces)
+    if K < 2:
         return None
-    seg_off = n - n_v
-    return dict(n_v=n_v, seg_off=seg_off, seam_a=n_v - margin, seam_b=n_v - margin - seg_off)
+    margin = (ntaps - 1) // 2 + 4 * int(np.ceil(sps)) + 8
+    lead = int(np.ceil(GARDNER_WARMUP_SYMBOLS * sps)) + margin
+    if 10 * n < 19 * K * lead:
+        return None
+    n_v0 = (n + (K - 1) * lead + K - 1) // K
+    seg_step = (n - n_v0) // (K - 1)
+    n_v = n - (K - 1) * seg_step
+    return dict(pieces=K, n_v=n_v, seg_step=seg_step, seam_out=n_v - margin, seam_in=n_v - margin - seg_step, margin=margin)
 
 
-def _gardner_loop(x, sample_rate, bn_t, zeta):
-    """one loop over one stretch of samples: symbols and their instants"""
+def _gardner_loop(x, sample_rate, bn_t, zeta, ff_init=False):
+    """one loop over one stretch of samples: symbols and their instants.
+    ff_init (the pieces of a chunk behind the first, demod_gardner(segments=K)): the first instant is not 1 + sps but the
+    instant in [1 + sps, 1 + 2 sps) that the square-law estimate over the first 512 filter outputs puts a symbol at --
+    the maximum of the symbol-rate component of |y|^2, tau = -arg(sum_n |y_n|^2 exp(-2 pi i n / sps)) sps / (2 pi) -- so that
+    a piece's loop starts next to the eye instead of wherever its first sample happens to lie: started half a symbol off,
+    the Gardner detector's error is zero too, and the loop can sit there for hundreds of symbols before it pulls in."""
     sps = sample_rate / SYMBOL_RATE
-    y = matched_filter(x, rrc_taps(sps))
+    taps = rrc_taps(sps)
+    y = matched_filter(x, taps)
     n = len(y)
     # loop constants (Rice, Digital Communications, eq. C.61) for detector gain kp (S-curve slope of the
     # normalised Gardner detector for RRC alpha 0.35, about 2.7 per symbol) and unit NCO gain
@@ -193,6 +209,12 @@ def _gardner_loop(x, sample_rate, bn_t, zeta):
     k1 = 4 * zeta * th / (1 + 2 * zeta * th + th * th) / kp
     k2 = 4 * th * th / (1 + 2 * zeta * th + th * th) / kp
     t = 1.0 + sps          # first symbol instant (the loop pulls it onto the eye)
+    if ff_init and n >= GARDNER_INIT_SAMPLES:
+        h = (len(taps) - 1) // 2
+        nn = np.arange(h, GARDNER_INIT_SAMPLES)
+        c = np.sum(np.abs(y[h:GARDNER_INIT_SAMPLES]) ** 2 * np.exp(-2j * np.pi * nn / sps))
+        tau = -np.angle(c) * sps / (2 * np.pi)
+        t = t + (tau - t) % sps
     integ = 0.0
     pw = 1.0               # running symbol power
     ts, s = [], []
@@ -220,31 +242,41 @@ def demod_gardner(x, sample_rate, bn_t=0.01, zeta=0.7071, segments=1):
     output; then the same differential detection, 4th-power carrier-offset estimate and quadrant slicer as demod().
     Returns (hard, derotated d_k, info with the symbol instants `t`).
 
-    segments = 2 (what the library does for batches that would leave most of the device idle, tdm_plan_info.gardner_segments):
-    the chunk as TWO independently started loops over samples [0, n_v) and [n - n_v, n) (gardner_segments: n_v = half the
-    chunk plus an overlap of 512 warm-up symbols), joined at a seam near the overlap's end: the first loop's symbols whose
-    instant's whole part lies before the seam, then the second loop's from the symbol that is the first loop's first one at
-    or behind the seam (their instants relative to the seam differ by a whole number of symbol periods, 0 unless the two
-    loops place a symbol on different sides of the seam).  The loop is a contraction, so the second loop runs onto the
-    first one's trajectory during its warm-up; the chunk's second half starts as every chunk does -- stateless."""
+    segments = K >= 2 (what the library does for batches that would leave most of the device idle, tdm_plan_info.gardner_segments):
+    the chunk as K independently started loops over the pieces of gardner_segments(pieces=K), joined at the K - 1 seams: a
+    piece's symbols up to its first one at or behind its outgoing seam, then the next piece's from the symbol that IS that
+    one (the two loops' instants relative to the seam differ by a whole number of symbol periods, 0 unless they place a
+    symbol on different sides of the seam).  The loop is a contraction, so a piece's loop -- started next to the eye
+    (_gardner_loop ff_init) -- runs onto its predecessor's trajectory during its 384 warm-up symbols; stateless like a chunk."""
     x = np.asarray(x, dtype=np.complex128)
     sps = sample_rate / SYMBOL_RATE
-    geo = gardner_segments(len(x), sample_rate) if segments == 2 else None
+    geo = gardner_segments(len(x), sample_rate, pieces=segments) if segments >= 2 else None
     if geo is None:
         s, ts = _gardner_loop(x, sample_rate, bn_t, zeta)
     else:
-        sa, ta = _gardner_loop(x[:geo["n_v"]], sample_rate, bn_t, zeta)
-        sb, tb = _gardner_loop(x[geo["seg_off"]:], sample_rate, bn_t, zeta)
-        ia = np.nonzero(np.floor(ta) >= geo["seam_a"])[0]
-        ib = np.nonzero(np.floor(tb) >= geo["seam_b"])[0]
-        ka = int(ia[0]) if len(ia) else len(sa)
-        jb = int(ib[0]) if len(ib) else len(sb)
-        rel_a = (ta[ka] - geo["seam_a"]) if ka < len(sa) else 0.0
-        rel_b = (tb[jb] - geo["seam_b"]) if jb < len(sb) else 0.0
-        d = int(np.rint(np.float32(rel_b - rel_a) / np.float32(sps)))
-        jb = min(max(jb - d, 0), len(sb))
-        s = np.concatenate([sa[:ka], sb[jb:]])
-        ts = np.concatenate([ta[:ka], tb[jb:] + geo["seg_off"]])
+        K, n_v, step = geo["pieces"], geo["n_v"], geo["seg_step"]
+        s_parts, t_parts = [], []
+        start = 0                 # index of the piece's first kept symbol
+        t_out_prev = 0.0
+        for p in range(K):
+            sp, tp = _gardner_loop(x[p * step:p * step + n_v], sample_rate, bn_t, zeta, ff_init=p > 0)
+            if p > 0:
+                i_in = np.nonzero(np.floor(tp) >= geo["seam_in"])[0]
+                k_in = int(i_in[0]) if len(i_in) else len(sp)
+                rel_in = (tp[k_in] - geo["seam_in"]) if k_in < len(sp) else 0.0
+                d = int(np.rint(np.float32(rel_in - t_out_prev) / np.float32(sps)))
+                start = min(max(k_in - d, 0), len(sp))
+            end = len(sp)
+            if p < K - 1:
+                i_out = np.nonzero(np.floor(tp) >= geo["seam_out"])[0]
+                k_out = int(i_out[0]) if len(i_out) else len(sp)
+                t_out_prev = (tp[k_out] - geo["seam_out"]) if k_out < len(sp) else 0.0
+                end = k_out
+            end = max(end, start)
+            s_parts.append(sp[start:end])
+            t_parts.append(tp[start:end] + p * step)
+        s = np.concatenate(s_parts)
+        ts = np.concatenate(t_parts)
     d = s[1:] * np.conj(s[:-1])
     if len(d) == 0:
         return np.zeros(0, np.uint8), d, dict(t=ts)

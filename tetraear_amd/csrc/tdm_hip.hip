@@ -51,7 +51,7 @@ static DebugSwitch g_debug[] = {
     {"pfb_direct", {0}, 0},              // 1: channeliser plans made from now on use the direct-DFT kernel
     {"pfb_rounds", {0}, 0},              // > 0: rounds per channeliser workgroup (plans made from now on)
     {"pfb_halftile", {0}, 0},
-    {"gardner_segments", {1}, 1},        // 0: TDM_MODE_TETRA_GARDNER plans used from now on walk whole chunks (no two halves per carrier)
+    {"gardner_segments", {1}, 1},        // 0: TDM_MODE_TETRA_GARDNER plans used from now on walk whole chunks; K > 1: at most K pieces per chunk
 };
 static DebugSwitch *debug_find(const char *key)
 {
@@ -432,12 +432,12 @@ struct tdm_plan {
     int64_t gy_pitch = 0;
     int gardner_fused_ok = -1;      // does the fused Gardner kernel serve this plan (tap count, carriers, device)?  -1: not asked yet
     // two segments per carrier (GardnerSeg): geometry and temporaries, made the first time the plan runs that way
-    int gardner_seg = -1;           // -1: not decided yet, 0: whole chunks, 1: two halves
+    int gardner_seg = 0;            // pieces per carrier's chunk (TDM_MODE_TETRA_GARDNER: 1 whole chunks, 2 / 4 / 8: GardnerSeg)
     GardnerSeg gseg{};
     TetraParams gtp{};              // the plan's parameters with a half's length and row capacity
-    float2 *d_gsoft = nullptr;      // [2 rows][gtp.max_soft] the halves' symbols
-    int32_t *d_gint = nullptr;      // [3][2 rows]: symbol counts, timing, seam indices
-    float *d_gts = nullptr;         // [2 rows] seam instants
+    float2 *d_gsoft = nullptr;      // [K or K - 1][rows][gtp.max_soft] the pieces' symbols
+    int32_t *d_gint = nullptr;      // [4][K rows]: symbol counts, timing, seam indices (in, out)
+    float *d_gts = nullptr;         // [2][K rows] seam instants (in, out)
     // staging for the host-pointer entry point
     void *d_iq = nullptr;
     size_t d_iq_bytes = 0;
@@ -774,37 +774,53 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             p->rows = n_carriers;
             p->device = device;
             p->gardner_fused_ok = (debug_value("gardner_fused") != 0 && tetra_gardner_fused_available(tp.ntaps, n_carriers)) ? 1 : 0;
-        // Two segments per carrier when the launch would otherwise leave most of the chip idle (one loop wavefront per
-        // sixteen carriers: at most one workgroup per compute unit) and the chunk is long enough for the second half's
-        // 512 warm-up symbols to be a small part of it; tdm_debug_set("gardner_segments", 0) keeps whole chunks
+        // K pieces per carrier when the launch would otherwise leave most of the chip idle (one loop wavefront per sixteen
+        // carriers; two workgroups share a compute unit up to 41 taps) and the chunk is long enough for a piece's 384 warm-up
+        // symbols to pay: K = the power of two up to 8 with the shortest pieces -- a piece's time is its length, times 1.18 when
+        // two loops share a compute unit (measured) -- among those whose workgroups are all resident at once;
+        // tdm_debug_set("gardner_segments", 0) keeps whole chunks, a value K > 1 allows at most K pieces
         {
             int cus = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
-            const int warm = 512;
+            const int warm = 384;             // (oracle/tetra_np.py GARDNER_WARMUP_SYMBOLS)
             const int margin = (ntaps_design - 1) / 2 + 4 * (int)std::ceil(tp.sps) + 8;   // (oracle/tetra_np.py gardner_segments)
-            const int ov = (((int)std::ceil(warm * tp.sps) + margin + 1) / 2 + 1) & ~1;
-            const int n_v = ((tp.n / 2 + ov) + 1) & ~1;
-            const bool fits = (int64_t)(p->rows + 15) / 16 <= cus && n_v + 8 * ov <= tp.n && p->gardner_fused_ok == 1 &&
-                          tetra_gardner_fused_per_cu(tp.ntaps) >= 2;   // (both halves' workgroups resident at once)
-            p->gardner_seg = (fits && debug_value("gardner_segments") != 0) ? 1 : 0;
-            if (p->gardner_seg) {
-                const int R = p->rows;
+            const int lead = (int)std::ceil(warm * tp.sps) + margin;
+            const long long allow = debug_value("gardner_segments");
+            const int per_cu = p->gardner_fused_ok == 1 ? tetra_gardner_fused_per_cu(tp.ntaps) : 0;
+            int best_k = 1, best_nv = 0, best_step = 0;
+            double best_cost = (double)tp.n * ((int64_t)(p->rows + 15) / 16 > cus ? 1.18 : 1.0);
+            for (int K = 2; K <= 8 && per_cu >= 1 && allow != 0 && (allow == 1 || K <= allow); K *= 2) {
+                const int64_t wgs = ((int64_t)K * p->rows + 15) / 16;
+                if (wgs > (int64_t)cus * (per_cu >= 2 ? 2 : 1)) break;            // (all pieces' workgroups resident at once)
+                if (10 * (int64_t)tp.n < 19 * (int64_t)K * lead) break;            // (a piece's own part at least 1.9 warm-ups)
+                const int n_v0 = (int)((tp.n + (int64_t)(K - 1) * lead + K - 1) / K);
+                const int step = (tp.n - n_v0) / (K - 1), n_v = tp.n - (K - 1) * step;
+                const double cost = (double)n_v * (wgs > cus ? 1.18 : 1.0);
+                if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best_nv = n_v; best_step = step; }
+            }
+            p->gardner_seg = best_k;
+            if (best_k > 1) {
+                const int R = p->rows, K = best_k, n_v = best_nv;
                 GardnerSeg &S = p->gseg;
                 S.rows_phys = R;
-                S.seg_off = tp.n - n_v;
-                S.seam_a = n_v - margin;
-                S.seam_b = S.seam_a - S.seg_off;
-                S.k_mid_a = (int)(0.5 * (double)tp.n / tp.sps);
+                S.pieces = K;
+                S.seg_step = best_step;
+                S.seam_out = n_v - margin;
+                S.seam_in = S.seam_out - best_step;
+                S.piece_mid = K / 2 - 1;
+                S.k_mid = (int)((0.5 * (double)tp.n - (double)S.piece_mid * (double)best_step) / tp.sps);
                 p->gtp = tp;
                 p->gtp.n = n_v;
                 p->gtp.max_soft = (int32_t)(1.02 * (double)n_v / tp.sps) + 8;
-                const bool direct = R % 16 == 0;   // (first halves straight into the caller's rows: GardnerSeg::soft_a)
-                HIP_TRY(hipMalloc((void **)&p->d_gsoft, (size_t)(direct ? 1 : 2) * R * p->gtp.max_soft * sizeof(float2)));
+                const bool direct = R % 16 == 0;   // (piece 0 straight into the caller's rows: GardnerSeg::soft_a)
+                HIP_TRY(hipMalloc((void **)&p->d_gsoft, (size_t)(direct ? K - 1 : K) * R * p->gtp.max_soft * sizeof(float2)));
                 S.pitch_a = direct ? tp.max_soft : 0;
-                HIP_TRY(hipMalloc((void **)&p->d_gint, (size_t)3 * 2 * R * sizeof(int32_t)));
-                HIP_TRY(hipMalloc((void **)&p->d_gts, (size_t)2 * R * sizeof(float)));
-                S.k_seam = p->d_gint + 4 * R;
-                S.t_seam = p->d_gts;
+                HIP_TRY(hipMalloc((void **)&p->d_gint, (size_t)4 * K * R * sizeof(int32_t)));
+                HIP_TRY(hipMalloc((void **)&p->d_gts, (size_t)2 * K * R * sizeof(float)));
+                S.k_in = p->d_gint + (size_t)2 * K * R;
+                S.k_out = p->d_gint + (size_t)3 * K * R;
+                S.t_in = p->d_gts;
+                S.t_out = p->d_gts + (size_t)K * R;
             }
         }
             // the matched-filter output of the three-launch path: [rows][pitch] cf32, rows 16-byte aligned; about 1 GB at 4096 x 32 768, so only a plan that ever takes the
@@ -895,7 +911,7 @@ int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info)
     info->in_fmt = plan->fmt;
     info->mode = plan->mode;
     info->device = plan->device;
-    info->gardner_segments = plan->mode == TDM_MODE_TETRA_GARDNER ? (plan->gardner_seg == 1 ? 2 : 1) : 0;
+    info->gardner_segments = plan->mode == TDM_MODE_TETRA_GARDNER ? plan->gardner_seg : 0;
     if (plan->mode == TDM_MODE_REFERENCE && h.decimated) {
         // (the rule of run_ref_fmt; a call with an input-rate pre-shift stays on the double-based kernel)
         const bool raw = h.raw_S > 0 && plan->fmt == TDM_CU8 && (int64_t)plan->rows * h.dec.p.nb >= h.raw_min_blocks;
@@ -930,26 +946,26 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
             constexpr int stages = 7;
             const bool fused = debug_value("gardner_fused") != 0;
             bool fused_done = false;
-            // (whether the fused kernel serves this plan, and whether as two halves per carrier, was settled when the plan was made)
-            if (fused && plan->gardner_fused_ok && plan->gardner_seg == 1) {
-                const int R = plan->rows;
+            // (whether the fused kernel serves this plan, and in how many pieces per chunk, was settled when the plan was made)
+            if (fused && plan->gardner_fused_ok && plan->gardner_seg > 1) {
+                const int R = plan->rows, K = plan->gardner_seg;
                 GardnerSeg S = plan->gseg;
                 S.soft_a = S.pitch_a ? (float2 *)soft : nullptr;
                 {
                     HipBackend::Scope s(be, ST_TETRA_LOOP);
-                    fused_done = tetra_gardner_fused_launch(plan->gtp, 2 * R, (const float2 *)iq, carrier_stride_samples, plan->d_gsoft,
-                                                            plan->d_gint, plan->d_gint + 2 * R, be.stream, &S);
+                    fused_done = tetra_gardner_fused_launch(plan->gtp, K * R, (const float2 *)iq, carrier_stride_samples, plan->d_gsoft,
+                                                            plan->d_gint, plan->d_gint + (size_t)K * R, be.stream, &S);
                 }
                 if (fused_done) {
-                    // decisions, with the halves joined first (the second halves' rows: behind the first halves' in the temporary
-                    // unless those went straight to the caller's rows)
+                    // decisions, with the pieces joined first (pieces 1..: behind piece 0's rows in the temporary unless those
+                    // went straight to the caller's rows)
                     HipBackend::Scope s(be, ST_TETRA_DECIDE);
-                    if (!S.soft_a)   // (carrier counts that are no multiple of sixteen: the first halves come out of the temporary too)
+                    if (!S.soft_a)   // (carrier counts that are no multiple of sixteen: piece 0 comes out of the temporary too)
                         HIP_TRY(hipMemcpy2DAsync(soft, (size_t)tp.max_soft * sizeof(float2), plan->d_gsoft, (size_t)plan->gtp.max_soft * sizeof(float2),
-                                                 (size_t)plan->gtp.max_soft * sizeof(float2), R, hipMemcpyDeviceToDevice, be.stream));
+                                                 (size_t)std::min(plan->gtp.max_soft, tp.max_soft) * sizeof(float2), R, hipMemcpyDeviceToDevice, be.stream));
                     tetra_decide_launch(tp, R, (float2 *)soft, n_soft, hard, min_margin, be.stream, &S,
                                         plan->d_gsoft + (S.soft_a ? 0 : (size_t)R * plan->gtp.max_soft), plan->gtp.max_soft, plan->d_gint,
-                                        plan->d_gint + 2 * R, best_phase);
+                                        plan->d_gint + (size_t)K * R, best_phase);
                     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
                     return TDM_OK;
                 }

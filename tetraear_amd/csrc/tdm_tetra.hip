@@ -113,7 +113,7 @@ void tetra_decide_launch(const TetraParams &tp, int rows, float2 *soft, int32_t 
 {
     if (seg) {
         const GardnerJoin J{soft_b, cap_b, n_v, timing_v, timing_milli, (float)tp.sps};
-        const dim3 grid((unsigned)((cap_b + kJoinTile - 1) / kJoinTile), (unsigned)rows);
+        const dim3 grid((unsigned)((cap_b + kJoinTile - 1) / kJoinTile), (unsigned)rows, (unsigned)(seg->pieces - 1));
         hipLaunchKernelGGL(k_tetra_gardner_join, grid, dim3(256), 0, stream, soft, (int)tp.max_soft, n_soft, *seg, J);
     }
     hipLaunchKernelGGL(k_tetra_decide, dim3((unsigned)rows), dim3(256), 0, stream, soft, (int)tp.max_soft, n_soft, hard, min_margin);

@@ -230,6 +230,7 @@ constexpr int kQuadOtherComponent = 0xB1;    // [1, 0, 3, 2]
 constexpr int kQuadMidStrobe = 0xEE;         // [2, 3, 2, 3]
 constexpr int kQuadFirst = 0x00;             // [0, 0, 0, 0]
 constexpr int kQuadSymbolPair = 0x44;        // [0, 1, 0, 1]
+constexpr int kQuadOtherPair = 0x4E;         // [2, 3, 0, 1]
 
 // NT = 0: the loop alone, one wavefront per workgroup, fed from the matched filter's output y in HBM (k_tetra_mf before it).
 // NT > 0: FUSED -- the workgroup has two more wavefronts that run the NT-tap matched filter for the loop's sixteen carriers
@@ -247,8 +248,8 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
     // input row of (virtual) carrier v: second halves start seg_off samples into their carrier's row
     auto row_in = [&](int v) {
         v = min(v, rows - 1);
-        const int h = (S.seg_off > 0 && v >= S.rows_phys) ? 1 : 0;
-        return y + (int64_t)(v - h * S.rows_phys) * y_pitch + h * S.seg_off;
+        const int h = S.pieces > 0 ? v / S.rows_phys : 0;     // the piece
+        return y + (int64_t)(v - h * S.rows_phys) * y_pitch + (int64_t)h * S.seg_step;
     };
     constexpr int kGRing = GardnerRing<FUSED>::slots, kGPitch = GardnerRing<FUSED>::pitch;
     __shared__ float2 ring[kGQuads * kGPitch];      // sample g of a carrier in slot g mod kGRing of its row (33 KB; fused: 66 KB)
@@ -394,10 +395,10 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
     const float *my = (const float *)(ring + quad * kGPitch) + c;      // component c of slot i: my[2 i]
     // soft symbols: the workgroup's rows from a scalar base, a lane's position in them as a 32-bit byte offset that also
     // counts the carrier's symbols (k = (off - off0) / 8)
-    // (two halves per carrier, GardnerSeg::soft_a: a wavefront of first halves writes into the caller's rows, one of second
+    // (pieces of a chunk, GardnerSeg::soft_a: a wavefront of first pieces writes into the caller's rows, one of later
     //  halves into the temporary, which then holds the second halves only)
-    const bool wg_a = S.seg_off > 0 && S.soft_a && (int)blockIdx.x * kGQuads < S.rows_phys;
-    const int wg_row0 = (int)blockIdx.x * kGQuads - ((S.seg_off > 0 && S.soft_a && !wg_a) ? S.rows_phys : 0);
+    const bool wg_a = S.pieces > 0 && S.soft_a && (int)blockIdx.x * kGQuads < S.rows_phys;
+    const int wg_row0 = (int)blockIdx.x * kGQuads - ((S.pieces > 0 && S.soft_a && !wg_a) ? S.rows_phys : 0);
     const uint32_t soft_pitch = wg_a ? (uint32_t)S.pitch_a : (uint32_t)P.max_soft;
     char *const wg_soft = (char *)((wg_a ? S.soft_a : soft) + (int64_t)wg_row0 * soft_pitch);
     const uint32_t off0 = (uint32_t)quad * soft_pitch * 8u + 4u * (uint32_t)c;
@@ -469,11 +470,13 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
     int m_mid = 0;
     float mu_mid = 0.f;                             // the instant of the chunk's middle symbol
     const int m_end = n - 3;                        // t <= n - 3  <=>  m < n - 3 or (m == n - 3 and mu == 0)
-    const bool first_half = S.seg_off > 0 && row < S.rows_phys;
-    const int k_mid = first_half ? S.k_mid_a : (int)(0.5 * (double)n / sps);
-    const int seam = S.seg_off > 0 ? (first_half ? S.seam_a : S.seam_b) : 0x7fffffff;
-    int k_seam_rec = -1;                            // the first symbol at or behind the seam: its index and its instant
-    float t_seam_rec = 0.f;
+    // (pieces of a chunk, GardnerSeg: the first symbol at or behind the piece's incoming and its outgoing seam -- index and instant)
+    const int piece = S.pieces > 0 ? row / S.rows_phys : 0;
+    const int k_mid = S.pieces > 0 ? (piece == S.piece_mid ? S.k_mid : 0x7fffffff) : (int)(0.5 * (double)n / sps);
+    const int seam_in = (S.pieces > 0 && piece > 0) ? S.seam_in : -0x7fffffff;
+    const int seam_out = (S.pieces > 0 && piece < S.pieces - 1) ? S.seam_out : 0x7fffffff;
+    int k_in_rec = seam_in < 0 ? 0 : -1, k_out_rec = -1;
+    float t_in_rec = 0.f, t_out_rec = 0.f;
     // a carrier takes its strobes in a turn when m < hi_v: see the block loop
     int hi_v = -0x7fffffff;
     // Software pipeline over the symbols: the strobe positions of the NEXT symbol are known as soon as this symbol's error is
@@ -553,7 +556,8 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
         if (SLOW) {
             const int k = (int)((off - off0) >> 3) + T;
             if (k == k_mid) { m_mid = m; mu_mid = mu; }
-            if (k_seam_rec < 0 && m >= seam) { k_seam_rec = k; t_seam_rec = (float)(m - seam) + mu; }
+            if (k_in_rec < 0 && m >= seam_in) { k_in_rec = k; t_in_rec = (float)(m - seam_in) + mu; }
+            if (k_out_rec < 0 && m >= seam_out) { k_out_rec = k; t_out_rec = (float)(m - seam_out) + mu; }
             if (k + 1 >= P.max_soft) hi_v = -0x7fffffff;     // the row is full
         }
         prev = val;
@@ -568,7 +572,48 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
         __syncthreads();                            // the first hand-over: the producers have made the ring's eight chunks
     }
     int produced = GardnerRing<true>::chunks;
-    aim(std::true_type{}, m, mu - half_lane);       // the first symbol's strobes (its samples lie in the first chunks: m = 1 + floor(sps))
+    if constexpr (FUSED) {
+        // The pieces of a chunk behind the first (GardnerSeg) start next to the eye: their first instant is the one in
+        // [1 + sps, 1 + 2 sps) at which the square-law estimate over the ring's 512 filter outputs puts a symbol --
+        // tau = -arg(sum_n |y_n|^2 exp(-2 pi i n / sps)) sps / (2 pi), oracle/tetra_np.py _gardner_loop(ff_init) -- instead of
+        // wherever the piece's first sample happens to lie: half a symbol off the eye the detector's error vanishes too, and a
+        // loop started there can sit for hundreds of symbols before it pulls in (seen in 1 of ~30 pieces).  A quad's four
+        // lanes take every fourth sample each.
+        if (S.pieces > 0 && __any(piece > 0)) {
+            constexpr int H = (NT - 1) / 2;
+            const int l4 = lane & 3;
+            const float w = -6.28318530717958648f / sps_f;
+            float sr, cr, ss, cs;
+            sincosf(w * (float)(H + l4), &sr, &cr);
+            sincosf(w * 4.f, &ss, &cs);
+            const float2 *rp = ring + quad * kGPitch;
+            float ar = 0.f, ai = 0.f;
+#pragma unroll 4
+            for (int nn = H + l4; nn < kGRing; nn += 4) {
+                const float2 v = rp[nn];
+                const float pw = fmaf(v.x, v.x, v.y * v.y);
+                ar = fmaf(pw, cr, ar);
+                ai = fmaf(pw, sr, ai);
+                const float cn = fmaf(cr, cs, -(sr * ss));
+                sr = fmaf(sr, cs, cr * ss);
+                cr = cn;
+            }
+            ar += gardner_quad<kQuadOtherComponent>(ar);
+            ai += gardner_quad<kQuadOtherComponent>(ai);
+            ar += gardner_quad<kQuadOtherPair>(ar);
+            ai += gardner_quad<kQuadOtherPair>(ai);
+            const float tau = -atan2f(ai, ar) * sps_f * 0.159154943091895336f;
+            const float base = 1.f + sps_f;
+            float dd = fmodf(tau - base, sps_f);
+            if (dd < 0.f) dd += sps_f;
+            const float t0 = base + dd;
+            if (piece > 0) {
+                m = (int)floorf(t0);
+                mu = t0 - floorf(t0);
+            }
+        }
+    }
+    aim(std::true_type{}, m, mu - half_lane);       // the first symbol's strobes (its samples lie in the first chunks: m < 2 + 2 sps)
     if (active) {
         symbol(std::true_type{}, std::true_type{}, 0);
         off += 8;
@@ -588,7 +633,8 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
         // wavefront's slowest carrier by more than three chunks waits for the ring to move on
         hi_v = (active && (c0 == 0 || m - back >= kGChunk * c0)) ? min(kGChunk * (c0 + kGChunks) - 2, m_end + (corner ? 1 : 0)) : -0x7fffffff;
         const bool near = (k <= k_mid && k_mid < k + kGBlock) || k + kGBlock > P.max_soft ||
-                          (k_seam_rec < 0 && m + kGBlock * back >= seam);     // (the block that may cross the seam)
+                          (k_in_rec < 0 && m + kGBlock * back >= seam_in) ||
+                          (k_out_rec < 0 && m + kGBlock * back >= seam_out);     // (the block that may cross a seam)
         // The block's turns run with the active carriers' lanes enabled and NO per-lane decision while every one of them can
         // take its strobes (one wavefront-uniform branch per turn: carriers of a wavefront move in step unless their clocks
         // differ by more than three chunks); what is left of the block when one cannot is done lane by lane.
@@ -650,29 +696,32 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
     if (mine && (lane & 3) == 0) {
         n_soft[row] = k;
         if (timing_milli) {
-            const double u = ((double)m_mid + (double)mu_mid) / sps;
+            const double u = ((double)piece * (double)S.seg_step + (double)m_mid + (double)mu_mid) / sps;
             timing_milli[row] = (int32_t)rint((u - rint(u)) * 1000.0);
         }
-        if (S.seg_off > 0) {
-            S.k_seam[row] = k_seam_rec < 0 ? k : k_seam_rec;
-            S.t_seam[row] = t_seam_rec;
+        if (S.pieces > 0) {
+            S.k_in[row] = k_in_rec < 0 ? k : k_in_rec;
+            S.t_in[row] = t_in_rec;
+            S.k_out[row] = k_out_rec < 0 ? k : k_out_rec;
+            S.t_out[row] = t_out_rec;
         }
     }
 }
 
-// ---- two halves per carrier (GardnerSeg): the join.  The first half's symbols before the seam already lie in the carrier's
-// row; the second half's follow from the symbol that IS the first half's first one behind the seam (the recorded instants say
-// which: they differ by a whole number of symbol periods, 0 unless the two loops place a symbol on different sides of the
-// seam).  A bulk copy of its own ahead of k_tetra_decide (grid: tiles of kJoinTile symbols x carriers), 0.05 ms for 4096
-// carriers.  Measured alternatives, join + decisions together (separate launches: 0.121 ms): the copy at the head of a deciding
-// workgroup 0.157, its stores among that workgroup's loads 0.170 (every wait for a load becomes a wait for the stores'
-// acknowledgements as well: one counter), behind its decisions 0.220 (a second latency chain), as workgroups of their own in
-// the deciding launch, which then reads the two halves where they lie, 0.152.
+// ---- pieces of a chunk (GardnerSeg): the join.  Piece 0's symbols before its outgoing seam already lie in the carrier's row;
+// every further piece's follow from the symbol that IS its predecessor's first one at or behind their seam (the recorded
+// instants say which: they differ by a whole number of symbol periods, 0 unless the two loops place a symbol on different
+// sides of the seam) up to its own outgoing seam.  A bulk copy of its own ahead of k_tetra_decide (grid: tiles of kJoinTile
+// symbols x carriers x pieces - 1), 0.05 ms for 4096 carriers in two pieces.  Measured alternatives for two pieces, join +
+// decisions together (separate launches: 0.121 ms): the copy at the head of a deciding workgroup 0.157, its stores among that
+// workgroup's loads 0.170 (every wait for a load becomes a wait for the stores' acknowledgements as well: one counter), behind
+// its decisions 0.220 (a second latency chain), as workgroups of their own in the deciding launch, which then reads the
+// pieces where they lie, 0.152.
 struct GardnerJoin {
-    const float2 *b;          // [rows][cap_b] the second halves' symbols
+    const float2 *b;          // [(pieces - 1) rows][cap_b] the symbols of pieces 1..
     int32_t cap_b;
-    const int32_t *n_v;       // [2 rows] the halves' symbol counts
-    const int32_t *timing_v;  // [2 rows]
+    const int32_t *n_v;       // [pieces rows] the pieces' symbol counts
+    const int32_t *timing_v;  // [pieces rows]
     int32_t *timing_milli;    // [rows] or null
     float sps;
 };
@@ -680,27 +729,35 @@ constexpr int kJoinPer = 8, kJoinTile = 256 * kJoinPer;
 __global__ __launch_bounds__(256) void k_tetra_gardner_join(float2 *__restrict__ soft, int max_soft, int32_t *__restrict__ n_soft,
                                                             const GardnerSeg S, const GardnerJoin J)
 {
-    const int row = blockIdx.y, tid = threadIdx.x;
-    const int R = S.rows_phys;
-    const int nB = J.n_v[R + row];
-    const int kA = min(S.k_seam[row], J.n_v[row]);
-    const int d = (int)rintf((S.t_seam[R + row] - S.t_seam[row]) / J.sps);
-    const int jB = min(max(S.k_seam[R + row] - d, 0), nB);
-    const int ns = min(kA + (nB - jB), max_soft);
-    if (blockIdx.x == 0 && tid == 0) {
-        n_soft[row] = ns;
-        if (J.timing_milli) J.timing_milli[row] = J.timing_v[row];
+    const int row = blockIdx.y, tid = threadIdx.x, mine = (int)blockIdx.z + 1;
+    const int R = S.rows_phys, K = S.pieces;
+    // the chain of pieces: where piece q's kept symbols start (j) and end (e) in its own row, and where they go (dst)
+    int dst = min(S.k_out[row], J.n_v[row]);     // piece 0 keeps [0, its outgoing seam)
+    int j_mine = 0, e_mine = 0, dst_mine = 0;
+    for (int q = 1; q < K; ++q) {
+        const int nq = J.n_v[q * R + row];
+        const int d = (int)rintf((S.t_in[q * R + row] - S.t_out[(q - 1) * R + row]) / J.sps);
+        const int j = min(max(S.k_in[q * R + row] - d, 0), nq);
+        const int e = max(q < K - 1 ? min(S.k_out[q * R + row], nq) : nq, j);
+        if (q == mine) { j_mine = j; e_mine = e; dst_mine = dst; }
+        dst += e - j;
     }
-    const float2 *__restrict__ B = J.b + (int64_t)row * J.cap_b + jB - kA;      // symbol i >= kA at B[i]
-    float2 *__restrict__ sr = soft + (int64_t)row * max_soft;
-    const int i0 = kA + blockIdx.x * kJoinTile + tid;
-    if (i0 >= ns) return;
+    const int ns = min(dst, max_soft);
+    if (blockIdx.x == 0 && mine == 1 && tid == 0) {
+        n_soft[row] = ns;
+        if (J.timing_milli) J.timing_milli[row] = J.timing_v[S.piece_mid * R + row];
+    }
+    const int cnt = min(e_mine - j_mine, max_soft - dst_mine);      // (a full row: what does not fit is dropped, as the loop does)
+    const float2 *__restrict__ B = J.b + ((int64_t)(mine - 1) * R + row) * J.cap_b + j_mine;
+    float2 *__restrict__ sr = soft + (int64_t)row * max_soft + dst_mine;
+    const int i0 = blockIdx.x * kJoinTile + tid;
+    if (i0 >= cnt) return;
     float2 v[kJoinPer];
 #pragma unroll
-    for (int j = 0; j < kJoinPer; ++j) v[j] = B[min(i0 + 256 * j, ns - 1)];
+    for (int t = 0; t < kJoinPer; ++t) v[t] = B[min(i0 + 256 * t, cnt - 1)];
 #pragma unroll
-    for (int j = 0; j < kJoinPer; ++j)
-        if (i0 + 256 * j < ns) sr[i0 + 256 * j] = v[j];
+    for (int t = 0; t < kJoinPer; ++t)
+        if (i0 + 256 * t < cnt) sr[i0 + 256 * t] = v[t];
 }
 
 // ---- decisions (the same detection as demod(): d_k = s_k conj(s_{k-1}), delta = arg(-sum d^4) / 4, quadrant of d e^{-i delta})

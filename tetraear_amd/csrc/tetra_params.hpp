@@ -73,28 +73,31 @@ bool tetra_gardner_fused_available(int ntaps, int rows);   // instantiated for t
 // Two segments per carrier (rounds of 4096 carriers or fewer: one loop wavefront per compute unit leaves seven eighths of the
 // chip idle, and the loop's time is symbols x instructions whatever shares the unit).  The loop filter is a contraction: a
 // second loop started anywhere converges onto the first one's trajectory with the loop's time constant (~75 symbols at 1 %
-// noise bandwidth), so a carrier's chunk is walked as TWO virtual carriers -- samples [0, n_v) and [n - n_v, n), n_v = n / 2
-// plus an overlap of 512 warm-up symbols -- and the two symbol streams are joined at a seam near the overlap's end, where the
-// second loop has converged and the first is still clear of its segment's end: each half records the index and the instant of
-// its first symbol at or behind the seam, and k_tetra_stitch joins them (the instants tell whether both mean the same symbol).
+// noise bandwidth), so a carrier's chunk is walked as K = 2, 4 or 8 virtual carriers -- pieces of n_v samples, piece p starting p * seg_step samples
+// into the chunk, n_v such that a piece -- started next to the eye by a feed-forward estimate -- has run for 384 warm-up symbols when it reaches the seam at which it takes over -- and
+// the symbol streams are joined at the K - 1 seams, each `margin` samples before a piece's end (clear of its matched filter's
+// edge): a piece records the index and the instant of its first symbol at or behind its incoming and its outgoing seam, and
+// k_tetra_gardner_join chains them (the instants tell whether two loops mean the same symbol).  oracle/tetra_np.py
+// gardner_segments / demod_gardner(segments=K) is the same construction in fp64.
 struct GardnerSeg {
-    int32_t rows_phys;        // physical carriers; the kernel's `rows` counts the virtual ones (2 rows_phys), first halves first
-    int32_t seg_off;          // samples from a carrier's first sample to its second half's first (0: no segments)
-    int32_t seam_a, seam_b;   // the seam in the first / the second half's own sample coordinates
-    int32_t k_mid_a;          // the PHYSICAL chunk's middle symbol (an index of the first half; timing_milli comes from it)
-    int32_t *k_seam;          // [rows] index of the half's first symbol at or behind the seam (its symbol count if none)
-    float *t_seam;            // [rows] that symbol's instant relative to the seam, samples
-    // first halves write straight into the caller's rows (their symbols before the seam are final where they land); only the
-    // second halves go through a temporary.  Needs rows_phys % 16 == 0 (a loop wavefront's sixteen carriers all of one kind);
-    // null: both halves into the temporary, [2 rows_phys][max_soft]
+    int32_t rows_phys;        // physical carriers; the kernel's `rows` counts the virtual ones (pieces x rows_phys), piece 0's first
+    int32_t pieces;           // K (0: no segments)
+    int32_t seg_step;         // samples from a piece's first sample to the next piece's first
+    int32_t seam_in, seam_out;   // the seams in a piece's own sample coordinates (the first piece has no seam_in, the last no seam_out)
+    int32_t piece_mid, k_mid; // the PHYSICAL chunk's middle symbol: which piece keeps it and its index there (timing_milli comes from it)
+    int32_t *k_in, *k_out;    // [rows] index of the piece's first symbol at or behind the seam (its symbol count if none)
+    float *t_in, *t_out;      // [rows] that symbol's instant relative to the seam, samples
+    // piece 0 writes straight into the caller's rows (its symbols before the seam are final where they land); only the other
+    // pieces go through a temporary.  Needs rows_phys % 16 == 0 (a loop wavefront's sixteen carriers all of one kind);
+    // null: all pieces into the temporary, [pieces rows_phys][max_soft]
     float2 *soft_a;           // [rows_phys][pitch_a]
     int32_t pitch_a;
 };
 
 bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
                                 int32_t *timing_milli, hipStream_t stream, const GardnerSeg *seg = nullptr);
-// seg != null: the carriers' two halves are joined first (k_tetra_decide): soft_b [rows][cap_b] the second halves' symbols,
-// n_v / timing_v [2 rows] the halves' counts and timing; soft / n_soft / timing_milli receive the joined carrier
+// seg != null: the carriers' pieces are joined first (k_tetra_gardner_join): soft_b [(pieces - 1) rows][cap_b] the symbols of
+// pieces 1.., n_v / timing_v [pieces rows] the pieces' counts and timing; soft / n_soft / timing_milli receive the joined carrier
 void tetra_decide_launch(const TetraParams &tp, int rows, float2 *soft, int32_t *n_soft, uint8_t *hard, double *min_margin,
                          hipStream_t stream, const GardnerSeg *seg = nullptr, const float2 *soft_b = nullptr, int cap_b = 0,
                          const int32_t *n_v = nullptr, const int32_t *timing_v = nullptr, int32_t *timing_milli = nullptr);

@@ -15,7 +15,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 base = bench.tetra_rows()
 fs = float(sys.argv[3]) if len(sys.argv) > 3 else bench.TETRA_FS
 import os
-if "GSEG" in os.environ:      # two halves per carrier on/off (tdm_debug_set)
+if "GSEG" in os.environ:      # pieces per chunk: 0 whole chunks, 1 the plan's choice, K at most K (tdm_debug_set)
     from tetraear_amd import _lib
     _lib.load().tdm_debug_set(b"gardner_segments", int(os.environ["GSEG"]))
 bd = BatchDemodulator(fs, bench.TETRA_N, rows, "cf32", mode=MODE_TETRA_GARDNER)

@@ -1,21 +1,22 @@
 """Randomised sweep of TDM_MODE_TETRA_GARDNER on the GPU: random chunk lengths, sample rates (3..8 samples/symbol), row
 strides, timing / carrier / symbol-clock offsets at 15..25 dB; decisions against the fp64 definition's loop
 (oracle/tetra_np.demod_gardner: decisions may differ where the definition's own derotated product lies within 0.1 rad of a quadrant boundary -- an fp32 loop against an fp64 one at 15 dB --, at most 2e-3 of them; count within one
--- evaluated as two halves where the plan runs two halves, tdm_plan_info.gardner_segments); also the stand-alone RRC filter
+-- evaluated in as many pieces per chunk as the plan runs, tdm_plan_info.gardner_segments); also the stand-alone RRC filter
 against the definition."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
 from oracle import tetra_np
 from tetraear_amd import synth
-from tetraear_amd._lib import MODE_TETRA_GARDNER, check, ptr
+from tetraear_amd._lib import MODE_TETRA_GARDNER, check, debug_option, ptr
 from tetraear_amd.batch import BatchDemodulator
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
 t0 = time.time(); bad = 0; cnt = 0; worst = 0.0; halves = {}
+sent = {"pieces": [0, 0], "whole": [0, 0]}
 while time.time() - t0 < budget:
     fs = float(rng.choice([54000.0, 72000.0, 75000.0, 80000.0, 90000.0, 108000.0, 144000.0]))
-    n = int(rng.integers(3000, 20000)) if rng.random() < 0.5 else int(rng.integers(20000, 70000))   # (the longer ones run as two halves per carrier)
+    n = int(rng.integers(3000, 20000)) if rng.random() < 0.5 else int(rng.integers(20000, 70000))   # (the longer ones run in pieces)
     rows = int(rng.integers(1, 4)) if rng.random() < 0.7 else int(rng.integers(15, 35))
     pitch = n + int(rng.integers(0, 9))
     xs, dibs = [], []
@@ -34,6 +35,19 @@ while time.time() - t0 < budget:
     hard = np.zeros((rows, ms), np.uint8); soft = np.zeros((rows, ms), np.complex64); ns = np.zeros(rows, np.int32)
     check(bd.lib.tdm_process(bd.handle, ptr(buf), pitch, None, None, ptr(hard), ptr(soft), ptr(ns), None, None))
     y = bd.rrc_filter(np.stack(xs))
+    pieces = bd.info.gardner_segments
+    if pieces > 1:      # the same batch as whole chunks: symbol errors against what was sent, both ways
+        with debug_option("gardner_segments", 0):
+            bw = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+            hw = np.zeros((rows, ms), np.uint8); sw = np.zeros((rows, ms), np.complex64); nw = np.zeros(rows, np.int32)
+            check(bw.lib.tdm_process(bw.handle, ptr(buf), pitch, None, None, ptr(hw), ptr(sw), ptr(nw), None, None))
+            bw.close()
+        for r in range(rows):
+            for tag, hh, nn_ in (("pieces", hard, ns), ("whole", hw, nw)):
+                h = hh[r, :max(nn_[r] - 1, 0)]
+                m = len(h)
+                e = min((int(np.sum(h[300:m - 8] != dibs[r][lag + 300:lag + m - 8])) for lag in range(40) if len(dibs[r]) - lag >= m), default=0)
+                sent[tag][0] += e; sent[tag][1] += max(m - 308, 0)
     for r in range(rows):
         cnt += 1
         h = hard[r, :max(ns[r] - 1, 0)]
@@ -52,4 +66,5 @@ while time.time() - t0 < budget:
         if not ok:
             bad += 1; print("MISMATCH", fs, n, rows, pitch, ns[r], len(info["t"]), frac, mf_err)
     bd.close()
-print(f"{cnt} carriers ({halves.get(2, 0)} of them as two halves), {bad} mismatches, worst fraction of differing decisions {worst:.2e}")
+print("symbol errors against what was sent, carriers run in pieces: in pieces %d of %d, as whole chunks %d of %d" % (*sent["pieces"], *sent["whole"]))
+print(f"{cnt} carriers (pieces per chunk: {dict(sorted(halves.items()))}), {bad} mismatches, worst fraction of differing decisions {worst:.2e}")
