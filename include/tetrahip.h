@@ -130,7 +130,11 @@ TDM_API int tdm_plan_destroy(tdm_plan *plan);
  *       reference to 1e-9 instead of 1e-10 (north_star: 1e-5); a HARD decision can differ only where its margin to a
  *       threshold is below that, which the per-carrier min_margin output reports: a caller that needs the reference's
  *       decision there re-runs the carriers with min_margin < 1e-8 on a plan without the option
- *       (tetraear_amd.batch.BatchDemodulator.process does). */
+ *       (tetraear_amd.batch.BatchDemodulator.process does).
+ *   "gardner_segments"  (TDM_MODE_TETRA_GARDNER) 0: whole chunks; 1: the plan's own rule (the state after tdm_plan_create);
+ *       K = 2..8: at most K independently started loops per chunk.  Waits for the plan's stream; tdm_plan_get_info reports
+ *       the number now in force.  In pieces the symbols before the first seam are those of the whole-chunk path bit for
+ *       bit, behind a seam the soft symbols agree with it to about 1 % of the largest symbol. */
 TDM_API int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value);
 TDM_API int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
 /* Serve another chunk length with the same plan (TDM_MODE_REFERENCE): the reference designs its filters inside every

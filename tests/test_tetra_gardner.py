@@ -358,3 +358,36 @@ def test_gpu_gardner_pieces_per_carrier_against_whole_chunks():
                     errs = _check_against_definition(sig[r][0], fs, h2[r], s2[r], sig[r][1], segments=K)
                     assert errs == 0, (fs, K, r, errs)
             print(f"fs {fs:.0f} n {n} rows {rows} pieces {K}: largest soft-symbol deviation from the whole-chunk path {worst:.4f} of the largest symbol")
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_segments_as_a_plan_option():
+    """tdm_plan_option "gardner_segments" on a live plan: whole chunks, the rule's choice, a cap -- each time the outputs of a
+    plan made that way; options of the wrong kind are refused."""
+    from tetraear_amd._lib import MODE_TETRA, MODE_TETRA_GARDNER, TetraHipError, debug_option
+    from tetraear_amd.batch import BatchDemodulator
+    fs, n, rows = 72000.0, 32768, 16
+    sig = [_gardner_case(n, fs, 3100 + r, 0.05 * r - 0.3, float(r * 11 - 80), 20.0, float((r % 3) - 1) * 80.0) for r in range(rows)]
+    iq = np.concatenate([s[0] for s in sig])
+    fresh = {}
+    for allow in (0, 1, 2):
+        with debug_option("gardner_segments", allow):
+            bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+            fresh[allow] = (bd.info.gardner_segments, bd.process(iq))
+            bd.close()
+    assert [fresh[a][0] for a in (0, 1, 2)] == [1, 8, 2]
+    bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+    for allow in (2, 0, 1, 0):
+        bd.set_gardner_segments(allow)
+        assert bd.info.gardner_segments == fresh[allow][0]
+        h, s, t, m = bd.process(iq)
+        for r in range(rows):
+            assert np.array_equal(h[r], fresh[allow][1][0][r]) and np.array_equal(s[r], fresh[allow][1][1][r]), (allow, r)
+        assert np.array_equal(t, fresh[allow][1][2])
+    with pytest.raises(TetraHipError):
+        bd.set_gardner_segments(9)
+    bd.close()
+    bf = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA)
+    with pytest.raises(TetraHipError):
+        bf.set_gardner_segments(0)
+    bf.close()

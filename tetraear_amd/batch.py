@@ -74,6 +74,13 @@ class BatchDemodulator:
         self.fast_pre_shift = bool(on)
         return self
 
+    def set_gardner_segments(self, pieces=1):
+        """tdm_plan_option "gardner_segments" (MODE_TETRA_GARDNER): 0 whole chunks, 1 the plan's own rule, K at most K
+        independently started loops per chunk; `info.gardner_segments` then says how many are in force."""
+        check(self.lib.tdm_plan_option(self.handle, b"gardner_segments", int(pieces)))
+        check(self.lib.tdm_plan_get_info(self.handle, C.byref(self.info)))
+        return self
+
     def resize(self, n_samples):
         """Serve another chunk length with this plan (tdm_plan_resize): tables of a new length are built once (a fraction of
         a millisecond), a length seen before is a look-up; `info` then describes the new length.  Device I/O buffers made

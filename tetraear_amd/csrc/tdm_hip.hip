@@ -432,6 +432,7 @@ struct tdm_plan {
     int64_t gy_pitch = 0;
     int gardner_fused_ok = -1;      // does the fused Gardner kernel serve this plan (tap count, carriers, device)?  -1: not asked yet
     // two segments per carrier (GardnerSeg): geometry and temporaries, made the first time the plan runs that way
+    int gardner_ntaps_design = 0;   // the RRC filter's designed length (before the padding to an instantiated one)
     int gardner_seg = 0;            // pieces per carrier's chunk (TDM_MODE_TETRA_GARDNER: 1 whole chunks, 2 / 4 / 8: GardnerSeg)
     GardnerSeg gseg{};
     TetraParams gtp{};              // the plan's parameters with a half's length and row capacity
@@ -634,6 +635,65 @@ static size_t fmt_bytes(int fmt) { return fmt == TDM_CU8 || fmt == TDM_CS8 ? 2 :
 
 static void sync_scratch_release(int device, hipStream_t st);   // (find_sync's per-stream scratch, below)
 
+// TDM_MODE_TETRA_GARDNER: K pieces per carrier's chunk when the launch would otherwise leave most of the chip idle (one loop
+// wavefront per sixteen carriers; two workgroups share a compute unit up to 41 taps) and the chunk is long enough for a
+// piece's 384 warm-up symbols to pay: K = the power of two up to 8 with the shortest pieces -- a piece's time is its length,
+// times 1.18 when two loops share a compute unit (measured) -- among those whose workgroups are all resident at once.
+// allow: 0 whole chunks, 1 the rule's choice, K > 1 at most K pieces (tdm_plan_option / tdm_debug_set "gardner_segments").
+// Called when the plan is made and when the option changes (the stream idle): sets plan->gardner_seg, the geometry and the
+// temporaries.
+static int gardner_choose_pieces(tdm_plan *p, long long allow)
+{
+    const TetraParams &tp = p->tp;
+    for (void **q : {(void **)&p->d_gsoft, (void **)&p->d_gint, (void **)&p->d_gts}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    p->gseg = GardnerSeg{};
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    const int warm = 384;             // (oracle/tetra_np.py GARDNER_WARMUP_SYMBOLS)
+    const int margin = (p->gardner_ntaps_design - 1) / 2 + 4 * (int)std::ceil(tp.sps) + 8;   // (oracle/tetra_np.py gardner_segments)
+    const int lead = (int)std::ceil(warm * tp.sps) + margin;
+    const int per_cu = p->gardner_fused_ok == 1 ? tetra_gardner_fused_per_cu(tp.ntaps) : 0;
+    int best_k = 1, best_nv = 0, best_step = 0;
+    double best_cost = (double)tp.n * ((int64_t)(p->rows + 15) / 16 > cus ? 1.18 : 1.0);
+    for (int K = 2; K <= 8 && per_cu >= 1 && allow != 0 && (allow == 1 || K <= allow); K *= 2) {
+        const int64_t wgs = ((int64_t)K * p->rows + 15) / 16;
+        if (wgs > (int64_t)cus * (per_cu >= 2 ? 2 : 1)) break;            // (all pieces' workgroups resident at once)
+        if (10 * (int64_t)tp.n < 19 * (int64_t)K * lead) break;            // (a piece's own part at least 1.9 warm-ups)
+        const int n_v0 = (int)((tp.n + (int64_t)(K - 1) * lead + K - 1) / K);
+        const int step = (tp.n - n_v0) / (K - 1), n_v = tp.n - (K - 1) * step;
+        const double cost = (double)n_v * (wgs > cus ? 1.18 : 1.0);
+        if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best_nv = n_v; best_step = step; }
+    }
+    p->gardner_seg = best_k;
+    if (best_k > 1) {
+        const int R = p->rows, K = best_k, n_v = best_nv;
+        GardnerSeg &S = p->gseg;
+        S.rows_phys = R;
+        S.pieces = K;
+        S.seg_step = best_step;
+        S.seam_out = n_v - margin;
+        S.seam_in = S.seam_out - best_step;
+        S.piece_mid = K / 2 - 1;
+        S.k_mid = (int)((0.5 * (double)tp.n - (double)S.piece_mid * (double)best_step) / tp.sps);
+        p->gtp = tp;
+        p->gtp.n = n_v;
+        p->gtp.max_soft = (int32_t)(1.02 * (double)n_v / tp.sps) + 8;
+        const bool direct = R % 16 == 0;   // (piece 0 straight into the caller's rows: GardnerSeg::soft_a)
+        HIP_TRY(hipMalloc((void **)&p->d_gsoft, (size_t)(direct ? K - 1 : K) * R * p->gtp.max_soft * sizeof(float2)));
+        S.pitch_a = direct ? tp.max_soft : 0;
+        HIP_TRY(hipMalloc((void **)&p->d_gint, (size_t)4 * K * R * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&p->d_gts, (size_t)2 * K * R * sizeof(float)));
+        S.k_in = p->d_gint + (size_t)2 * K * R;
+        S.k_out = p->d_gint + (size_t)3 * K * R;
+        S.t_in = p->d_gts;
+        S.t_out = p->d_gts + (size_t)K * R;
+    }
+    return TDM_OK;
+}
+
 static void plan_free(tdm_plan *p)
 {
     if (!p) return;
@@ -774,55 +834,11 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             p->rows = n_carriers;
             p->device = device;
             p->gardner_fused_ok = (debug_value("gardner_fused") != 0 && tetra_gardner_fused_available(tp.ntaps, n_carriers)) ? 1 : 0;
-        // K pieces per carrier when the launch would otherwise leave most of the chip idle (one loop wavefront per sixteen
-        // carriers; two workgroups share a compute unit up to 41 taps) and the chunk is long enough for a piece's 384 warm-up
-        // symbols to pay: K = the power of two up to 8 with the shortest pieces -- a piece's time is its length, times 1.18 when
-        // two loops share a compute unit (measured) -- among those whose workgroups are all resident at once;
-        // tdm_debug_set("gardner_segments", 0) keeps whole chunks, a value K > 1 allows at most K pieces
-        {
-            int cus = 0;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
-            const int warm = 384;             // (oracle/tetra_np.py GARDNER_WARMUP_SYMBOLS)
-            const int margin = (ntaps_design - 1) / 2 + 4 * (int)std::ceil(tp.sps) + 8;   // (oracle/tetra_np.py gardner_segments)
-            const int lead = (int)std::ceil(warm * tp.sps) + margin;
-            const long long allow = debug_value("gardner_segments");
-            const int per_cu = p->gardner_fused_ok == 1 ? tetra_gardner_fused_per_cu(tp.ntaps) : 0;
-            int best_k = 1, best_nv = 0, best_step = 0;
-            double best_cost = (double)tp.n * ((int64_t)(p->rows + 15) / 16 > cus ? 1.18 : 1.0);
-            for (int K = 2; K <= 8 && per_cu >= 1 && allow != 0 && (allow == 1 || K <= allow); K *= 2) {
-                const int64_t wgs = ((int64_t)K * p->rows + 15) / 16;
-                if (wgs > (int64_t)cus * (per_cu >= 2 ? 2 : 1)) break;            // (all pieces' workgroups resident at once)
-                if (10 * (int64_t)tp.n < 19 * (int64_t)K * lead) break;            // (a piece's own part at least 1.9 warm-ups)
-                const int n_v0 = (int)((tp.n + (int64_t)(K - 1) * lead + K - 1) / K);
-                const int step = (tp.n - n_v0) / (K - 1), n_v = tp.n - (K - 1) * step;
-                const double cost = (double)n_v * (wgs > cus ? 1.18 : 1.0);
-                if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best_nv = n_v; best_step = step; }
+            p->gardner_ntaps_design = ntaps_design;
+            {
+                const int rc = gardner_choose_pieces(p.get(), debug_value("gardner_segments"));
+                if (rc != TDM_OK) return rc;
             }
-            p->gardner_seg = best_k;
-            if (best_k > 1) {
-                const int R = p->rows, K = best_k, n_v = best_nv;
-                GardnerSeg &S = p->gseg;
-                S.rows_phys = R;
-                S.pieces = K;
-                S.seg_step = best_step;
-                S.seam_out = n_v - margin;
-                S.seam_in = S.seam_out - best_step;
-                S.piece_mid = K / 2 - 1;
-                S.k_mid = (int)((0.5 * (double)tp.n - (double)S.piece_mid * (double)best_step) / tp.sps);
-                p->gtp = tp;
-                p->gtp.n = n_v;
-                p->gtp.max_soft = (int32_t)(1.02 * (double)n_v / tp.sps) + 8;
-                const bool direct = R % 16 == 0;   // (piece 0 straight into the caller's rows: GardnerSeg::soft_a)
-                HIP_TRY(hipMalloc((void **)&p->d_gsoft, (size_t)(direct ? K - 1 : K) * R * p->gtp.max_soft * sizeof(float2)));
-                S.pitch_a = direct ? tp.max_soft : 0;
-                HIP_TRY(hipMalloc((void **)&p->d_gint, (size_t)4 * K * R * sizeof(int32_t)));
-                HIP_TRY(hipMalloc((void **)&p->d_gts, (size_t)2 * K * R * sizeof(float)));
-                S.k_in = p->d_gint + (size_t)2 * K * R;
-                S.k_out = p->d_gint + (size_t)3 * K * R;
-                S.t_in = p->d_gts;
-                S.t_out = p->d_gts + (size_t)K * R;
-            }
-        }
             // the matched-filter output of the three-launch path: [rows][pitch] cf32, rows 16-byte aligned; about 1 GB at 4096 x 32 768, so only a plan that ever takes the
             // three launches allocates it (the default fused kernel keeps the filter output in LDS)
             p->gy_pitch = (n_samples + 1) & ~(int64_t)1;
@@ -873,6 +889,13 @@ int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value)
         if (plan->mode != TDM_MODE_REFERENCE) return fail(TDM_ERR_UNSUPPORTED, "fast_pre_shift is a reference-mode option");
         plan->fast_pre_shift = value ? 1 : 0;
         return TDM_OK;
+    }
+    if (std::strcmp(key, "gardner_segments") == 0) {
+        if (plan->mode != TDM_MODE_TETRA_GARDNER) return fail(TDM_ERR_UNSUPPORTED, "gardner_segments is an option of TDM_MODE_TETRA_GARDNER plans");
+        if (value < 0 || value > 8) return fail(TDM_ERR_INVALID, "gardner_segments: 0 (whole chunks), 1 (the plan's rule) or the largest number of pieces allowed (2..8)");
+        HIP_TRY(hipSetDevice(plan->device));
+        HIP_TRY(hipStreamSynchronize(plan->stream));     // (calls in flight use the temporaries)
+        return gardner_choose_pieces(plan, value);
     }
     return fail(TDM_ERR_INVALID, std::string("tdm_plan_option: unknown option '") + key + "'");
 }
