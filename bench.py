@@ -1015,7 +1015,27 @@ def leg_gardner(rows, base, chk, steps):
     st = bd.stage_times()
     hard, soft, n_soft, tm, mm = bd.download()
     halves = int(bd.info.gardner_segments)
+
+    def timed(b):
+        for _ in range(max(3, steps)):
+            b.enqueue()
+        b.sync()
+        b.time_begin()
+        for _ in range(steps):
+            b.enqueue()
+        return b.time_end() / steps
+    # beside it: the same batch as whole chunks (plan option), and a quarter of it (more pieces per chunk: the plan's rule)
+    side = {}
+    if halves > 1:
+        bd.set_gardner_segments(0)
+        side["whole_chunks_ms_per_step"] = timed(bd)
     bd.close()
+    if rows >= 4 * TETRA_DISTINCT:
+        bq = BatchDemodulator(TETRA_FS, TETRA_N, rows // 4, "cf32", mode=MODE_TETRA_GARDNER)
+        bq.alloc_device_io()
+        bq.upload(np.concatenate([base[i % TETRA_DISTINCT] for i in range(rows // 4)]))
+        side["quarter_batch"] = {"carriers": rows // 4, "loops_per_carrier": int(bq.info.gardner_segments), "ms_per_step": timed(bq)}
+        bq.close()
     nsym = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
     check = {"status": "no pinned decisions for this workload"}
     if chk is not None and "gardner_hard" in chk.files and rows >= TETRA_DISTINCT:
@@ -1034,7 +1054,7 @@ def leg_gardner(rows, base, chk, steps):
     return {"what": "TDM_MODE_TETRA_GARDNER: matched filter (producer wavefronts) -> LDS ring -> Gardner TED + PI loop + Farrow, four lanes per carrier, one kernel -> decisions"
                     + (" (2 launches)" if halves == 1 else "; every carrier's chunk as %d independently started loops (each later one starts at a feed-forward "
                        "timing estimate and warms up over 384 symbols before the seam it takes over at), joined by a copy of the later pieces' symbols (3 launches)" % halves),
-            "loops_per_carrier": halves,
+            "loops_per_carrier": halves, **side,
 
             "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6, "unit": "Msym/s", "steps": steps, "stage_ms_per_launch": st,
             "output_check": check}
