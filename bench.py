@@ -345,6 +345,11 @@ def spawn_local_ranks(n):
     fails.  The environment is what torch.distributed.run would have set."""
     import socket
     import subprocess
+    if not os.environ.get("TDM_BENCH_TEST_HOOK"):      # (the CPU-tier test's stand-in device has no count to ask for)
+        from tetraear_amd import _lib
+        have = int(_lib.load().tdm_device_count())
+        if have < n:
+            raise SystemExit(f"bench: --gpus {n} needs {n} devices on this node, the library sees " + (str(have) if have >= 0 else f"none (tdm_device_count: status {have})"))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
