@@ -1,3 +1,6 @@
+"""Compares two dumps of tools/run_gardner.py (argv[4] there: an .npz of the first 64 rows) -- e.g. the Gardner mode in pieces
+against whole chunks (GSEG=0): symbol counts, differing hard decisions, largest soft-symbol difference per row.
+usage: cmp_gardner.py a.npz b.npz"""
 import numpy as np, sys
 a=np.load(sys.argv[1]); b=np.load(sys.argv[2])
 for r in range(0,64,7):
