@@ -667,7 +667,7 @@ static int gardner_choose_pieces(tdm_plan *p, long long allow)
         const double cost = (double)n_v * (wgs > cus ? 1.18 : 1.0);
         if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best_nv = n_v; best_step = step; }
     }
-    p->gardner_seg = best_k;
+    p->gardner_seg = 1;   // (whole chunks unless everything below succeeds: a failed allocation leaves a plan that works)
     if (best_k > 1) {
         const int R = p->rows, K = best_k, n_v = best_nv;
         GardnerSeg &S = p->gseg;
@@ -682,14 +682,23 @@ static int gardner_choose_pieces(tdm_plan *p, long long allow)
         p->gtp.n = n_v;
         p->gtp.max_soft = (int32_t)(1.02 * (double)n_v / tp.sps) + 8;
         const bool direct = R % 16 == 0;   // (piece 0 straight into the caller's rows: GardnerSeg::soft_a)
-        HIP_TRY(hipMalloc((void **)&p->d_gsoft, (size_t)(direct ? K - 1 : K) * R * p->gtp.max_soft * sizeof(float2)));
         S.pitch_a = direct ? tp.max_soft : 0;
-        HIP_TRY(hipMalloc((void **)&p->d_gint, (size_t)4 * K * R * sizeof(int32_t)));
-        HIP_TRY(hipMalloc((void **)&p->d_gts, (size_t)2 * K * R * sizeof(float)));
+        if (hipMalloc((void **)&p->d_gsoft, (size_t)(direct ? K - 1 : K) * R * p->gtp.max_soft * sizeof(float2)) != hipSuccess ||
+            hipMalloc((void **)&p->d_gint, (size_t)4 * K * R * sizeof(int32_t)) != hipSuccess ||
+            hipMalloc((void **)&p->d_gts, (size_t)2 * K * R * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            for (void **q : {(void **)&p->d_gsoft, (void **)&p->d_gint, (void **)&p->d_gts}) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
+            p->gseg = GardnerSeg{};
+            return fail(TDM_ERR_NOMEM, "TETRA_GARDNER plan: no memory for the temporaries of " + std::to_string(K) + " pieces per chunk (the plan walks whole chunks)");
+        }
         S.k_in = p->d_gint + (size_t)2 * K * R;
         S.k_out = p->d_gint + (size_t)3 * K * R;
         S.t_in = p->d_gts;
         S.t_out = p->d_gts + (size_t)K * R;
+        p->gardner_seg = K;
     }
     return TDM_OK;
 }
@@ -836,8 +845,9 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
             p->gardner_fused_ok = (debug_value("gardner_fused") != 0 && tetra_gardner_fused_available(tp.ntaps, n_carriers)) ? 1 : 0;
             p->gardner_ntaps_design = ntaps_design;
             {
+                // (no memory for the pieces' temporaries: the plan is made all the same and walks whole chunks)
                 const int rc = gardner_choose_pieces(p.get(), debug_value("gardner_segments"));
-                if (rc != TDM_OK) return rc;
+                if (rc != TDM_OK && rc != TDM_ERR_NOMEM) return rc;
             }
             // the matched-filter output of the three-launch path: [rows][pitch] cf32, rows 16-byte aligned; about 1 GB at 4096 x 32 768, so only a plan that ever takes the
             // three launches allocates it (the default fused kernel keeps the filter output in LDS)
