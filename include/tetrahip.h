@@ -136,6 +136,12 @@ TDM_API int tdm_plan_destroy(tdm_plan *plan);
  *       the number now in force.  In pieces the symbols before the first seam are those of the whole-chunk path bit for
  *       bit, behind a seam the soft symbols agree with it to about 1 % of the largest symbol. */
 TDM_API int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value);
+/* Host only (no device): the geometry of a TDM_MODE_TETRA_GARDNER chunk of n_samples walked in `pieces` independently started
+ * loops -- out[0..5] = piece length, samples from a piece's start to the next one's, the incoming and the outgoing seam in a
+ * piece's own coordinates, the seam's distance from a piece's end, warm-up + margin -- the arithmetic of
+ * oracle/tetra_np.py gardner_segments (a CPU-tier test holds the two together); TDM_ERR_UNSUPPORTED when the chunk is too
+ * short for that many pieces. */
+TDM_API int tdm_gardner_geometry(double sample_rate, int64_t n_samples, int32_t pieces, int32_t *out);
 TDM_API int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info);
 /* Serve another chunk length with the same plan (TDM_MODE_REFERENCE): the reference designs its filters inside every
  * process() call (processor.py:78, :254), so its callers read whatever lengths they like (ui/modern.py:1912 128 Ki,

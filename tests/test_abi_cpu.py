@@ -102,3 +102,26 @@ def test_ctypes_plan_info_has_the_headers_layout(tmp_path):
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got[0] == ctypes.sizeof(_lib.PlanInfo)
     assert got[1:] == [getattr(_lib.PlanInfo, f).offset for f in fields]
+
+
+def test_gardner_geometry_is_the_definitions():
+    """tdm_gardner_geometry (host only) against oracle/tetra_np.gardner_segments: the library's plan code and the fp64
+    definition cut a chunk in the same places -- every sample rate a plan takes, odd and even lengths, 2..8 pieces, and the
+    same verdict on chunks too short for them."""
+    from oracle import tetra_np
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    seen = 0
+    for fs in (54000.0, 72000.0, 75000.0, 80000.0, 90000.0, 108000.0, 126000.0, 144000.0):
+        for n in [4096, 8192, 30001, 32768, 65536, 131072] + [int(v) for v in rng.integers(2000, 131072, 12)]:
+            for K in (2, 3, 4, 8):
+                out = np.zeros(6, np.int32)
+                rc = L.tdm_gardner_geometry(C.c_double(fs), C.c_int64(n), K, _lib.ptr(out))
+                geo = tetra_np.gardner_segments(n, fs, pieces=K)
+                if geo is None:
+                    assert rc == -5, (fs, n, K, rc)      # TDM_ERR_UNSUPPORTED
+                    continue
+                assert rc == 0, (fs, n, K, rc)
+                assert [int(v) for v in out[:5]] == [geo["n_v"], geo["seg_step"], geo["seam_in"], geo["seam_out"], geo["margin"]], (fs, n, K)
+                seen += 1
+    assert seen > 300

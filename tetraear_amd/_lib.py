@@ -42,6 +42,7 @@ SIGNATURES = {
     "tdm_plan_create": (C.c_int, [_f64, _i64, _i32, _i32, _i32, _i32, _P(_vp)]),
     "tdm_plan_destroy": (C.c_int, [_vp]),
     "tdm_plan_option": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "tdm_gardner_geometry": (C.c_int, [C.c_double, _i64, C.c_int32, _vp]),
     "tdm_plan_get_info": (C.c_int, [_vp, _P(PlanInfo)]),
     "tdm_plan_resize": (C.c_int, [_vp, _i64]),
     "tdm_process": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

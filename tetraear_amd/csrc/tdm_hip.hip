@@ -635,6 +635,25 @@ static size_t fmt_bytes(int fmt) { return fmt == TDM_CU8 || fmt == TDM_CS8 ? 2 :
 
 static void sync_scratch_release(int device, hipStream_t st);   // (find_sync's per-stream scratch, below)
 
+// Geometry of a chunk walked in K pieces (oracle/tetra_np.py gardner_segments is the same arithmetic): false when the chunk is
+// too short (a piece's own part, n / K, under 1.9 warm-ups)
+struct GardnerGeom {
+    int margin, lead, n_v, step, seam_in, seam_out;
+};
+static bool gardner_geometry(int64_t n, double sps, int ntaps_design, int K, GardnerGeom *g)
+{
+    const int warm = 384;             // (oracle/tetra_np.py GARDNER_WARMUP_SYMBOLS)
+    g->margin = (ntaps_design - 1) / 2 + 4 * (int)std::ceil(sps) + 8;
+    g->lead = (int)std::ceil(warm * sps) + g->margin;
+    if (K < 2 || 10 * n < 19 * (int64_t)K * g->lead) return false;
+    const int n_v0 = (int)((n + (int64_t)(K - 1) * g->lead + K - 1) / K);
+    g->step = (int)((n - n_v0) / (K - 1));
+    g->n_v = (int)(n - (int64_t)(K - 1) * g->step);
+    g->seam_out = g->n_v - g->margin;
+    g->seam_in = g->seam_out - g->step;
+    return true;
+}
+
 // TDM_MODE_TETRA_GARDNER: K pieces per carrier's chunk when the launch would otherwise leave most of the chip idle (one loop
 // wavefront per sixteen carriers; two workgroups share a compute unit up to 41 taps) and the chunk is long enough for a
 // piece's 384 warm-up symbols to pay: K = the power of two up to 8 with the shortest pieces -- a piece's time is its length,
@@ -652,32 +671,29 @@ static int gardner_choose_pieces(tdm_plan *p, long long allow)
     p->gseg = GardnerSeg{};
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
-    const int warm = 384;             // (oracle/tetra_np.py GARDNER_WARMUP_SYMBOLS)
-    const int margin = (p->gardner_ntaps_design - 1) / 2 + 4 * (int)std::ceil(tp.sps) + 8;   // (oracle/tetra_np.py gardner_segments)
-    const int lead = (int)std::ceil(warm * tp.sps) + margin;
     const int per_cu = p->gardner_fused_ok == 1 ? tetra_gardner_fused_per_cu(tp.ntaps) : 0;
-    int best_k = 1, best_nv = 0, best_step = 0;
+    int best_k = 1;
+    GardnerGeom best{};
     double best_cost = (double)tp.n * ((int64_t)(p->rows + 15) / 16 > cus ? 1.18 : 1.0);
     for (int K = 2; K <= 8 && per_cu >= 1 && allow != 0 && (allow == 1 || K <= allow); K *= 2) {
         const int64_t wgs = ((int64_t)K * p->rows + 15) / 16;
         if (wgs > (int64_t)cus * (per_cu >= 2 ? 2 : 1)) break;            // (all pieces' workgroups resident at once)
-        if (10 * (int64_t)tp.n < 19 * (int64_t)K * lead) break;            // (a piece's own part at least 1.9 warm-ups)
-        const int n_v0 = (int)((tp.n + (int64_t)(K - 1) * lead + K - 1) / K);
-        const int step = (tp.n - n_v0) / (K - 1), n_v = tp.n - (K - 1) * step;
-        const double cost = (double)n_v * (wgs > cus ? 1.18 : 1.0);
-        if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best_nv = n_v; best_step = step; }
+        GardnerGeom g;
+        if (!gardner_geometry(tp.n, tp.sps, p->gardner_ntaps_design, K, &g)) break;
+        const double cost = (double)g.n_v * (wgs > cus ? 1.18 : 1.0);
+        if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best = g; }
     }
     p->gardner_seg = 1;   // (whole chunks unless everything below succeeds: a failed allocation leaves a plan that works)
     if (best_k > 1) {
-        const int R = p->rows, K = best_k, n_v = best_nv;
+        const int R = p->rows, K = best_k, n_v = best.n_v;
         GardnerSeg &S = p->gseg;
         S.rows_phys = R;
         S.pieces = K;
-        S.seg_step = best_step;
-        S.seam_out = n_v - margin;
-        S.seam_in = S.seam_out - best_step;
+        S.seg_step = best.step;
+        S.seam_out = best.seam_out;
+        S.seam_in = best.seam_in;
         S.piece_mid = K / 2 - 1;
-        S.k_mid = (int)((0.5 * (double)tp.n - (double)S.piece_mid * (double)best_step) / tp.sps);
+        S.k_mid = (int)((0.5 * (double)tp.n - (double)S.piece_mid * (double)best.step) / tp.sps);
         p->gtp = tp;
         p->gtp.n = n_v;
         p->gtp.max_soft = (int32_t)(1.02 * (double)n_v / tp.sps) + 8;
@@ -908,6 +924,18 @@ int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value)
         return gardner_choose_pieces(plan, value);
     }
     return fail(TDM_ERR_INVALID, std::string("tdm_plan_option: unknown option '") + key + "'");
+}
+
+int tdm_gardner_geometry(double sample_rate, int64_t n_samples, int32_t pieces, int32_t *out)
+{
+    if (!out) return fail(TDM_ERR_INVALID, "null output");
+    const double sps = sample_rate / kSymbolRate;
+    if (!(sps >= 2.0 && sps <= 8.0) || n_samples < 1) return fail(TDM_ERR_UNSUPPORTED, "TETRA mode needs 2..8 samples per symbol");
+    GardnerGeom g;
+    if (!gardner_geometry(n_samples, sps, (int)tetra_rrc_taps(sps).size(), pieces, &g))
+        return fail(TDM_ERR_UNSUPPORTED, "the chunk is too short for this many pieces");
+    out[0] = g.n_v; out[1] = g.step; out[2] = g.seam_in; out[3] = g.seam_out; out[4] = g.margin; out[5] = g.lead;
+    return TDM_OK;
 }
 
 int tdm_plan_destroy(tdm_plan *plan)
