@@ -1010,7 +1010,7 @@ def leg_gardner(rows, base, chk, steps):
     bd = BatchDemodulator(TETRA_FS, TETRA_N, rows, "cf32", mode=MODE_TETRA_GARDNER)
     bd.alloc_device_io()
     bd.upload(np.concatenate([base[i % TETRA_DISTINCT] for i in range(rows)]))
-    for _ in range(max(3, steps)):      # (the loop kernel is clock-bound: as many untimed passes as timed ones, so the clocks have settled)
+    for _ in range(max(25, steps)):     # (the loop kernel is clock-bound: at least 25 untimed passes, about 20 ms, so the clocks have settled)
         bd.enqueue()
     bd.sync()
     bd.time_begin()
@@ -1022,7 +1022,7 @@ def leg_gardner(rows, base, chk, steps):
     halves = int(bd.info.gardner_segments)
 
     def timed(b):
-        for _ in range(max(3, steps)):
+        for _ in range(max(25, steps)):
             b.enqueue()
         b.sync()
         b.time_begin()
