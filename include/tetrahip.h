@@ -134,7 +134,12 @@ TDM_API int tdm_plan_destroy(tdm_plan *plan);
  *   "gardner_segments"  (TDM_MODE_TETRA_GARDNER) 0: whole chunks; 1: the plan's own rule (the state after tdm_plan_create);
  *       K = 2..8: at most K independently started loops per chunk.  Waits for the plan's stream; tdm_plan_get_info reports
  *       the number now in force.  In pieces the symbols before the first seam are those of the whole-chunk path bit for
- *       bit, behind a seam the soft symbols agree with it to about 1 % of the largest symbol. */
+ *       bit, behind a seam the soft symbols agree with it to about 1 % of the largest symbol.
+ *   "gardner_ff_start"  (TDM_MODE_TETRA_GARDNER, default 0) 1: the first loop of every chunk starts at a feed-forward
+ *       (square-law) timing estimate over the chunk's first 512 filter outputs instead of at sample 1 + sps -- the later
+ *       pieces of a chunk always do.  The Gardner detector's error vanishes half a symbol off the eye as well as on it, so a
+ *       loop started there can sit for hundreds of symbols before it pulls in; with the option a chunk's first few hundred
+ *       symbols are as good as the rest (oracle/tetra_np.py demod_gardner(ff_first=True)).  Needs the fused kernel. */
 TDM_API int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value);
 /* Host only (no device): the geometry of a TDM_MODE_TETRA_GARDNER chunk of n_samples walked in `pieces` independently started
  * loops -- out[0..5] = piece length, samples from a piece's start to the next one's, the incoming and the outgoing seam in a

@@ -236,7 +236,7 @@ def _gardner_loop(x, sample_rate, bn_t, zeta, ff_init=False):
     return np.array(s), np.array(ts)
 
 
-def demod_gardner(x, sample_rate, bn_t=0.01, zeta=0.7071, segments=1):
+def demod_gardner(x, sample_rate, bn_t=0.01, zeta=0.7071, segments=1, ff_first=False):
     """Gardner TED (e_k = Re{(s_k - s_{k-1}) conj(s_{k-1/2})}, normalised by the running symbol power) -> PI loop
     (noise bandwidth bn_t symbol rates, damping zeta) -> period-controlled Farrow interpolation of the matched-filter
     output; then the same differential detection, 4th-power carrier-offset estimate and quadrant slicer as demod().
@@ -247,19 +247,22 @@ def demod_gardner(x, sample_rate, bn_t=0.01, zeta=0.7071, segments=1):
     piece's symbols up to its first one at or behind its outgoing seam, then the next piece's from the symbol that IS that
     one (the two loops' instants relative to the seam differ by a whole number of symbol periods, 0 unless they place a
     symbol on different sides of the seam).  The loop is a contraction, so a piece's loop -- started next to the eye
-    (_gardner_loop ff_init) -- runs onto its predecessor's trajectory during its 384 warm-up symbols; stateless like a chunk."""
+    (_gardner_loop ff_init) -- runs onto its predecessor's trajectory during its 384 warm-up symbols; stateless like a chunk.
+
+    ff_first (the library's plan option "gardner_ff_start"): the chunk's FIRST loop -- the only one of a whole chunk --
+    starts at the feed-forward estimate too, instead of at 1 + sps: no hang-up at the start of a chunk either."""
     x = np.asarray(x, dtype=np.complex128)
     sps = sample_rate / SYMBOL_RATE
     geo = gardner_segments(len(x), sample_rate, pieces=segments) if segments >= 2 else None
     if geo is None:
-        s, ts = _gardner_loop(x, sample_rate, bn_t, zeta)
+        s, ts = _gardner_loop(x, sample_rate, bn_t, zeta, ff_init=ff_first)
     else:
         K, n_v, step = geo["pieces"], geo["n_v"], geo["seg_step"]
         s_parts, t_parts = [], []
         start = 0                 # index of the piece's first kept symbol
         t_out_prev = 0.0
         for p in range(K):
-            sp, tp = _gardner_loop(x[p * step:p * step + n_v], sample_rate, bn_t, zeta, ff_init=p > 0)
+            sp, tp = _gardner_loop(x[p * step:p * step + n_v], sample_rate, bn_t, zeta, ff_init=p > 0 or ff_first)
             if p > 0:
                 i_in = np.nonzero(np.floor(tp) >= geo["seam_in"])[0]
                 k_in = int(i_in[0]) if len(i_in) else len(sp)

@@ -98,6 +98,38 @@ def test_definition_in_pieces_joins_to_the_whole_chunks_symbols(pieces):
         assert best == 0, (fs, n, best)
 
 
+def _early_errors(hard, dib, lo=8, hi=400):
+    """symbol errors against what was sent among symbols lo..hi of a chunk (lag found over the whole chunk)"""
+    m = len(hard)
+    lag = min(range(40), key=lambda g: int(np.sum(hard[600:m - 8] != dib[g + 600:g + m - 8])) if len(dib) - g >= m else 1 << 30)
+    return int(np.sum(hard[lo:hi] != dib[lag + lo:lag + hi]))
+
+
+def test_definition_with_a_feed_forward_start_acquires_at_once():
+    """demod_gardner(ff_first=True) (the library's plan option gardner_ff_start): the chunk's first loop starts at the square-law
+    estimate instead of at sample 1 + sps.  Over 48 carriers with random timing phases the plain loop loses symbols at the
+    start of the chunks it begins half a symbol off the eye in (its detector's error vanishes there too); the feed-forward
+    start does not -- and a thousand symbols in, both have made the same decisions."""
+    fs, n = 72000.0, 12000
+    plain = ff = 0
+    worst_plain = 0
+    for r in range(48):
+        x, dib = _gardner_case(n, fs, 5200 + r, (r * 0.0213) % 1.0 - 0.5, float((r * 37) % 200 - 100), 20.0, float((r % 5) - 2) * 50.0)
+        x = x.astype(np.complex128)
+        h0, _, i0 = tetra_np.demod_gardner(x, fs)
+        h1, _, i1 = tetra_np.demod_gardner(x, fs, ff_first=True)
+        e0, e1 = _early_errors(h0, dib), _early_errors(h1, dib)
+        plain, ff, worst_plain = plain + e0, ff + e1, max(worst_plain, e0)
+        m = min(len(h0), len(h1))
+        assert abs(len(h0) - len(h1)) <= 1
+        d = 0 if np.array_equal(h0[1500:m - 4], h1[1500:m - 4]) else (1 if np.array_equal(h0[1501:m - 4], h1[1500:m - 5]) else -1)
+        a, b = (h0[1500 + max(d, 0):m - 4], h1[1500 + max(-d, 0):m - 4])
+        k = min(len(a), len(b))
+        assert np.array_equal(a[:k], b[:k]), r
+    print(f"symbol errors among symbols 8..400 of 48 chunks: plain start {plain} (worst chunk {worst_plain}), feed-forward start {ff}")
+    assert ff == 0 and plain > 20
+
+
 # ---- the device's Gardner receiver (TDM_MODE_TETRA_GARDNER) against the same definition ------------------------------
 def _gardner_case(n, fs, seed, toff, coff, snr_db, rate_ppm=0.0):
     """a carrier whose symbol clock runs rate_ppm fast (the loop has to track a ramp, and the carriers of a wavefront drift
@@ -110,10 +142,10 @@ def _gardner_case(n, fs, seed, toff, coff, snr_db, rate_ppm=0.0):
     return (x * np.exp(2j * np.pi * coff * np.arange(n) / fs)).astype(np.complex64), dib
 
 
-def _check_against_definition(x, fs, hard, soft, dib, skip=300, segments=1):
+def _check_against_definition(x, fs, hard, soft, dib, skip=300, segments=1, ff_first=False):
     """segments: tdm_plan_info.gardner_segments of the plan that made `hard` (2: every chunk as two independently started
     loops joined at a seam -- the definition is then evaluated the same way)"""
-    ref_hard, ref_dd, info = tetra_np.demod_gardner(x.astype(np.complex128), fs, segments=segments)
+    ref_hard, ref_dd, info = tetra_np.demod_gardner(x.astype(np.complex128), fs, segments=segments, ff_first=ff_first)
     # the loop runs in fp32 on the device (instants in fp64): symbol count within one of the definition's at the end of
     # the chunk, decisions equal wherever the definition's own derotated product is not within 0.1 rad of a quadrant
     # boundary (the bar tools/sweep_gardner.py uses) -- and never more than 1e-3 of them
@@ -420,3 +452,44 @@ def test_gpu_gardner_pieces_with_a_silent_carrier_and_a_fast_clock():
         elif r == 5:      # (a 0.3 % clock offset: a loop may slip while it pulls in, in the definition as on the device)
             m = min(len(hards[r]), len(ref_hard))
             assert np.mean(hards[r][:m] != ref_hard[:m]) <= 0.02, r
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_feed_forward_start_option():
+    """tdm_plan_option "gardner_ff_start": every chunk's first loop starts at the feed-forward estimate -- as whole chunks and
+    in pieces the outputs are the definition's evaluated the same way (demod_gardner(ff_first=True)), chunks that the plain
+    start begins half a symbol off the eye lose no symbols at their start any more, and a plan the fused kernel does not
+    serve refuses the option."""
+    from tetraear_amd._lib import MODE_TETRA_GARDNER, TetraHipError, debug_option
+    from tetraear_amd.batch import BatchDemodulator
+    fs, n, rows = 72000.0, 12000, 48
+    sig = [_gardner_case(n, fs, 5200 + r, (r * 0.0213) % 1.0 - 0.5, float((r * 37) % 200 - 100), 20.0, float((r % 5) - 2) * 50.0) for r in range(rows)]
+    iq = np.concatenate([s[0] for s in sig])
+    early = {}
+    for allow in (0, 1):
+        for ff in (False, True):
+            with debug_option("gardner_segments", allow):
+                bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+            K = bd.info.gardner_segments
+            assert (K == 1) if allow == 0 else (K > 1)
+            if ff:
+                bd.set_gardner_ff_start(True)
+            hards, softs, timing, margin = bd.process(iq)
+            bd.close()
+            early[(K, ff)] = sum(_early_errors(hards[r], sig[r][1]) for r in range(rows))
+            for r in range(0, rows, 3):
+                ref_hard, ref_dd, info = tetra_np.demod_gardner(sig[r][0].astype(np.complex128), fs, segments=K, ff_first=ff)
+                assert abs(len(softs[r]) - len(info["t"])) <= 1, (K, ff, r)
+                m = min(len(hards[r]), len(ref_hard))
+                diff = np.flatnonzero(hards[r][:m] != ref_hard[:m])
+                # (a loop that hangs half a symbol off the eye decides on noise: only the feed-forward start is held to the tight bar)
+                assert len(diff) <= (1e-3 if ff else 2e-2) * m, (K, ff, r, len(diff))
+    print("symbol errors among symbols 8..400 of 48 chunks, (pieces, feed-forward start):", early)
+    whole = [k for k in early if k[0] == 1]
+    assert early[(1, True)] == 0 and early[(1, False)] > 20, early
+    assert all(v == 0 for k, v in early.items() if k[1]), early
+    with debug_option("gardner_fused", 0):
+        bd = BatchDemodulator(fs, n, 4, "cf32", mode=MODE_TETRA_GARDNER)
+        with pytest.raises(TetraHipError):
+            bd.set_gardner_ff_start(True)
+        bd.close()

@@ -74,6 +74,12 @@ class BatchDemodulator:
         self.fast_pre_shift = bool(on)
         return self
 
+    def set_gardner_ff_start(self, on=True):
+        """tdm_plan_option "gardner_ff_start" (MODE_TETRA_GARDNER): the first loop of every chunk starts at a feed-forward timing
+        estimate (no hang-up half a symbol off the eye at the start of a chunk); the later pieces of a chunk always do."""
+        check(self.lib.tdm_plan_option(self.handle, b"gardner_ff_start", 1 if on else 0))
+        return self
+
     def set_gardner_segments(self, pieces=1):
         """tdm_plan_option "gardner_segments" (MODE_TETRA_GARDNER): 0 whole chunks, 1 the plan's own rule, K at most K
         independently started loops per chunk; `info.gardner_segments` then says how many are in force."""

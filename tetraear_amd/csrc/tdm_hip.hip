@@ -432,6 +432,7 @@ struct tdm_plan {
     int64_t gy_pitch = 0;
     int gardner_fused_ok = -1;      // does the fused Gardner kernel serve this plan (tap count, carriers, device)?  -1: not asked yet
     // two segments per carrier (GardnerSeg): geometry and temporaries, made the first time the plan runs that way
+    int gardner_ff_first = 0;       // tdm_plan_option "gardner_ff_start"
     int gardner_ntaps_design = 0;   // the RRC filter's designed length (before the padding to an instantiated one)
     int gardner_seg = 0;            // pieces per carrier's chunk (TDM_MODE_TETRA_GARDNER: 1 whole chunks, 2 / 4 / 8: GardnerSeg)
     GardnerSeg gseg{};
@@ -916,6 +917,12 @@ int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value)
         plan->fast_pre_shift = value ? 1 : 0;
         return TDM_OK;
     }
+    if (std::strcmp(key, "gardner_ff_start") == 0) {
+        if (plan->mode != TDM_MODE_TETRA_GARDNER) return fail(TDM_ERR_UNSUPPORTED, "gardner_ff_start is an option of TDM_MODE_TETRA_GARDNER plans");
+        if (value && plan->gardner_fused_ok != 1) return fail(TDM_ERR_UNSUPPORTED, "gardner_ff_start needs the fused Gardner kernel, which does not serve this plan");
+        plan->gardner_ff_first = value ? 1 : 0;
+        return TDM_OK;
+    }
     if (std::strcmp(key, "gardner_segments") == 0) {
         if (plan->mode != TDM_MODE_TETRA_GARDNER) return fail(TDM_ERR_UNSUPPORTED, "gardner_segments is an option of TDM_MODE_TETRA_GARDNER plans");
         if (value < 0 || value > 8) return fail(TDM_ERR_INVALID, "gardner_segments: 0 (whole chunks), 1 (the plan's rule) or the largest number of pieces allowed (2..8)");
@@ -1012,6 +1019,7 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
                 const int R = plan->rows, K = plan->gardner_seg;
                 GardnerSeg S = plan->gseg;
                 S.soft_a = S.pitch_a ? (float2 *)soft : nullptr;
+                S.ff_first = plan->gardner_ff_first;
                 {
                     HipBackend::Scope s(be, ST_TETRA_LOOP);
                     fused_done = tetra_gardner_fused_launch(plan->gtp, K * R, (const float2 *)iq, carrier_stride_samples, plan->d_gsoft,
@@ -1032,8 +1040,13 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
                 }
             } else if (fused && plan->gardner_fused_ok) {
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
-                fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream);
+                GardnerSeg S{};
+                S.ff_first = plan->gardner_ff_first;
+                fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream,
+                                                        S.ff_first ? &S : nullptr);
             }
+            if (plan->gardner_ff_first && !fused_done)
+                return fail(TDM_ERR_UNSUPPORTED, "gardner_ff_start needs the fused Gardner kernel (gardner_fused switched off, or no kernel for this tap count / batch)");
             const bool three = !fused_done;   // (gardner_fused = 0, no fused kernel for this tap count, or too many carriers for it)
             if (three && !plan->d_gy)
                 HIP_TRY(hipMalloc((void **)&plan->d_gy, (size_t)plan->rows * plan->gy_pitch * sizeof(float2)));

@@ -579,7 +579,9 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
         // wherever the piece's first sample happens to lie: half a symbol off the eye the detector's error vanishes too, and a
         // loop started there can sit for hundreds of symbols before it pulls in (seen in 1 of ~30 pieces).  A quad's four
         // lanes take every fourth sample each.
-        if (S.pieces > 0 && __any(piece > 0)) {
+        // (the first loop of a chunk only by the plan option gardner_ff_start, and like the definition only when the chunk fills the ring)
+        const bool ff_here = (piece > 0 || S.ff_first != 0) && n >= kGRing;
+        if (__any(ff_here)) {
             constexpr int H = (NT - 1) / 2;
             const int l4 = lane & 3;
             const float w = -6.28318530717958648f / sps_f;
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
             float dd = fmodf(tau - base, sps_f);
             if (dd < 0.f) dd += sps_f;
             const float t0 = base + dd;
-            if (piece > 0) {
+            if (ff_here) {
                 m = (int)floorf(t0);
                 mu = t0 - floorf(t0);
             }

@@ -92,6 +92,9 @@ struct GardnerSeg {
     // null: all pieces into the temporary, [pieces rows_phys][max_soft]
     float2 *soft_a;           // [rows_phys][pitch_a]
     int32_t pitch_a;
+    // plan option "gardner_ff_start": the FIRST loop of a chunk (the only one of a whole chunk) starts at the feed-forward
+    // estimate as well (the later pieces always do); usable with pieces == 0
+    int32_t ff_first;
 };
 
 bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
