@@ -14,6 +14,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
 t0 = time.time(); bad = 0; cnt = 0; worst = 0.0; halves = {}
 sent = {"pieces": [0, 0], "whole": [0, 0]}
+n_ff = 0
 while time.time() - t0 < budget:
     fs = float(rng.choice([54000.0, 72000.0, 75000.0, 80000.0, 90000.0, 108000.0, 144000.0]))
     n = int(rng.integers(3000, 20000)) if rng.random() < 0.5 else int(rng.integers(20000, 70000))   # (the longer ones run in pieces)
@@ -29,6 +30,10 @@ while time.time() - t0 < budget:
         x = x * np.exp(2j * np.pi * float(rng.uniform(-100, 100)) * np.arange(n) / fs)
         xs.append(x.astype(np.complex64)); dibs.append(d)
     bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+    ff = bool(rng.random() < 0.5)      # plan option gardner_ff_start on half of the plans
+    if ff:
+        bd.set_gardner_ff_start(True)
+    n_ff += rows if ff else 0
     buf = np.full((rows, pitch), 9.0, dtype=np.complex64)
     for r in range(rows): buf[r, :n] = xs[r]
     ms = bd.info.max_soft
@@ -39,6 +44,8 @@ while time.time() - t0 < budget:
     if pieces > 1:      # the same batch as whole chunks: symbol errors against what was sent, both ways
         with debug_option("gardner_segments", 0):
             bw = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+            if ff:
+                bw.set_gardner_ff_start(True)
             hw = np.zeros((rows, ms), np.uint8); sw = np.zeros((rows, ms), np.complex64); nw = np.zeros(rows, np.int32)
             check(bw.lib.tdm_process(bw.handle, ptr(buf), pitch, None, None, ptr(hw), ptr(sw), ptr(nw), None, None))
             bw.close()
@@ -51,7 +58,7 @@ while time.time() - t0 < budget:
     for r in range(rows):
         cnt += 1
         h = hard[r, :max(ns[r] - 1, 0)]
-        rh, rdd, info = tetra_np.demod_gardner(xs[r].astype(np.complex128), fs, segments=bd.info.gardner_segments)
+        rh, rdd, info = tetra_np.demod_gardner(xs[r].astype(np.complex128), fs, segments=bd.info.gardner_segments, ff_first=ff)
         halves[bd.info.gardner_segments] = halves.get(bd.info.gardner_segments, 0) + 1
         m = min(len(h), len(rh))
         diff = np.flatnonzero(h[:m] != rh[:m])
@@ -67,4 +74,5 @@ while time.time() - t0 < budget:
             bad += 1; print("MISMATCH", fs, n, rows, pitch, ns[r], len(info["t"]), frac, mf_err)
     bd.close()
 print("symbol errors against what was sent, carriers run in pieces: in pieces %d of %d, as whole chunks %d of %d" % (*sent["pieces"], *sent["whole"]))
+print(f"{n_ff} of the carriers with the plan option gardner_ff_start")
 print(f"{cnt} carriers (pieces per chunk: {dict(sorted(halves.items()))}), {bad} mismatches, worst fraction of differing decisions {worst:.2e}")
