@@ -22,9 +22,10 @@ class WidebandReceiver:
     sample_rate/M and decimated by D (channel rate sample_rate/D), all demodulated per call."""
 
     def __init__(self, sample_rate, n_in, M, D, streams=1, fmt="cu8", device=0, slots=1, group=None, mode=MODE_TETRA,
-                 gated=False, snr_db=15.0, min_dbfs=-70.0):
+                 gated=False, snr_db=15.0, min_dbfs=-70.0, gardner_ff_start=False):
         """mode: MODE_TETRA (feed-forward timing, the default) or MODE_TETRA_GARDNER (Gardner detector + loop) for the channels'
-        demodulation.
+        demodulation; gardner_ff_start: that loop started at a feed-forward timing estimate in every chunk (the plan option of
+        the same name: no hang-up at a chunk's head).
 
         slots = 2: two independent (channel buffer, demodulator plan) pairs, each with its own stream.  Consecutive
         batches go to alternating slots (enqueue(slot=k % 2)), so the channeliser of batch k+1 -- bound by its output
@@ -56,6 +57,8 @@ class WidebandReceiver:
             d_ch = DeviceBuffer(device, self.group * self.M * self.pitch * 8)
             demod = BatchDemodulator(self.sample_rate / self.D, self.n_out, self.group * self.M, "cf32",
                                      device=device, mode=mode)
+            if gardner_ff_start:
+                demod.set_gardner_ff_start(True)
             if self.group == self.streams:
                 demod.alloc_device_io()
             self.slots.append((d_ch, demod))
