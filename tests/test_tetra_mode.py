@@ -443,19 +443,21 @@ def test_gpu_wideband_receiver_with_the_gardner_loop():
     ks = [0, 5, 47, 49, 90]
     x, dibs = _wideband(n, fs, ks, M, seed0=640)
     xin = (x / 6).astype(np.complex64)
-    rx = WidebandReceiver(fs, n, M, D, streams=1, fmt="cf32", mode=MODE_TETRA_GARDNER)
-    hard, n_sym, timing, margin = rx.process(xin)
-    rx.close()
     ref = dict(zip(ks, pfb_np.channelise(xin.astype(np.complex128), M, D, channels=ks)))
-    for k in ks:
-        got = hard[0, k, :n_sym[0, k]]
-        assert n_sym[0, k] > 900
-        m = len(got)
-        errs = min(int(np.sum(got[700:m - 8] != dibs[k][lag + 700:lag + m - 8])) for lag in range(40) if len(dibs[k]) - lag >= m)
-        assert errs == 0, (k, errs)           # (a loop of this bandwidth may need a few hundred symbols from a half-symbol offset)
-        ref_hard, _, info = tetra_np.demod_gardner(ref[k], fs / D)
-        mm = min(m, len(ref_hard))
-        assert abs(m + 1 - len(info["t"])) <= 1 and np.mean(got[:mm] != ref_hard[:mm]) <= 2e-3, k
+    for ff in (False, True):      # gardner_ff_start: the loop of every chunk started at the feed-forward timing estimate
+        rx = WidebandReceiver(fs, n, M, D, streams=1, fmt="cf32", mode=MODE_TETRA_GARDNER, gardner_ff_start=ff)
+        hard, n_sym, timing, margin = rx.process(xin)
+        rx.close()
+        skip = 60 if ff else 700      # (a loop of this bandwidth may need a few hundred symbols from a half-symbol offset; started at the estimate it needs none)
+        for k in ks:
+            got = hard[0, k, :n_sym[0, k]]
+            assert n_sym[0, k] > 900
+            m = len(got)
+            errs = min(int(np.sum(got[skip:m - 8] != dibs[k][lag + skip:lag + m - 8])) for lag in range(40) if len(dibs[k]) - lag >= m)
+            assert errs == 0, (ff, k, errs)
+            ref_hard, _, info = tetra_np.demod_gardner(ref[k], fs / D, ff_first=ff)
+            mm = min(m, len(ref_hard))
+            assert abs(m + 1 - len(info["t"])) <= 1 and np.mean(got[:mm] != ref_hard[:mm]) <= 2e-3, (ff, k)
 
 
 @pytest.mark.gpu
