@@ -339,6 +339,15 @@ def cpu_baseline_allcore(chunk, budget_s=5.0):
             "sample": f"{procs} processes x {budget_s:.0f} s of {chunk}-sample chunks, C oracle"}
 
 
+def emit(out):
+    """Print the ONE JSON line.  Under TDM_BENCH_TEST_HOOK (tests/: a stand-in device) the line says so, in a field of its own
+    and in `data`, so that no hooked run can pass for a measurement."""
+    hook = os.environ.get("TDM_BENCH_TEST_HOOK")
+    if hook:
+        out = dict(out, test_hook=os.path.abspath(hook), data="test hook: stand-in device, NOT a measurement")
+    print(json.dumps(out), flush=True)
+
+
 def spawn_local_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this very command on this node -- rank r on device r,
     rendezvous on 127.0.0.1 (RcclGroup: librccl through ctypes) -- pass rank 0's one JSON line through, fail if any rank
@@ -395,7 +404,13 @@ def main():
     args = ap.parse_args()
 
     hook = os.environ.get("TDM_BENCH_TEST_HOOK")
-    if hook:   # (tests/: replaces the device with a stand-in so that the launch logic runs on a CPU-only box; never set in a measurement)
+    if hook:
+        # tests/ only: replaces the device with a stand-in so that the launch logic runs on a CPU-only box.  A measurement
+        # script says so itself when it is not measuring: the hook is REFUSED on a box that has a device, and every JSON line
+        # printed under it carries "test_hook": <path> and "data": "test hook ..." (emit()).
+        from tetraear_amd import _lib
+        if int(_lib.load().tdm_device_count()) > 0:
+            raise SystemExit("bench: TDM_BENCH_TEST_HOOK is set but this box has a GPU; refusing to run a measurement with a stand-in device")
         import runpy
         runpy.run_path(hook, init_globals={"bench": sys.modules[__name__]})
     if args.mode == "tetra":
@@ -658,7 +673,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     out[key] = {"error": str(e)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if group is not None:
         group.close()
     if rank == 0:
@@ -768,9 +783,9 @@ def main_stream(args):
     dt = time.perf_counter() - t0
     nsym = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0))) * reps
     gb = allq.nbytes * reps / 1e9
-    print(json.dumps({"metric": "Msymbols/s demodulated, host-fed cu8 (PCIe inclusive)", "value": nsym / dt / 1e6,
+    emit({"metric": "Msymbols/s demodulated, host-fed cu8 (PCIe inclusive)", "value": nsym / dt / 1e6,
                       "unit": "Msym/s", "n_gpus": 1, "config": {"workload": f"{n_batches} batches x {rows} carriers x {args.chunk} cu8 samples from host memory"},
-                      "host_to_device_GBps": gb / dt, "seconds": dt, "realtime_carriers": nsym / dt / (SAMPLE_RATE / 130)}))
+          "host_to_device_GBps": gb / dt, "seconds": dt, "realtime_carriers": nsym / dt / (SAMPLE_RATE / 130)})
     bd.close()
 
 
@@ -843,7 +858,7 @@ def leg_pfb(carriers, steps, warmup):
 def _print_leg(out):
     """a north-star leg run on its own: the JSON line, then -- as main() does for the headline -- a non-zero exit when the
     leg's output differs from the pinned definition (a number from wrong output must not look like a result)"""
-    print(json.dumps(out), flush=True)
+    emit(out)
     status = str(out.get("output_check", {}).get("status", ""))
     side = str(((out.get("gardner_mode") or {}).get("output_check") or {}).get("status", ""))
     if status.startswith("DIFFERS") or side.startswith("DIFFERS"):

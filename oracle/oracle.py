@@ -64,6 +64,13 @@ def _split(x):
     return xr, xi
 
 
+def _join(re, im):
+    """re + 1j*im without the arithmetic (`1j * inf` is `nan + inf j`): the components as they are"""
+    out = np.empty(len(re), dtype=np.complex128)
+    out.real, out.imag = re, im
+    return out
+
+
 _DESIGN_CACHE = {}
 
 
@@ -98,14 +105,14 @@ class OracleSignalProcessor:
         rc = lib().orc_filtfilt(_p(b), _p(a), _p(zi), 4, _p(xr), _p(xi), len(xr))
         if rc != 0:
             return samples
-        return xr + 1j * xi
+        return _join(xr, xi)
 
     # processor.py:85-100
     def frequency_shift(self, samples, freq_offset, sample_rate=None):
         fs = sample_rate if sample_rate is not None else self.sample_rate
         xr, xi = _split(samples)
         lib().orc_frequency_shift(_p(xr), _p(xi), len(xr), float(freq_offset), float(fs))
-        return xr + 1j * xi
+        return _join(xr, xi)
 
     # processor.py:102-166
     def demodulate_dqpsk(self, samples):
@@ -132,7 +139,7 @@ class OracleSignalProcessor:
         n = lib().orc_extract_symbols(_p(xr), _p(xi), len(xr), float(fs), float(self.symbol_rate), _p(sr),
                                       _p(si), C.byref(bp), _p(powers))
         self.best_phase = bp.value
-        out = sr[:n] + 1j * si[:n]
+        out = _join(sr[:n], si[:n])
         if return_powers:
             return out, powers
         return out
@@ -148,7 +155,7 @@ class OracleSignalProcessor:
         r = lib().orc_decimate(_p(sos), _p(zi), sos.shape[0], q, _p(xr), _p(xi), len(xr), _p(yr), _p(yi))
         if r < 0:
             raise ValueError("The length of the input vector x must be greater than padlen, which is 27.")
-        return yr[:r] + 1j * yi[:r]
+        return _join(yr[:r], yi[:r])
 
     # processor.py:221-273
     def process(self, samples, freq_offset=0):
@@ -170,7 +177,7 @@ class OracleSignalProcessor:
                                _p(sos), _p(soszi), 4, _p(b1), _p(a1), _p(zi1), _p(b0), _p(a0), _p(zi0),
                                _p(sr), _p(si), C.byref(ns), hard.ctypes.data_as(_u8p), C.byref(bp),
                                C.byref(margin))
-        self.symbols = sr[:ns.value] + 1j * si[:ns.value]
+        self.symbols = _join(sr[:ns.value], si[:ns.value])
         self.best_phase = bp.value
         self.min_margin = margin.value
         return hard[:nh].copy()

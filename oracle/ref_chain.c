@@ -139,6 +139,23 @@ static int filtfilt_real(const double *b, const double *a, const double *zi, int
     return 0;
 }
 
+/* ---- non-finite samples.  The per-component form above is numpy's complex product only for FINITE data: scipy filters
+ * complex samples with complex coefficients (b + 0j), whose zero cross terms (0*inf, 0*nan) turn a non-finite component
+ * into NaN in BOTH components of that output; the forward pass carries it to the end of the extended array, the backward
+ * pass -- started from zi * (the forward pass's last value) -- back to its start.  So one non-finite sample anywhere in a
+ * zero-phase filter's input is NaN + NaN j at every output (goldens of the imported reference: tests/golden/nonfinite.npz;
+ * a real float64 input is a real array there and comes out all-NaN the same way).  Returns 1 and fills when it applies. */
+static int smear_nonfinite(const double *xr, const double *xi, int64_t n, double *yr, double *yi, int64_t m)
+{
+    int bad = 0;
+    for (int64_t i = 0; i < n && !bad; ++i)
+        bad = !isfinite(xr[i]) || !isfinite(xi[i]);
+    if (bad)
+        for (int64_t i = 0; i < m; ++i)
+            yr[i] = yi[i] = NAN;
+    return bad;
+}
+
 /* ---- scipy.signal.decimate(x, q) IIR zero-phase branch (_signaltools.py:4975-4989):
  * sosfiltfilt then y[::q].  out has ceil(n/q) entries. Returns that count or -1.       */
 ORC_API int64_t orc_decimate(const double *sos, const double *soszi, int nsec, int q, const double *xr,
@@ -149,6 +166,10 @@ ORC_API int64_t orc_decimate(const double *sos, const double *soszi, int nsec, i
     if (sosfiltfilt_real(sos, soszi, nsec, xr, n, t) != 0) {
         free(t);
         return -1;
+    }
+    if (smear_nonfinite(xr, xi, n, yr, yi, m)) {
+        free(t);
+        return m;
     }
     for (int64_t i = 0; i < m; ++i)
         yr[i] = t[i * q];
@@ -183,6 +204,8 @@ ORC_API int orc_filtfilt(const double *b, const double *a, const double *zi, int
 {
     if (n <= 3 * (order + 1))
         return -1;
+    if (smear_nonfinite(xr, xi, n, xr, xi, n))
+        return 0;
     double *t = (double *)malloc((size_t)n * sizeof(double));
     filtfilt_real(b, a, zi, order, xr, n, t);
     memcpy(xr, t, (size_t)n * sizeof(double));

@@ -149,6 +149,7 @@ struct EmuBlockComm {
     double reduce_sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
     double reduce_max(double v) { return reduce(v, [](double a, double b) { return std::fmax(a, b); }); }
     double reduce_min(double v) { return reduce(v, [](double a, double b) { return std::fmin(a, b); }); }
+    double reduce_max_nan(double v) { return reduce(v, [](double a, double b) { return (a != a) ? a : ((b != b) ? b : std::fmax(a, b)); }); }
 };
 
 template <class F>

@@ -72,3 +72,68 @@ def dtype_case_input(name):
         return np.cos(2 * np.pi * 4000.0 * np.arange(20000) / 1.8e6) + 0.05 * rng.standard_normal(20000)
     x = rng.standard_normal(32768)
     return x.astype(np.float32) if name.startswith("f32") else x
+
+
+# ---- non-finite samples (tests/golden/make_golden_nonfinite.py -> nonfinite.npz).  The reference does not guard against
+# them: a zero-phase filter (processor.py:254 sosfiltfilt inside decimate, :79 filtfilt) carries ONE NaN / Inf over the whole
+# chunk, every slicer comparison is then false (:152-161 -> 3), no timing phase beats max_power = -1 (:196-210 -> phase 0).
+# name -> (fs, freq_offset, n, seed, dtype, [(index, value), ...])
+_nan, _inf = float("nan"), float("inf")
+NONFINITE_CASES = {
+    "nan_head_2400": (2.4e6, 0.0, 131072, 6100, "c128", [(0, _nan)]),
+    "nan_mid_2400_off": (2.4e6, 1171.875, 131072, 6101, "c128", [(65536, _nan)]),
+    "nan_tail_2400": (2.4e6, 0.0, 131072, 6102, "c128", [(131071, _nan)]),
+    "nan_in_odd_ext_2400": (2.4e6, -3515.625, 131072, 6103, "c128", [(20, _nan)]),
+    "nan_in_tail_ext_2400": (2.4e6, 0.0, 131072, 6104, "c128", [(131072 - 9, _nan)]),
+    "inf_mid_2400": (2.4e6, 0.0, 131072, 6105, "c128", [(70001, _inf)]),
+    "minf_imag_2400_off": (2.4e6, 1171.875, 131072, 6106, "c128", [(333, complex(0.25, -_inf))]),
+    "nan_real_part_only_2400": (2.4e6, 0.0, 131072, 6107, "c128", [(99999, complex(_nan, 0.5))]),
+    "inf_last_of_a_lane_2400": (2.4e6, 0.0, 65536, 6108, "c128", [(29, _inf), (1919, -_inf)]),
+    "two_nans_256k": (2.4e6, 0.0, 262144, 6109, "c128", [(7, _nan), (200000, _nan)]),
+    "nan_1800_q7": (1.8e6, -3515.625, 20000, 6110, "c128", [(12345, _nan)]),
+    "nan_10M_q41": (10e6, 0.0, 100000, 6111, "c128", [(50000, _nan)]),
+    "nan_4500_q18_cascade": (4.5e6, 0.0, 40000, 6112, "c128", [(1000, _nan)]),
+    "nan_225_no_decimation": (0.225e6, 500.0, 5000, 6113, "c128", [(2500, _nan)]),
+    "inf_225_no_decimation": (0.225e6, 0.0, 5000, 6114, "c128", [(4999, _inf)]),
+    "nan_c64_2400": (2.4e6, 1171.875, 32768, 6115, "c64", [(16000, _nan)]),
+    "nan_f64_real_2400": (2.4e6, 0.0, 32768, 6116, "f64", [(5, _nan)]),
+    "nan_f64_real_2400_off": (2.4e6, 1171.875, 32768, 6117, "f64", [(32767, _nan)]),
+    "nan_short_300": (2.4e6, 0.0, 300, 6118, "c128", [(150, _nan)]),
+    "nan_short_28": (2.4e6, 0.0, 28, 6119, "c128", [(3, _nan)]),
+    # no filter runs (<= 15 samples at a rate that is not decimated): nothing smears, the NaN stays where it is
+    "nan_225_15_samples_no_filter": (0.225e6, 0.0, 15, 6120, "c128", [(12, _nan)]),
+    "nan_225_15_samples_no_filter_p0": (0.225e6, 0.0, 15, 6121, "c128", [(0, _nan)]),
+    "nan_225_16_samples": (0.225e6, 0.0, 16, 6122, "c128", [(12, _nan)]),
+}
+
+
+def nonfinite_case_input(name):
+    """the array handed to process() in a non-finite case: seeded noise with the listed samples replaced"""
+    fs, foff, n, seed, dt, inject = NONFINITE_CASES[name]
+    if dt == "f64":
+        x = np.random.default_rng(seed).standard_normal(n)
+    else:
+        x = synth.cu8_to_c128(synth.noise_cu8(n, seed))
+        if dt == "c64":
+            x = x.astype(np.complex64)
+    for i, v in inject:
+        x[i] = v
+    return x
+
+
+def nonfinite_stage_inputs():
+    """inputs of the per-method non-finite goldens: name -> array"""
+    x = synth.cu8_to_c128(synth.noise_cu8(4000, 6200))
+    out = {}
+    for tag, v in (("nan", _nan), ("inf", _inf)):
+        a = x.copy(); a[1234] = v
+        out["x4000_" + tag] = a
+    a = x.copy(); a[[13, 14, 500, 3999]] = _nan      # extract_symbols: some timing phases poisoned, some clean
+    out["x4000_nan_some_phases"] = a
+    s = x[:200].copy(); s[100] = _nan
+    out["sym200_nan"] = s                             # demodulate_dqpsk: np.max propagates the NaN -> no normalisation
+    s = x[:200].copy(); s[100] = complex(_inf, 1.0)
+    out["sym200_inf"] = s                             # ... an Inf normalises every finite sample to 0 -> symbol 0
+    s = x[:200].copy(); s[0] = _nan; s[199] = complex(0.0, _nan)
+    out["sym200_nan_ends"] = s
+    return out

@@ -24,7 +24,39 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert L.tdm_version() == 101
+    # header, bindings and library agree on the version (the loader itself refuses a library that does not)
+    assert L.tdm_version() == _lib.header_version() == _lib.ABI_VERSION
+
+
+def test_loader_refuses_a_stale_or_experiment_library(tmp_path):
+    """_lib.load() checks tdm_version(): a library of another version (its tdm_plan_info may be shorter) and a timing-only
+    -DTDM_EXPERIMENT build (negative version) both raise.  Stand-in libraries of one function, compiled here."""
+    import subprocess
+    import sys
+    for ver, env, ok in ((100, {}, False), (-101, {}, False), (-101, {_lib.ALLOW_EXPERIMENT_ENV: "1"}, None)):
+        src = tmp_path / f"v{abs(ver)}_{ver < 0}.c"
+        so = tmp_path / f"libv{abs(ver)}_{ver < 0}.so"
+        src.write_text(f"int tdm_version(void) {{ return {ver}; }}\n")
+        subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+        code = ("from tetraear_amd import _lib\n"
+                "try:\n    _lib.load()\nexcept _lib.TetraHipError as e:\n    print('REFUSED', e)\n"
+                "except AttributeError as e:\n    print('PASSED-VERSION', e)\n")
+        r = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True,
+                           env={**os.environ, "TETRAHIP_LIB": str(so), **env})
+        assert r.returncode == 0, r.stderr
+        if ok is False:
+            assert "REFUSED" in r.stdout and "tdm_version" in r.stdout, r.stdout
+        else:   # the experiment override lets the version check pass (the stand-in then lacks every other symbol)
+            assert "PASSED-VERSION" in r.stdout, r.stdout
+
+
+def test_graft_entry_build_returns():
+    """The driver's build entry: compiles (a no-op when up to date), imports, binds, version handshake."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); print('BUILD-OK')"],
+                       cwd=REPO, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and "BUILD-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_design_matches_scipy_tables(gold_design):

@@ -83,15 +83,42 @@ SIGNATURES = {
 
 _lib = None
 
+# The header version these bindings (PlanInfo's layout, SIGNATURES) were written for: include/tetrahip.h TDM_VERSION.
+# tests/test_abi_cpu.py holds it to the header; load() holds the library to it.
+ABI_VERSION = 101
+ALLOW_EXPERIMENT_ENV = "TETRAHIP_ALLOW_EXPERIMENT"   # timing-only builds (negative version): tools/ab_*.py only
+
+
+def header_version(path=None):
+    """TDM_VERSION as include/tetrahip.h states it (the header travels with the repo; a deployment without it has
+    ABI_VERSION)."""
+    path = path or os.path.join(os.path.dirname(_HERE), "include", "tetrahip.h")
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#define TDM_VERSION"):
+                return int(line.split()[2])
+    raise TetraHipError(-2, f"no TDM_VERSION in {path}")
+
 
 def load():
-    """Load libtetrahip.so; raises (never falls back) when it is absent."""
+    """Load libtetrahip.so; raises (never falls back) when it is absent, when it is not the version these bindings were
+    written for (a stale .so fills a shorter tdm_plan_info), or when it is a timing-only experiment build (negative
+    version: such a library knowingly returns wrong results)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise TetraHipError(-2, f"{LIB_PATH} not built (run `make -C tetraear_amd/csrc`); "
                                     "this package has no CPU path")
         lib = C.CDLL(LIB_PATH)
+        lib.tdm_version.restype = C.c_int
+        lib.tdm_version.argtypes = []
+        v = lib.tdm_version()
+        if v < 0 and not os.environ.get(ALLOW_EXPERIMENT_ENV):
+            raise TetraHipError(-2, f"{LIB_PATH} is a timing-only experiment build (tdm_version() = {v}): its results "
+                                    f"are knowingly wrong; set {ALLOW_EXPERIMENT_ENV}=1 only to time it")
+        if abs(v) != ABI_VERSION:
+            raise TetraHipError(-2, f"{LIB_PATH} reports tdm_version() = {v}, these bindings are for {ABI_VERSION} "
+                                    "(rebuild: `make -C tetraear_amd/csrc`)")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

@@ -229,6 +229,7 @@ class BatchDemodulator:
         check(self.lib.tdm_set_stream(None))
 
     def download(self):
+        self.sync()   # (the plan's stream does not block the copies below by itself)
         d = self._dev
         rows, ms = self.n_carriers, self.info.max_soft
         n_soft = d["n_soft"].download(np.int32, rows)

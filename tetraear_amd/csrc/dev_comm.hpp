@@ -122,6 +122,8 @@ struct BlockComm {
     __device__ __forceinline__ double reduce_sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
     __device__ __forceinline__ double reduce_max(double v) { return reduce(v, [](double a, double b) { return fmax(a, b); }); }
     __device__ __forceinline__ double reduce_min(double v) { return reduce(v, [](double a, double b) { return fmin(a, b); }); }
+    // numpy's np.max: a NaN operand wins
+    __device__ __forceinline__ double reduce_max_nan(double v) { return reduce(v, [](double a, double b) { return (a != a) ? a : ((b != b) ? b : fmax(a, b)); }); }
 };
 
 }  // namespace tdm

@@ -113,6 +113,7 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     fa.n_soft = io.n_soft;
     fa.best_phase = io.best_phase;
     fa.min_margin = io.min_margin;
+    fa.smear = (h.decimated || h.lpf) ? 1 : 0;   // a zero-phase filter ran: one non-finite sample is the reference's all-NaN chunk
     if (h.lp2.ok) {
         // fix-up + frequency_shift + filter_signal + phase powers in one kernel, output final and phase-major; then the
         // finish stage

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1633,6 +1634,16 @@ struct DevZp {
 // one zero-phase stage on a c128 host array
 int run_zp_stage(const ZpHostTables &t, bool sos, const double *x, int64_t n, double *y, int64_t n_out, double fs)
 {
+    // scipy's zero-phase filters carry one non-finite sample over the whole output (forward pass to the end, backward pass
+    // back to the start: every value NaN + NaN j; goldens tests/golden/nonfinite.npz).  The device evaluates the filter in
+    // blocks whose carries are cut below 1e-30 and would keep the NaN local, so this host-buffer entry point looks at its
+    // input first: nothing is computed for such a call, the answer is the fill.  (process() decides the same thing on the
+    // device, from the phase powers: FinishArgs::smear.)
+    for (int64_t i = 0; i < 2 * n; ++i)
+        if (!std::isfinite(x[i])) {
+            std::fill(y, y + 2 * n_out, std::numeric_limits<double>::quiet_NaN());
+            return TDM_OK;
+        }
     DevZp dz;
     DevBuf dx, dy;
     int rc;

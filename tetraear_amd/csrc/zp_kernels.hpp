@@ -1036,6 +1036,15 @@ struct FinishArgs {
     // sample p + sps*k of a row at zt[(row*sps + p)*zt_k + k]
     const double *zt;
     int64_t zt_k;
+    // smear != 0: a zero-phase filter ran in front of this stage (scipy's decimate / filtfilt, processor.py:254, :79).  In the
+    // reference such a filter carries ONE non-finite sample over the whole chunk -- forward pass to the end, backward pass,
+    // started from the forward pass's last value, back to the start -- so every soft symbol is NaN, no timing phase beats
+    // max_power = -1 (:196-210 -> phase 0) and every slicer comparison is false (:152-161 -> symbol 3).  The device's
+    // filters are evaluated in blocks whose carries are cut below 1e-30, so a NaN stays inside its block and chunk; but it
+    // does reach that chunk's phase powers, every one of them, and a non-finite phase power here is therefore the reference's
+    // all-NaN chunk.  (smear == 0 -- the stand-alone methods, and the <= 15 samples no filter takes: nothing is carried
+    // anywhere and the comparisons below behave as numpy's do.)
+    int32_t smear;
 };
 
 constexpr int kMaxSps = 32;       // phases a partial-power record holds
@@ -1083,6 +1092,7 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
     int64_t best = 0;
     int64_t ns = n;
     const int64_t sps = A.sps;
+    bool nonfinite = false;   // (FinishArgs::smear) the reference's zero-phase filters made this chunk all-NaN
     if (A.do_extract && n > 0 && sps > 1) {
         const int64_t step = sps / 8 > 1 ? sps / 8 : 1;
         if (A.partials) {
@@ -1109,10 +1119,13 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
                 }
             }
             // "first strictly greater wins" == the lowest phase among those with the maximum power
-            const double mxp = cm.reduce_max(power);
-            const double cand = (power >= 0 && power == mxp) ? (double)tid : 1e9;
+            const double mxp = cm.reduce_max(power);   // (fmax: a NaN power never wins, as `power > max_power` never does)
+            // a non-finite power of a tried phase rides the same reduction as candidate -1
+            const double cand = (A.smear && !(fabs(power) <= 1.7976931348623157e308)) ? -1.0
+                                : ((power >= 0 && power == mxp) ? (double)tid : 1e9);
             const double first = cm.reduce_min(cand);
-            best = first < 1e8 ? (int64_t)first : 0;
+            nonfinite = first < 0;
+            best = (first < 1e8 && !nonfinite) ? (int64_t)first : 0;
         } else {
             double maxp = -1.0;
             for (int64_t ph = 0; ph < sps; ph += step) {
@@ -1126,7 +1139,9 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
                 }
                 const double power = cm.reduce_sum(acc) / (double)np_;
                 if (power > maxp) { maxp = power; best = ph; }  // identical on every thread
+                if (A.smear && !(fabs(power) <= 1.7976931348623157e308)) nonfinite = true;
             }
+            if (nonfinite) best = 0;
         }
         ns = (n - best) / sps;
     }
@@ -1137,7 +1152,9 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
     for (int64_t k = tid; k < ns; k += nt) {
         const int64_t j = best + k * stride;
         double re, im;
-        if (A.zt) {
+        if (nonfinite) {
+            re = im = NAN;
+        } else if (A.zt) {
             const double *sp = A.zt + (((int64_t)row * sps + best) * A.zt_k + k) * 2;
             re = sp[0];
             im = sp[1];
@@ -1151,17 +1168,20 @@ TDM_HD void finish_body(const FinishArgs &A, Comm &cm, int row)
         }
         soft[k * 2] = re;
         soft[k * 2 + 1] = im;
-        mx = fmax(mx, hypot(re, im));
+        const double h = hypot(re, im);
+        mx = (mx != mx) ? mx : ((h != h || h > mx) ? h : mx);   // np.max: a NaN wins
     }
     if (tid == 0) {
         A.n_soft[row] = (int32_t)ns;
         if (A.best_phase) A.best_phase[row] = (int32_t)best;
     }
     if (!A.do_demod) return;
-    mx = cm.reduce_max(mx);   // (its barriers also make the soft symbols of other threads visible)
+    mx = cm.reduce_max_nan(mx);   // (its barriers also make the soft symbols of other threads visible)
     double margin = INFINITY;
     if (ns >= 2) {
-        const double scl = mx > 0 ? 1.0 / mx : 1.0;  // samples / max_power == samples * fl(1/max)
+        // samples / max_power == samples * fl(1/max).  `if max_power > 0` (processor.py:126) is false for a NaN maximum: no
+        // normalisation; an infinite one scales every finite sample to a signed zero, as the reference's division does
+        const double scl = mx > 0 ? 1.0 / mx : 1.0;
         for (int64_t k = 1 + tid; k < ns; k += nt) {
             const double *c = soft + k * 2;
             const double *p = soft + (k - 1) * 2;
