@@ -1044,9 +1044,15 @@ def leg_gardner(rows, base, chk, steps):
         for _ in range(steps):
             b.enqueue()
         return b.time_end() / steps
-    # beside it: the same batch as whole chunks (plan option), and a quarter of it (more pieces per chunk: the plan's rule)
-    side = {}
+    # beside it: the number of pieces FITTED TO THIS BATCH (plan option -1: the fastest for this row count on this device,
+    # and the one setting under which a carrier's soft symbols depend on the plan's size -- the default's pieces follow from
+    # the chunk alone), the same batch as whole chunks, and a quarter of it
+    side = {"loops_per_carrier_rule": "default: the largest of 2, 4, 8 pieces the chunk's length allows (chunk-only: the same "
+                                      "carrier gives the same symbols in a plan of any size)"}
     if halves > 1:
+        bd.set_gardner_segments(-1)
+        side["fitted_to_batch"] = {"loops_per_carrier": int(bd.info.gardner_segments), "ms_per_step": timed(bd),
+                                   "note": "tdm_plan_option gardner_segments = -1: fewer, longer pieces when the batch fills the device by itself"}
         bd.set_gardner_segments(0)
         side["whole_chunks_ms_per_step"] = timed(bd)
     bd.close()

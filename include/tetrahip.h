@@ -87,9 +87,9 @@ typedef struct tdm_plan_info {
     int32_t dec_engine;   /* decimator kernel the next call runs: 0 none, 1 cascade engine, 2 parallel form on doubles,
                              3 parallel form on the raw bytes (cu8 batches of at least 8 blocks per CU) */
     int32_t gardner_segments; /* TDM_MODE_TETRA_GARDNER: the number of independently started loops every carrier's chunk is
-                             walked as, joined at seams (2, 4 or 8 for batches that would otherwise leave most of the device
-                             idle, chunks long enough for a loop's 384 warm-up symbols; oracle/tetra_np.py
-                             demod_gardner(segments=K)), else 1; 0 in the other modes */
+                             walked as, joined at seams: by default the largest of 2, 4, 8 that leaves every loop its 384
+                             warm-up symbols -- a function of the chunk (length, rate, taps) alone, never of the batch --
+                             else 1 (oracle/tetra_np.py demod_gardner(segments=K)); 0 in the other modes */
 } tdm_plan_info;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -106,9 +106,8 @@ TDM_API int tdm_last_error(char *buf, size_t buflen);
  *   "raw_min_blocks"  >= 0: decimator blocks below which a batch stays on the double-based kernel, for plans
  *                     created from now on                                                                   (default -1: 8 per CU)
  *   "gardner_fused"   0: TDM_MODE_TETRA_GARDNER as three launches (matched filter -> HBM -> loop -> decisions)  (default 1)
- *   "gardner_segments" 0: TDM_MODE_TETRA_GARDNER plans created from now on walk every carrier's chunk in one piece instead of
- *                     as 2, 4 or 8 independently started pieces joined at seams (the default for batches that leave the
- *                     device mostly idle); K > 1: at most K pieces                                          (default 1)
+ *   "gardner_segments" what tdm_plan_option "gardner_segments" sets per plan, for TDM_MODE_TETRA_GARDNER plans created from
+ *                     now on: 0 whole chunks, 1 the default, K > 1 at most K pieces, -1 fitted to the batch   (default 1)
  *   "pfb_direct"      1: channeliser plans created from now on use the direct-DFT kernel                     (default 0)
  *   "pfb_rounds"      > 0: rounds per channeliser workgroup, for plans created from now on                  (default 0: computed)
  *   "pfb_halftile"    1: half-tile channeliser kernel for 8-bit formats, plans created from now on          (default 0) */
@@ -131,10 +130,17 @@ TDM_API int tdm_plan_destroy(tdm_plan *plan);
  *       threshold is below that, which the per-carrier min_margin output reports: a caller that needs the reference's
  *       decision there re-runs the carriers with min_margin < 1e-8 on a plan without the option
  *       (tetraear_amd.batch.BatchDemodulator.process does).
- *   "gardner_segments"  (TDM_MODE_TETRA_GARDNER) 0: whole chunks; 1: the plan's own rule (the state after tdm_plan_create);
- *       K = 2..8: at most K independently started loops per chunk.  Waits for the plan's stream; tdm_plan_get_info reports
- *       the number now in force.  In pieces the symbols before the first seam are those of the whole-chunk path bit for
- *       bit, behind a seam the soft symbols agree with it to about 1 % of the largest symbol.
+ *   "gardner_segments"  (TDM_MODE_TETRA_GARDNER) how many independently started loops a carrier's chunk is walked as.
+ *       1 (the state after tdm_plan_create): the largest of 2, 4, 8 pieces that leaves every loop its 384 warm-up symbols
+ *       -- decided by the chunk's length, rate and tap count ALONE, so the same carrier gives the same symbols bit for bit
+ *       whatever the plan's carrier count and whatever the device (tap counts above 41, whose fused kernel serves one round
+ *       of workgroups only, keep whole chunks); 0: whole chunks; K = 2..8: at most K pieces, by the same rule;
+ *       -1: FITTED TO THE BATCH -- the number of pieces that is fastest for this plan's carrier count on this device
+ *       (e.g. 2 at 4096 carriers x 32 768 samples, where the default's 8 cost 20 % more time for their warm-ups): the one
+ *       setting under which a carrier's soft symbols behind a seam depend on the plan's size.  Waits for the device;
+ *       tdm_plan_get_info reports the number now in force.  In pieces the symbols before the first seam are those of the
+ *       whole-chunk path bit for bit, behind a seam the soft symbols agree with it to about 1 % of the largest symbol
+ *       (DESIGN.md 4.8).
  *   "gardner_ff_start"  (TDM_MODE_TETRA_GARDNER, default 0) 1: the first loop of every chunk starts at a feed-forward
  *       (square-law) timing estimate over the chunk's first 512 filter outputs instead of at sample 1 + sps -- the later
  *       pieces of a chunk always do.  The Gardner detector's error vanishes half a symbol off the eye as well as on it, so a

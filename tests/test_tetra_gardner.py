@@ -343,14 +343,18 @@ def test_gpu_gardner_pieces_per_carrier_against_whole_chunks():
     warm-ups, batches that fill the device by themselves."""
     from tetraear_amd._lib import MODE_TETRA_GARDNER, debug_option
     from tetraear_amd.batch import BatchDemodulator
-    for fs, n, rows in ((72000.0, 4096, 8), (72000.0, 32768, 8200)):
+    # the default follows from the chunk alone (length, rate, taps): too short for the warm-ups -> whole chunks; long enough ->
+    # 8 pieces whatever the batch (8200 and 4096 carriers run in several rounds of workgroups); 65 taps (8 samples per
+    # symbol: one workgroup per compute unit, the fused kernel serves one round only) -> whole chunks.  Fitted to the
+    # batch (-1, the round-5 rule): 2 pieces at the bench leg's 4096 carriers, whole chunks once the batch fills the device.
+    for fs, n, rows, want, fitted in ((72000.0, 4096, 8, 1, 1), (72000.0, 32768, 8200, 8, 1), (72000.0, 32768, 4096, 8, 2),
+                                     (72000.0, 32768, 16, 8, 8), (144000.0, 65536, 16, 1, 8)):
         bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
-        assert bd.info.gardner_segments == 1, (fs, n, rows)
+        assert bd.info.gardner_segments == want, (fs, n, rows, bd.info.gardner_segments)
+        bd.set_gardner_segments(-1)
+        assert bd.info.gardner_segments == fitted, (fs, n, rows, bd.info.gardner_segments)
         bd.close()
-    bd = BatchDemodulator(72000.0, 32768, 4096, "cf32", mode=MODE_TETRA_GARDNER)
-    assert bd.info.gardner_segments == 2      # (the bench leg's batch: two workgroups per compute unit)
-    bd.close()
-    for fs, n, rows, picks in ((72000.0, 32768, 32, 8), (72000.0, 30001, 21, 8), (90000.0, 40960, 16, 8), (144000.0, 65536, 16, 8)):
+    for fs, n, rows, picks, rule in ((72000.0, 32768, 32, 8, 1), (72000.0, 30001, 21, 8, 1), (90000.0, 40960, 16, 8, 1), (144000.0, 65536, 16, 8, -1)):
         sig = [_gardner_case(n, fs, 1500 + r, 0.07 * r - 0.4, float((r * 29) % 200 - 100), 20.0, float((r % 5) - 2) * 60.0) for r in range(rows)]
         iq = np.concatenate([s[0] for s in sig])
         with debug_option("gardner_segments", 0):
@@ -359,11 +363,11 @@ def test_gpu_gardner_pieces_per_carrier_against_whole_chunks():
             h1, s1, t1, m1 = bd.process(iq)
             bd.close()
         seen = set()
-        for at_most in (1, 2, 4):       # 1: the plan's own choice
+        for at_most in ((rule, 2, 4) if rule == 1 else (rule,)):       # 1: the default; -1: fitted to the batch (65 taps: the only way to pieces)
             with debug_option("gardner_segments", at_most):
                 bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
                 K = bd.info.gardner_segments
-                assert K == (picks if at_most == 1 else min(picks, at_most)), (fs, n, rows, at_most, K)
+                assert K == (picks if at_most in (1, -1) else min(picks, at_most)), (fs, n, rows, at_most, K)
                 if K in seen:
                     bd.close()
                     continue
@@ -418,6 +422,8 @@ def test_gpu_gardner_segments_as_a_plan_option():
         assert np.array_equal(t, fresh[allow][1][2])
     with pytest.raises(TetraHipError):
         bd.set_gardner_segments(9)
+    with pytest.raises(TetraHipError):
+        bd.set_gardner_segments(-2)
     bd.close()
     bf = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA)
     with pytest.raises(TetraHipError):
@@ -493,3 +499,40 @@ def test_gpu_gardner_feed_forward_start_option():
         with pytest.raises(TetraHipError):
             bd.set_gardner_ff_start(True)
         bd.close()
+
+
+@pytest.mark.gpu
+def test_gpu_gardner_result_does_not_depend_on_the_batch():
+    """Round-5 review: "a receiver's result must not depend on who else is in the launch".  The same 16 carriers demodulated
+    inside plans of 16, 1024 and 4096 carriers (the rest of each batch other signals): the default number of pieces is the
+    same in all three (it follows from the chunk alone) and the 16 carriers' hard decisions, soft symbols, counts and timing
+    come out bit for bit the same -- also where they sit in the batch (first rows, last rows).  With the pieces fitted to the
+    batch (plan option -1) the number differs between those plans, which is what the default no longer does."""
+    from tetraear_amd._lib import MODE_TETRA_GARDNER
+    from tetraear_amd.batch import BatchDemodulator
+    fs, n, keep = 72000.0, 32768, 16
+    sig = [_gardner_case(n, fs, 7100 + r, 0.06 * r - 0.45, float((r * 23) % 200 - 100), 20.0, float((r % 5) - 2) * 70.0)[0] for r in range(keep)]
+    filler = [_gardner_case(n, fs, 7300 + r, 0.11 * r - 0.3, float(r * 17 - 60), 18.0, 0.0)[0] for r in range(8)]
+    ref, pieces, fitted = None, set(), set()
+    for rows, at in ((16, 0), (1024, 0), (1024, 1008), (4096, 0), (4096, 4080)):
+        iq = np.empty((rows, n), np.complex64)
+        for r in range(rows):
+            iq[r] = filler[r % len(filler)]
+        iq[at:at + keep] = sig
+        bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+        pieces.add(int(bd.info.gardner_segments))
+        hards, softs, timing, margin = bd.process(iq.reshape(-1))
+        bd.set_gardner_segments(-1)
+        fitted.add(int(bd.info.gardner_segments))
+        bd.close()
+        got = ([hards[at + r] for r in range(keep)], [softs[at + r] for r in range(keep)], np.array(timing[at:at + keep]), np.array(margin[at:at + keep]))
+        if ref is None:
+            ref = got
+            assert all(len(h) > 8000 for h in got[0])
+            continue
+        for r in range(keep):
+            assert np.array_equal(got[0][r], ref[0][r]), (rows, at, r)
+            assert np.array_equal(got[1][r], ref[1][r]), (rows, at, r)
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), (rows, at)
+    assert pieces == {8}, pieces
+    assert fitted == {8, 2}, fitted

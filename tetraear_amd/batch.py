@@ -81,8 +81,10 @@ class BatchDemodulator:
         return self
 
     def set_gardner_segments(self, pieces=1):
-        """tdm_plan_option "gardner_segments" (MODE_TETRA_GARDNER): 0 whole chunks, 1 the plan's own rule, K at most K
-        independently started loops per chunk; `info.gardner_segments` then says how many are in force."""
+        """tdm_plan_option "gardner_segments" (MODE_TETRA_GARDNER): 0 whole chunks, 1 the default (from the chunk alone: the
+        same symbols whatever the batch), K at most K independently started loops per chunk, -1 fitted to this plan's batch
+        and device (fastest; soft symbols behind a seam then depend on the plan's size); `info.gardner_segments` then says
+        how many are in force."""
         check(self.lib.tdm_plan_option(self.handle, b"gardner_segments", int(pieces)))
         check(self.lib.tdm_plan_get_info(self.handle, C.byref(self.info)))
         return self

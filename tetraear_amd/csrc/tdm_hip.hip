@@ -52,7 +52,7 @@ static DebugSwitch g_debug[] = {
     {"pfb_direct", {0}, 0},              // 1: channeliser plans made from now on use the direct-DFT kernel
     {"pfb_rounds", {0}, 0},              // > 0: rounds per channeliser workgroup (plans made from now on)
     {"pfb_halftile", {0}, 0},
-    {"gardner_segments", {1}, 1},        // 0: TDM_MODE_TETRA_GARDNER plans used from now on walk whole chunks; K > 1: at most K pieces per chunk
+    {"gardner_segments", {1}, 1},        // tdm_plan_option "gardner_segments" for TDM_MODE_TETRA_GARDNER plans made from now on (0, 1, K, -1)
 };
 static DebugSwitch *debug_find(const char *key)
 {
@@ -656,12 +656,18 @@ static bool gardner_geometry(int64_t n, double sps, int ntaps_design, int K, Gar
     return true;
 }
 
-// TDM_MODE_TETRA_GARDNER: K pieces per carrier's chunk when the launch would otherwise leave most of the chip idle (one loop
-// wavefront per sixteen carriers; two workgroups share a compute unit up to 41 taps) and the chunk is long enough for a
-// piece's 384 warm-up symbols to pay: K = the power of two up to 8 with the shortest pieces -- a piece's time is its length,
-// times 1.18 when two loops share a compute unit (measured) -- among those whose workgroups are all resident at once.
-// allow: 0 whole chunks, 1 the rule's choice, K > 1 at most K pieces (tdm_plan_option / tdm_debug_set "gardner_segments").
-// Called when the plan is made and when the option changes (the stream idle): sets plan->gardner_seg, the geometry and the
+// TDM_MODE_TETRA_GARDNER: K pieces per carrier's chunk (K independently started loops joined at seams).  The DEFAULT depends
+// on the chunk alone -- its length, rate and tap count: the largest power of two up to 8 whose pieces leave every loop its
+// 384 warm-up symbols (gardner_geometry) -- so a carrier's symbols do not depend on how many other carriers share the plan or
+// on the device's size (round-5 review: the default used to be fitted to the batch); a batch whose K x rows / 16 workgroups
+// are not all resident at once runs in more than one round of them.  The tap counts above 41 (one 79 KB workgroup per
+// compute unit: the fused kernel only serves a launch of one round there) keep whole chunks by default.
+// allow (tdm_plan_option / tdm_debug_set "gardner_segments"): 0 whole chunks; 1 the default above; K = 2, 4, 8 at most K
+// pieces (the chunk's rule, capped); -1 FITTED TO THE BATCH, the round-5 rule: the power of two up to 8 with the shortest
+// pieces -- a piece's time is its length, times 1.18 when two loops share a compute unit (measured) -- among those whose
+// workgroups are all resident at once: the fastest for this plan's row count on this device, and the one setting under
+// which the same carrier gives (slightly) different soft symbols behind a seam in plans of different size.
+// Called when the plan is made and when the option changes (the device idle): sets plan->gardner_seg, the geometry and the
 // temporaries.
 static int gardner_choose_pieces(tdm_plan *p, long long allow)
 {
@@ -673,17 +679,27 @@ static int gardner_choose_pieces(tdm_plan *p, long long allow)
     p->gseg = GardnerSeg{};
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
-    const int per_cu = p->gardner_fused_ok == 1 ? tetra_gardner_fused_per_cu(tp.ntaps) : 0;
+    const int per_cu = tetra_gardner_fused_per_cu(tp.ntaps);   // (0: no fused kernel for this tap count)
     int best_k = 1;
     GardnerGeom best{};
-    double best_cost = (double)tp.n * ((int64_t)(p->rows + 15) / 16 > cus ? 1.18 : 1.0);
-    for (int K = 2; K <= 8 && per_cu >= 1 && allow != 0 && (allow == 1 || K <= allow); K *= 2) {
-        const int64_t wgs = ((int64_t)K * p->rows + 15) / 16;
-        if (wgs > (int64_t)cus * (per_cu >= 2 ? 2 : 1)) break;            // (all pieces' workgroups resident at once)
-        GardnerGeom g;
-        if (!gardner_geometry(tp.n, tp.sps, p->gardner_ntaps_design, K, &g)) break;
-        const double cost = (double)g.n_v * (wgs > cus ? 1.18 : 1.0);
-        if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best = g; }
+    if (allow == -1) {
+        const int per_cu_ok = p->gardner_fused_ok == 1 ? per_cu : 0;
+        double best_cost = (double)tp.n * ((int64_t)(p->rows + 15) / 16 > cus ? 1.18 : 1.0);
+        for (int K = 2; K <= 8 && per_cu_ok >= 1; K *= 2) {
+            const int64_t wgs = ((int64_t)K * p->rows + 15) / 16;
+            if (wgs > (int64_t)cus * (per_cu_ok >= 2 ? 2 : 1)) break;            // (all pieces' workgroups resident at once)
+            GardnerGeom g;
+            if (!gardner_geometry(tp.n, tp.sps, p->gardner_ntaps_design, K, &g)) break;
+            const double cost = (double)g.n_v * (wgs > cus ? 1.18 : 1.0);
+            if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best = g; }
+        }
+    } else if (allow != 0 && per_cu >= 2 && debug_value("gardner_fused") != 0) {
+        for (int K = 2; K <= 8 && (allow == 1 || K <= allow); K *= 2) {
+            GardnerGeom g;
+            if (!gardner_geometry(tp.n, tp.sps, p->gardner_ntaps_design, K, &g)) break;
+            best_k = K;
+            best = g;
+        }
     }
     p->gardner_seg = 1;   // (whole chunks unless everything below succeeds: a failed allocation leaves a plan that works)
     if (best_k > 1) {
@@ -926,9 +942,10 @@ int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value)
     }
     if (std::strcmp(key, "gardner_segments") == 0) {
         if (plan->mode != TDM_MODE_TETRA_GARDNER) return fail(TDM_ERR_UNSUPPORTED, "gardner_segments is an option of TDM_MODE_TETRA_GARDNER plans");
-        if (value < 0 || value > 8) return fail(TDM_ERR_INVALID, "gardner_segments: 0 (whole chunks), 1 (the plan's rule) or the largest number of pieces allowed (2..8)");
+        if (value < -1 || value > 8) return fail(TDM_ERR_INVALID, "gardner_segments: 0 (whole chunks), 1 (the default: from the chunk alone), the largest number of pieces allowed (2..8), or -1 (fitted to this plan's batch and device)");
         HIP_TRY(hipSetDevice(plan->device));
-        HIP_TRY(hipStreamSynchronize(plan->stream));     // (calls in flight use the temporaries)
+        // calls in flight use the temporaries -- on the plan's stream or on one the caller handed to tdm_process_device
+        HIP_TRY(hipDeviceSynchronize());
         return gardner_choose_pieces(plan, value);
     }
     return fail(TDM_ERR_INVALID, std::string("tdm_plan_option: unknown option '") + key + "'");
@@ -980,7 +997,9 @@ int tdm_plan_get_info(const tdm_plan *plan, tdm_plan_info *info)
     info->in_fmt = plan->fmt;
     info->mode = plan->mode;
     info->device = plan->device;
-    info->gardner_segments = plan->mode == TDM_MODE_TETRA_GARDNER ? plan->gardner_seg : 0;
+    // (pieces are the fused kernel's: with tdm_debug_set("gardner_fused", 0) flipped after the plan was made the three launches
+    //  walk whole chunks)
+    info->gardner_segments = plan->mode == TDM_MODE_TETRA_GARDNER ? ((debug_value("gardner_fused") != 0 && plan->gardner_fused_ok) ? plan->gardner_seg : 1) : 0;
     if (plan->mode == TDM_MODE_REFERENCE && h.decimated) {
         // (the rule of run_ref_fmt; a call with an input-rate pre-shift stays on the double-based kernel)
         const bool raw = h.raw_S > 0 && plan->fmt == TDM_CU8 && (int64_t)plan->rows * h.dec.p.nb >= h.raw_min_blocks;
