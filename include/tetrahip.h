@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDM_VERSION 101 /* 0.1.1: tdm_plan_info grew by gardner_segments -- a binding checks tdm_version() against the header it was written for */
+#define TDM_VERSION 102 /* 0.1.2: + tdm_plan_wait_for (0.1.1: tdm_plan_info grew by gardner_segments) -- a binding checks tdm_version() against the header it was written for */
 
 #if defined(__GNUC__)
 #define TDM_API __attribute__((visibility("default")))
@@ -203,6 +203,12 @@ TDM_API int tdm_plan_rrc_filter(tdm_plan *plan, const void *iq, int64_t carrier_
  * Without that, a tdm_dev_sync / tdm_plan_sync is required between stages that run on different streams.       */
 TDM_API int tdm_set_stream(void *stream);
 TDM_API int tdm_plan_stream(tdm_plan *plan, void **stream);
+/* Device-side ordering between two plans of one device (no host synchronisation): what is enqueued on `plan`'s stream from
+ * now on starts after everything enqueued so far on `other`'s stream has finished.  Plans are independent objects on their
+ * own streams and normally overlap (a large batch run as two plans of half the carriers each is faster than as one, see
+ * tetraear_amd/batch.py SplitBatchDemodulator); this call is for the places where they must not -- a consumer plan behind a
+ * producer plan, or timing one plan's launches alone on the device.  No counterpart in the reference. */
+TDM_API int tdm_plan_wait_for(tdm_plan *plan, tdm_plan *other);
 /* Host-fed streaming: n_batches consecutive batches, each laid out like one
  * tdm_process call (n_carriers x n_samples back to back; outputs [n_batches][n_carriers][max_soft]...).
  * The host->device copy of batch i+1 and the device->host copy of batch i-1 overlap the kernels of

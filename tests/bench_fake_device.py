@@ -18,8 +18,10 @@ class FakeBatchDemodulator:
     def __init__(self, rate, chunk, carriers, fmt, device=0, **kw):
         self.carriers, self.info = carriers, _Info()
         self.rank = int(os.environ.get("RANK", "0"))
+        self.fmt, self.soft_dtype = 0, np.complex128
 
     def sync(self): pass
+    def wait_for(self, other): pass
     def alloc_device_io(self, shared_input=False): pass
     def upload(self, iq, freq_offsets=None, pre_shifts=None): pass
     def enqueue(self): pass

@@ -33,7 +33,7 @@ def test_loader_refuses_a_stale_or_experiment_library(tmp_path):
     -DTDM_EXPERIMENT build (negative version) both raise.  Stand-in libraries of one function, compiled here."""
     import subprocess
     import sys
-    for ver, env, ok in ((100, {}, False), (-101, {}, False), (-101, {_lib.ALLOW_EXPERIMENT_ENV: "1"}, None)):
+    for ver, env, ok in ((_lib.ABI_VERSION - 1, {}, False), (-_lib.ABI_VERSION, {}, False), (-_lib.ABI_VERSION, {_lib.ALLOW_EXPERIMENT_ENV: "1"}, None)):
         src = tmp_path / f"v{abs(ver)}_{ver < 0}.c"
         so = tmp_path / f"libv{abs(ver)}_{ver < 0}.so"
         src.write_text(f"int tdm_version(void) {{ return {ver}; }}\n")

@@ -34,6 +34,7 @@ class FakeBatchDemodulator:
         self.rank = int(os.environ.get("RANK", "0"))
 
     def sync(self): pass
+    def wait_for(self, other): pass
     def alloc_device_io(self, shared_input=False): pass
     def upload(self, iq, freq_offsets=None, pre_shifts=None): pass
     def enqueue(self): pass
@@ -196,3 +197,30 @@ def test_bench_gpus_2_as_a_plain_command_spawns_its_own_ranks():
     r = subprocess.run(cmd, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=100, cwd=ROOT)
     assert r.returncode != 0 and "refusing to report" in (r.stderr + r.stdout)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.timeout(240)
+def test_bench_gpus_2_default_workload_is_config_4_as_written():
+    """`python bench.py --gpus 2` with no workload flags -- the only form the driver runs: the headline is BASELINE config 4 as
+    written, ONE job of 1024 carriers block-partitioned over the ranks (512 each, scaling "strong", slice digests), and the
+    weak-scaling figure (every rank its own 1024) rides beside it as the side field `weak` (round-5 review).  At N = 1 the
+    default stays the 1024-carrier batch on the one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(TDM_RCCL_LIB=STUB, TDM_BENCH_TEST_HOOK=os.path.join(HERE, "bench_fake_device.py"), PYTHONPATH=ROOT,
+               TDM_BENCH_NO_PINNED="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--chunk", "4096", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["total_carriers"] == 1024
+    assert d["config"]["carriers_per_gpu"] == 512 and "strong0-512of1024" in d["output_check"]["key"]
+    assert d["config"]["steps_in_flight"]["plans"] == 3
+    assert d["weak"]["scaling"] == "weak" and d["weak"]["total_carriers"] == 2048 and d["weak"]["carriers_per_gpu"] == 1024
+    assert d["test_hook"].endswith("bench_fake_device.py")
+    # explicit --carriers keeps weak scaling, no side run
+    r = subprocess.run(cmd + ["--carriers", "4"], env=env, capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["total_carriers"] == 8 and "weak" not in d

@@ -48,6 +48,7 @@ SIGNATURES = {
     "tdm_process": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_process_device": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_plan_sync": (C.c_int, [_vp]),
+    "tdm_plan_wait_for": (C.c_int, [_vp, _vp]),
     "tdm_process_pipelined": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tdm_filter_signal": (C.c_int, [_vp, _i64, _f64, _f64, _vp, _P(_i32), _i32]),
     "tdm_frequency_shift": (C.c_int, [_vp, _i64, _f64, _f64, _vp, _i32]),
@@ -85,7 +86,7 @@ _lib = None
 
 # The header version these bindings (PlanInfo's layout, SIGNATURES) were written for: include/tetrahip.h TDM_VERSION.
 # tests/test_abi_cpu.py holds it to the header; load() holds the library to it.
-ABI_VERSION = 101
+ABI_VERSION = 102
 ALLOW_EXPERIMENT_ENV = "TETRAHIP_ALLOW_EXPERIMENT"   # timing-only builds (negative version): tools/ab_*.py only
 
 

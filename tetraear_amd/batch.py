@@ -220,6 +220,11 @@ class BatchDemodulator:
     def sync(self):
         check(self.lib.tdm_plan_sync(self.handle))
 
+    def wait_for(self, other):
+        """tdm_plan_wait_for: what is enqueued on this plan from now on starts after everything enqueued so far on `other`
+        has finished (device-side ordering between two plans' streams)."""
+        check(self.lib.tdm_plan_wait_for(self.handle, other.handle))
+
     def make_stream_current(self):
         """The stand-alone device-pointer entry points (gate, channeliser, find_sync) called from this thread now enqueue on
         this plan's stream, i.e. in order with `enqueue` and without a host synchronisation in between."""
@@ -272,3 +277,107 @@ class BatchDemodulator:
             self.close()
         except Exception:
             pass
+
+
+class PipelinedBatchDemodulator:
+    """`depth` plans of the SAME batch geometry, consecutive steps handed to them in turn: step k runs on plan k % depth, on
+    that plan's own stream and work buffers, so up to `depth` steps are in flight (device-resident path).
+
+    Why: behind the decimator (which keeps the fp64 pipes full) a step runs three launches that do not -- carries, low-rate
+    stage, finish: 40 % of a step at a third of the issue rate, and launch-latency for small batches.  With the next step's
+    decimator running beside them on another stream the device stays busy: measured on 128 / 512 / 1024 carriers x 262 144
+    samples (tools/split_bench.py, round 6) one plan 0.163 / 0.459 / 0.836 ms per step, two plans in turn 0.123 / 0.397 /
+    0.788, three 0.109 / 0.395 / 0.781; the same batch cut into two HALVES on two streams 0.152 / 0.425 / 0.802 (smaller
+    launches lose more than the overlap wins), "whole dispatch rounds on the raw-byte kernel + the rest on the double-based
+    one" slower than one plan.  A capture loop gets the same by giving chunk k to plan k % depth -- `upload(..., slot=k)`
+    then `enqueue()`; each plan's outputs are those of a lone plan bit for bit (every plan's digest is checked by the
+    bench).
+
+    The methods are BatchDemodulator's device-resident ones.  `upload` without a slot fills every plan's input (the bench:
+    one resident batch); `download` returns the outputs of the step enqueued last, `download_all` every plan's.
+    Per-stage timing (`time_begin(per_stage=True)`) orders the plans ONE AFTER THE OTHER on the device (tdm_plan_wait_for),
+    so that every launch is timed alone; `stage_times` then average over the plans.
+    """
+
+    def __init__(self, sample_rate, n_samples, n_carriers, fmt="cu8", device=0, depth=3):
+        self.plans = []
+        try:
+            for _ in range(max(1, int(depth))):
+                self.plans.append(BatchDemodulator(sample_rate, n_samples, n_carriers, fmt, device))
+        except Exception:
+            self.close()
+            raise
+        self.n_carriers, self.n_samples, self.device = int(n_carriers), int(n_samples), device
+        self.info = self.plans[0].info
+        self.soft_dtype = getattr(self.plans[0], "soft_dtype", np.complex128)
+        self._serial = False
+        self._turn = 0          # the plan the next step goes to
+        self._last = 0          # the plan that ran the step enqueued last
+
+    @property
+    def depth(self):
+        return len(self.plans)
+
+    def set_fast_pre_shift(self, on=True):
+        for p in self.plans:
+            p.set_fast_pre_shift(on)
+        return self
+
+    def alloc_device_io(self, shared_input=False):
+        for p in self.plans:
+            p.alloc_device_io(shared_input)
+
+    def upload(self, iq, freq_offsets=None, pre_shifts=None, slot=None):
+        """slot None: every plan's input buffer (one resident batch for all steps); slot k: the input of step k's plan"""
+        for p in (self.plans if slot is None else [self.plans[int(slot) % self.depth]]):
+            p.upload(iq, freq_offsets, pre_shifts)
+
+    def enqueue(self):
+        p = self.plans[self._turn]
+        if self._serial and self.depth > 1:
+            # per-stage timing: this step starts after the previous one has finished -- on the device, no host round trip
+            p.wait_for(self.plans[self._last])
+        p.enqueue()
+        self._last = self._turn
+        self._turn = (self._turn + 1) % self.depth
+
+    def sync(self):
+        for p in self.plans:
+            p.sync()
+
+    def download(self):
+        self.sync()
+        return self.plans[self._last].download()
+
+    def download_all(self):
+        self.sync()
+        return [p.download() for p in self.plans]
+
+    def time_begin(self, per_stage=True):
+        self.sync()
+        self._serial = bool(per_stage)
+        for p in self.plans:
+            p.time_begin(per_stage)
+
+    def time_end(self):
+        self._serial = False
+        return max(p.time_end() for p in self.plans)
+
+    def stage_times(self):
+        ts = [p.stage_times() for p in self.plans]
+        return {k: sum(t[k] for t in ts) / len(ts) for k in ts[0]}
+
+    def close(self):
+        for p in getattr(self, "plans", []):
+            p.close()
+        self.plans = []
+
+
+def batch_demodulator(sample_rate, n_samples, n_carriers, fmt="cu8", device=0, depth="auto"):
+    """The plan(s) for a device-resident reference-mode batch that is demodulated step after step: a
+    PipelinedBatchDemodulator of three plans (steps in turn, up to three in flight) -- depth "auto" -- or of `depth` plans;
+    depth 1 is a plain BatchDemodulator."""
+    d = 3 if depth == "auto" else int(depth)
+    if d <= 1:
+        return BatchDemodulator(sample_rate, n_samples, n_carriers, fmt, device)
+    return PipelinedBatchDemodulator(sample_rate, n_samples, n_carriers, fmt, device, depth=d)

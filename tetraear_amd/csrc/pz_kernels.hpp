@@ -529,10 +529,44 @@ TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 #endif
 // OPAQUE: the second conversion of a sample (other direction, many steps later) must not be recognised as the same
 // computation -- the compiler would keep the first result alive across the loop instead of converting again
+// The bias of the raw-integer kernel's samples (round 6).  4096 + u, u a byte, is exactly the double whose high dword is
+// 0x40B00000 | u << 8 and whose low dword is zero: byte 1 of the high dword IS the sample.  So a cu8 sample becomes an fp64
+// operand by ONE byte permute (v_perm_b32) into the high half of a register pair whose low half stays zero and whose high
+// half keeps its 0x40B0 -- against a bit-field extract plus a conversion (two instructions at the fp64 issue cost each:
+// 1012 of the ~7200 vector instructions per lane).  The kernel therefore filters u + 4096; the constant rides out by the
+// linearity that already carries the wire format's "- 1": the host folds it into PzLayout::off_yc
+// (in_offset = 1 + 4096 * fl(1/127.5), ref_plan.hpp).  Price: the constant part of every state is 33 times larger (DC 4224
+// instead of 127.5), i.e. five bits of the 53 go to it; the soft symbols stay within 1e-12 of the reference's.
+template <int FMT8>
+struct PzRawBias { static constexpr int value = FMT8 == FMT_CU8 ? kPzRawBiasCu8 : 0; };
+
+// a standing operand pair of the permute conversion: 4096.0 = (0x40B00000, 0), opaque to the compiler from here on
+TDM_HD void pz_raw_slot_init(double &x)
+{
+    x = 4096.0;
+    TDM_OPAQUE_V(x);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_OPAQUE)
+// byte BYTE of w into byte 1 of the slot's high dword (selector bytes: 7, 6 = the slot's own 0x40, 0xB0; BYTE; 0x0c = zero).
+// volatile: never merged with the other direction's conversion of the same byte, which would keep 240 converted values
+// alive across the loop
+template <int BYTE>
+__device__ __forceinline__ void pz_raw_perm(double &slot, uint32_t w)
+{
+    uint32_t hi = (uint32_t)__double2hiint(slot);
+    constexpr uint32_t sel = (7u << 24) | (6u << 16) | ((uint32_t)BYTE << 8) | 0x0cu;
+    asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(hi) : "v"(w), "s"(sel));
+    slot = __hiloint2double((int)hi, __double2loint(slot));
+}
+#endif
+
+// re / im are IN-OUT for the 8-bit unsigned narrow form on the device: standing slots made by pz_raw_slot_init
 template <int FMT8, bool WIDE, bool OPAQUE>
 TDM_HD void pz_raw_cvt(const uint32_t *raw, int i, double &re, double &im)
 {
     if (WIDE) {
+        // (int16 pairs; in-row samples were packed with the bias on)
         uint32_t w = raw[i];
         if (OPAQUE) TDM_OPAQUE_V(w);
         re = (double)(int32_t)(int16_t)(w & 0xffffu);
@@ -540,22 +574,13 @@ TDM_HD void pz_raw_cvt(const uint32_t *raw, int i, double &re, double &im)
     } else {
         const uint32_t w = raw[i / 2];
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_OPAQUE)
-        // the byte comes out of its dword by a bit-field extract written as volatile asm: it is never merged with the
-        // other direction's extract of the same byte (which would keep 240 extracted values alive across the loop) and,
-        // unlike an opaque copy of the dword (round 2: 120 v_mov per lane), costs no instruction of its own
         if (OPAQUE) {
-            uint32_t br, bi;
             if (FMT8 == FMT_CU8) {
-                if (i % 2 == 0) {
-                    asm volatile("v_bfe_u32 %0, %1, 0, 8" : "=v"(br) : "v"(w));
-                    asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(bi) : "v"(w));
-                } else {
-                    asm volatile("v_bfe_u32 %0, %1, 16, 8" : "=v"(br) : "v"(w));
-                    asm volatile("v_bfe_u32 %0, %1, 24, 8" : "=v"(bi) : "v"(w));
-                }
-                re = (double)br;
-                im = (double)bi;
+                if (i % 2 == 0) { pz_raw_perm<0>(re, w); pz_raw_perm<1>(im, w); }
+                else { pz_raw_perm<2>(re, w); pz_raw_perm<3>(im, w); }
             } else {
+                // the byte comes out of its dword by a bit-field extract written as volatile asm (see pz_raw_perm)
+                uint32_t br, bi;
                 if (i % 2 == 0) {
                     asm volatile("v_bfe_i32 %0, %1, 0, 8" : "=v"(br) : "v"(w));
                     asm volatile("v_bfe_i32 %0, %1, 8, 8" : "=v"(bi) : "v"(w));
@@ -571,8 +596,8 @@ TDM_HD void pz_raw_cvt(const uint32_t *raw, int i, double &re, double &im)
 #endif
         const int sh = 16 * (i % 2);
         if (FMT8 == FMT_CU8) {
-            re = (double)(float)((w >> sh) & 0xffu);          // v_cvt_f32_ubyteN + v_cvt_f64_f32
-            im = (double)(float)((w >> (sh + 8)) & 0xffu);
+            re = (double)(int)(((w >> sh) & 0xffu) + (uint32_t)PzRawBias<FMT8>::value);
+            im = (double)(int)(((w >> (sh + 8)) & 0xffu) + (uint32_t)PzRawBias<FMT8>::value);
         } else {
             re = (double)(int32_t)(int8_t)((w >> sh) & 0xffu);
             im = (double)(int32_t)(int8_t)((w >> (sh + 8)) & 0xffu);
@@ -624,15 +649,17 @@ TDM_HD void pz_raw_body(const ZpParams &P, const void *iq, int64_t row_stride, C
         for (int i = 0; i < NR; ++i) {
             if (WIDE) {
                 const uint32_t b = w[i / 2] >> (16 * (i % 2));
-                const int re = FMT8 == FMT_CU8 ? (int)(b & 0xffu) : (int)(int8_t)(b & 0xffu);
-                const int im = FMT8 == FMT_CU8 ? (int)((b >> 8) & 0xffu) : (int)(int8_t)((b >> 8) & 0xffu);
+                const int re = (FMT8 == FMT_CU8 ? (int)(b & 0xffu) : (int)(int8_t)(b & 0xffu)) + PzRawBias<FMT8>::value;
+                const int im = (FMT8 == FMT_CU8 ? (int)((b >> 8) & 0xffu) : (int)(int8_t)((b >> 8) & 0xffu)) + PzRawBias<FMT8>::value;
                 raw[i] = ((uint32_t)re & 0xffffu) | ((uint32_t)im << 16);
             } else {
                 raw[i] = w[i];
             }
         }
     } else if (!WIDE || e0 >= n + 2 * (int64_t)EDGE) {
-        // (nothing of the extended row in this lane; a narrow block never holds an extension sample: see the launch)
+        // (nothing of the extended row in this lane: zeros, WITHOUT the bias -- the constant the host removes is the one over
+        //  the extended row.  A narrow block never comes here: it holds neither an extension sample nor a position outside
+        //  the row, see the launch; its permute conversion could not make a zero)
 #pragma unroll
         for (int c = 0; c < NR; ++c) raw[c] = 0;
     } else {
@@ -664,6 +691,8 @@ TDM_HD void pz_raw_body(const ZpParams &P, const void *iq, int64_t row_stride, C
                     re = 2 * ar - re;
                     im = 2 * ai - im;
                 }
+                re += PzRawBias<FMT8>::value;   // (2 (a + B) - (b + B) = 2 a - b + B: the extension of the biased row)
+                im += PzRawBias<FMT8>::value;
             }
             buf[i] = ((uint32_t)re & 0xffffu) | ((uint32_t)im << 16);
         }
@@ -673,17 +702,20 @@ TDM_HD void pz_raw_body(const ZpParams &P, const void *iq, int64_t row_stride, C
 
     const auto pz = TDM_CPTR(P.pz);
     const bool inject = (blk == 0 && lane == 0);
+    // the four standing operand pairs of the conversions (pz_raw_perm): forward re / im, backward re / im
+    double xfr, xfq, xbr, xbq;
+    pz_raw_slot_init(xfr); pz_raw_slot_init(xfq); pz_raw_slot_init(xbr); pz_raw_slot_init(xbq);
     double e0r, e0i;
-    pz_raw_cvt<FMT8, WIDE, true>(raw, G::P0, e0r, e0i);
+    pz_raw_cvt<FMT8, WIDE, true>(raw, G::P0, xfr, xfq);
+    e0r = xfr; e0i = xfq;
     double yr[S], yi[S];
     {
         const double dx = pz[PzLayout::off_dx];
 #pragma unroll
         for (int t = 0; t < S; ++t) {
-            double xr, xi;
-            pz_raw_cvt<FMT8, WIDE, true>(raw, t * Q, xr, xi);
-            yr[t] = dx * xr;
-            yi[t] = dx * xi;
+            pz_raw_cvt<FMT8, WIDE, true>(raw, t * Q, xbr, xbq);
+            yr[t] = dx * xbr;
+            yi[t] = dx * xbq;
         }
     }
     // ---------------- phase 1: all pole pairs per sample (a sample is converted once per direction) ----------------
@@ -710,7 +742,6 @@ TDM_HD void pz_raw_body(const ZpParams &P, const void *iq, int64_t row_stride, C
                 f1q[s] = inject ? g * e0i : f1q[s]; f2q[s] = inject ? g * e0i : f2q[s];
             }
         }
-        double xfr, xfq, xbr, xbq;
         pz_raw_cvt<FMT8, WIDE, true>(raw, i, xfr, xfq);
         pz_raw_cvt<FMT8, WIDE, true>(raw, ib, xbr, xbq);
 #pragma unroll
@@ -746,8 +777,8 @@ TDM_HD void pz_raw_body(const ZpParams &P, const void *iq, int64_t row_stride, C
         int ar, ai, br, bi;
         pz_raw_sample<FMT8>(rowp, n - 1, ar, ai);
         pz_raw_sample<FMT8>(rowp, n - 1 - EDGE, br, bi);
-        P.flast[(int64_t)row * 2] = (double)(2 * ar - br);
-        P.flast[(int64_t)row * 2 + 1] = (double)(2 * ai - bi);
+        P.flast[(int64_t)row * 2] = (double)(2 * ar - br + PzRawBias<FMT8>::value);
+        P.flast[(int64_t)row * 2 + 1] = (double)(2 * ai - bi + PzRawBias<FMT8>::value);
     }
 }
 

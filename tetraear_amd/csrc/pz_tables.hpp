@@ -162,7 +162,9 @@ inline PzDesign design_pz(const double (*sos)[6], int nsec)
 // ---- tables.  L = samples per lane (a multiple of out_stride whenever S > 0 outputs per lane are tabulated), S =
 // outputs per lane of the in-lane tables.
 // in_scale / in_offset: the kernel runs on u with x = in_scale*u - in_offset (raw-integer kernel; 1 and 0 otherwise):
-// every output-side coefficient carries in_scale, and off_yc holds in_offset * H(1)^2.
+// every output-side coefficient carries in_scale, and off_yc holds in_offset * H(1)^2.  in_bias: the kernel's samples are
+// u + in_bias (pz_kernels.hpp PzRawBias: the one-instruction byte -> fp64 conversion), i.e. x = in_scale*(u + in_bias) -
+// (in_offset + in_scale*in_bias): the constant that off_yc removes grows by in_scale*in_bias, formed in long double.
 //
 // Everything that does not depend on the row length n is built once (PzShared: the design, the unit-state response
 // sequences in long double, the scan / transition matrices and the full blocks' carry tables); the tables of a given
@@ -204,8 +206,11 @@ inline void pz_fill_carry_tables(const PzShared &h, int len, int64_t extra, int 
 }
 }  // namespace detail
 
+// the bias of the raw-integer kernel's cu8 samples (pz_kernels.hpp PzRawBias: 4096 + u by one byte permute)
+constexpr int kPzRawBiasCu8 = 4096;
+
 inline std::shared_ptr<const PzShared> build_pz_shared(const double (*sos)[6], int nsec, int edge, int L, int S, int out_stride,
-                                                       double in_scale = 1.0, double in_offset = 0.0)
+                                                       double in_scale = 1.0, double in_offset = 0.0, double in_bias = 0.0)
 {
     using namespace detail;
     auto sh = std::make_shared<PzShared>();
@@ -285,7 +290,7 @@ inline std::shared_ptr<const PzShared> build_pz_shared(const double (*sos)[6], i
         pz[PzLayout::off_g + s] = (double)(1 / (1 + a1[s] + a2[s]));
     }
     pz[PzLayout::off_dx] = (double)dz.dx;
-    pz[PzLayout::off_yc] = (double)((ldbl)in_offset * h.h1 * h.h1);
+    pz[PzLayout::off_yc] = (double)(((ldbl)in_offset + (ldbl)in_scale * (ldbl)in_bias) * h.h1 * h.h1);
     for (int r = 0; r < D; ++r) pz[PzLayout::off_wx(S) + r] = (double)dz.AE[(size_t)r * (D + 1) + D];
     pz_fill_carry_tables(h, (int)Bn, 0, R_reg, &blob[h.off_T1reg], &blob[h.off_T2reg]);   // the full blocks' carry tables
     return sh;

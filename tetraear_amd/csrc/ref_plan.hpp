@@ -151,9 +151,10 @@ inline RefPlanHost build_ref_plan(double sample_rate, int64_t n, double bandwidt
         h.lpf_t = build_zp_tables(desc_from_tf(h.tf), h.n_dec, kEdgeTf, kLLpf, h.n_dec, 1);
     if (h.lp2.ok && h.decimated && in_fmt == 0 /* FMT_CU8 */ && pz_raw_outputs_per_lane(h.q)) {
         const int S = pz_raw_outputs_per_lane(h.q);
-        // x = fl(1/127.5) * u - 1 (pyrtlsdr's conversion without its two roundings, see pz_raw_body)
+        // x = fl(1/127.5) * u - 1 (pyrtlsdr's conversion without its two roundings, see pz_raw_body); the kernel's samples
+        // are u + 4096 (PzRawBias)
         auto sh = (base && base->raw_S == S && base->dec_raw.shared) ? std::static_pointer_cast<const PzShared>(base->dec_raw.shared)
-                                                                     : build_pz_shared(h.sos.sos, 4, kEdgeSos, h.q * S, S, h.q, 1.0 / 127.5, 1.0);
+                                                                     : build_pz_shared(h.sos.sos, 4, kEdgeSos, h.q * S, S, h.q, 1.0 / 127.5, 1.0, (double)kPzRawBiasCu8);
         h.dec_raw = build_pz_tables(sh, n, h.n_dec);
         h.lp2_raw = build_lp2(h.tf.sos, h.n_dec, kEdgeTf, h.sps, &h.dec_raw, h.sos.sos);
         if (h.lp2_raw.ok) h.raw_S = S;

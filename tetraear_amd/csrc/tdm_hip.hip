@@ -451,6 +451,7 @@ struct tdm_plan {
     int32_t *d_nsoft = nullptr, *d_bp = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_order = nullptr;   // tdm_plan_wait_for: "everything enqueued on this plan's stream so far" (made on first use)
     StageTimer timer;
 };
 
@@ -752,6 +753,7 @@ static void plan_free(tdm_plan *p)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->ev_order) (void)hipEventDestroy(p->ev_order);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -1158,6 +1160,18 @@ int tdm_plan_stream(tdm_plan *plan, void **stream)
 {
     if (!plan || !stream) return fail(TDM_ERR_INVALID, "null argument");
     *stream = (void *)plan->stream;
+    return TDM_OK;
+}
+
+int tdm_plan_wait_for(tdm_plan *plan, tdm_plan *other)
+{
+    if (!plan || !other) return fail(TDM_ERR_INVALID, "null plan");
+    if (plan == other) return TDM_OK;
+    if (plan->device != other->device) return fail(TDM_ERR_UNSUPPORTED, "tdm_plan_wait_for: the two plans are on different devices");
+    HIP_TRY(hipSetDevice(plan->device));
+    if (!other->ev_order) HIP_TRY(hipEventCreateWithFlags(&other->ev_order, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(other->ev_order, other->stream));
+    HIP_TRY(hipStreamWaitEvent(plan->stream, other->ev_order, 0));
     return TDM_OK;
 }
 
