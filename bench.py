@@ -190,6 +190,19 @@ def make_batch(carriers, chunk, fmt, first=0, workers=None):
     raise ValueError(fmt)
 
 
+def make_shared_stream(chunk, tchunks, fmt, rank=0):
+    """--shared: ONE stream of `tchunks` consecutive chunks (a single chunk: the job's stream `rank`, as before; more: one
+    longer stream of its own seed, so that the chunks are consecutive pieces of one signal)"""
+    if tchunks == 1:
+        return make_batch(1, chunk, fmt, rank)
+    from tetraear_amd import synth
+    u8 = synth.dqpsk_cu8_streams(chunk * tchunks, SAMPLE_RATE, [STREAM_SEED0 + 5000 + rank], 1).reshape(-1)
+    if fmt == "cu8":
+        return u8, np.zeros(1)
+    x = synth.cu8_to_c128(u8)
+    return (x.astype(np.complex64) if fmt == "cf32" else x), np.zeros(1)
+
+
 def shared_offsets(carriers):
     """--shared: the carriers' input-rate shifts, a 25 kHz grid centred on the stream (squeezed when more than 64 share it)"""
     return (np.arange(carriers) - (carriers - 1) / 2.0) * 25000.0 * (64.0 / max(carriers, 64))
@@ -395,6 +408,9 @@ def main():
     ap.add_argument("--shared", action="store_true",
                     help="BASELINE config 3: all carriers read ONE shared wideband stream, each shifted to baseband by its "
                          "own offset on load (process(frequency_shift(x, f_k)) per carrier)")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="--shared: T consecutive chunks of the stream per step, every carrier out of every chunk (plan rows = T x "
+                         "carriers, plan option rows_per_chunk): the reference's chunk-after-chunk caller loop, T turns per launch")
     ap.add_argument("--exact-shift", action="store_true",
                     help="--shared: the input-rate shift reproduces the reference's rounding of its phase sample by sample (the "
                          "library's default) instead of the plan option fast_pre_shift (ideal phase ramp, exactly anchored per lane)")
@@ -478,12 +494,17 @@ def main():
     lo, hi = carrier_range(args.total_carriers, rank, world) if strong else (0, args.carriers)
     carriers = hi - lo
     t_plan = time.perf_counter()
+    tchunks = max(1, args.chunks) if args.shared else 1
+    per_chunk = carriers            # carriers shifted out of one chunk of the stream
+    carriers = carriers * tchunks   # plan rows
     bd = batch_mod.batch_demodulator(args.rate, args.chunk, carriers, args.fmt, device=local_rank,
                                      depth=args.depth if args.depth == "auto" else int(args.depth))
     depth = getattr(bd, "depth", 1)
+    if tchunks > 1:
+        bd.set_rows_per_chunk(per_chunk)
     bd.sync()
     plan_create_ms = (time.perf_counter() - t_plan) * 1e3
-    bd.alloc_device_io(shared_input=args.shared)
+    bd.alloc_device_io(shared_input=args.shared and tchunks == 1)
     fast_shift = args.shared and not args.exact_shift
     if fast_shift:
         bd.set_fast_pre_shift()
@@ -491,17 +512,17 @@ def main():
     if args.pmc_child:
         # (the counters do not care what the bytes say: uniform noise, made in a second instead of the job's 1024 streams)
         from tetraear_amd import synth
-        iq = synth.noise_cu8((1 if args.shared else carriers) * args.chunk, 7)
+        iq = synth.noise_cu8((tchunks if args.shared else carriers) * args.chunk, 7)
         if args.fmt != "cu8":
             iq = synth.cu8_to_c128(iq).astype(np.complex64 if args.fmt == "cf32" else np.complex128)
         if args.shared:
-            bd.upload(iq, freq_offsets=None, pre_shifts=shared_offsets(carriers))
+            bd.upload(iq, freq_offsets=None, pre_shifts=np.tile(shared_offsets(per_chunk), tchunks))
         else:
             bd.upload(iq, freq_offsets=carrier_offsets(0, carriers).astype(np.float64))
     elif args.shared:
-        iq, foffs = make_batch(1, args.chunk, args.fmt, rank)
+        iq, foffs = make_shared_stream(args.chunk, tchunks, args.fmt, rank)
         foffs = np.zeros(carriers)
-        pre = shared_offsets(carriers)
+        pre = np.tile(shared_offsets(per_chunk), tchunks)
         bd.upload(iq, freq_offsets=None, pre_shifts=pre)
     else:
         # every carrier of the job is its own stream: this rank's are first .. first + carriers - 1
@@ -550,7 +571,7 @@ def main():
     sym_per_step = int(np.sum(np.maximum(n_soft.astype(np.int64) - 1, 0)))
     # the output of the last timed step is checked, not just counted: its digest must equal the one pinned to the oracle --
     # and so must the last output of every other plan that took steps in turn with it
-    dkey = digest_key(carriers, args.chunk, args.fmt, args.rate, rank, args.shared) + (f":strong{lo}-{hi}of{args.total_carriers}" if strong and world > 1 else "")
+    dkey = digest_key(per_chunk, args.chunk, args.fmt, args.rate, rank, args.shared) + (f":chunks{tchunks}" if tchunks > 1 else "") + (f":strong{lo}-{hi}of{args.total_carriers}" if strong and world > 1 else "")
     digest, want = output_digest(hard, n_soft, bp), expected_digest(dkey)
     if hasattr(bd, "download_all"):
         for o in bd.download_all():
@@ -613,7 +634,7 @@ def main():
         traffic, traffic_src, traffic_detail = None, None, None
         if world == 1 and not args.pmc_child:
             child = ["--carriers", str(carriers), "--chunk", str(args.chunk), "--fmt", args.fmt, "--rate", repr(args.rate),
-                     "--no-cpu-baseline", "--no-extra", "--depth", str(depth)] + (["--shared"] if args.shared else [])
+                     "--no-cpu-baseline", "--no-extra", "--depth", str(depth)] + (["--shared", "--chunks", str(tchunks)] if args.shared else [])
             traffic, traffic_src, traffic_detail = traffic_now(child, "k_pz_raw<" if engine == 3 else ("k_pz_block<" if engine == 2 else "k_zp_block<"),
                                                                samples_per_launch, args.fmt, "k1")
         total = args.total_carriers if strong else carriers * world
@@ -631,8 +652,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": (f"{carriers} carriers shifted out of ONE shared {args.chunk}-sample {args.fmt} stream "
-                                    f"@{args.rate / 1e6:g} MS/s (SURVEY 8(d) C3)") if args.shared else
+            "config": {"workload": (f"{per_chunk} carriers shifted out of ONE shared {args.fmt} stream @{args.rate / 1e6:g} MS/s, "
+                                    f"{tchunks} consecutive chunk(s) of {args.chunk} samples per step (SURVEY 8(d) C3)") if args.shared else
                                    (f"{total} independent 25 kHz carriers, every one its own stream (seeds 1000 + g), over {world} GPU(s) ({carriers} on rank 0), "
                                     f"{args.chunk}-sample {args.fmt} chunks @{args.rate / 1e6:g} MS/s (SURVEY 8(d) C4"
                                     f"{'' if strong else ' per-GPU share x ' + str(world)})"),

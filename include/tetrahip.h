@@ -130,6 +130,13 @@ TDM_API int tdm_plan_destroy(tdm_plan *plan);
  *       threshold is below that, which the per-carrier min_margin output reports: a caller that needs the reference's
  *       decision there re-runs the carriers with min_margin < 1e-8 on a plan without the option
  *       (tetraear_amd.batch.BatchDemodulator.process does).
+ *   "rows_per_chunk"  (TDM_MODE_REFERENCE, default 1) C > 1: the plan's n_carriers rows are T x C -- C carriers out of each of T
+ *       CONSECUTIVE CHUNKS of one stream in one call: plan rows r C ... r C + C - 1 all read input row r
+ *       (iq + r * carrier_stride_samples), each with its own pre_shift_hz / freq_offset_hz entry (both stay per plan row;
+ *       every row's phase starts at its chunk's first sample, as in the reference's per-call frequency_shift).  This is the
+ *       reference's caller loop (ui/modern.py:1908-1912: chunk after chunk through process()) for many carriers of one
+ *       wideband stream, T iterations per launch instead of one: a 64-carrier step is launch-latency, a 256-row step is not.
+ *       C must divide n_carriers.  The raw-byte decimator is not used by such a plan (its rows are rotated samples anyway).
  *   "gardner_segments"  (TDM_MODE_TETRA_GARDNER) how many independently started loops a carrier's chunk is walked as.
  *       1 (the state after tdm_plan_create): the largest of 2, 4, 8 pieces that leaves every loop its 384 warm-up symbols
  *       -- decided by the chunk's length, rate and tap count ALONE, so the same carrier gives the same symbols bit for bit

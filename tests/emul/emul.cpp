@@ -303,6 +303,7 @@ static void small_dft_host(const float *in, float *out)
 }
 
 static bool g_allow_pz = true, g_allow_raw = true, g_fast_shift = false;
+static int g_rows_per_chunk = 1;
 
 extern "C" {
 
@@ -319,6 +320,7 @@ void emu_allow_parallel_form(int on) { g_allow_pz = on != 0; }
 void emu_allow_raw_integer(int on) { g_allow_raw = on != 0; }
 // tests: 1 = the plan option "fast_pre_shift" (the input-rate shift's phase as the ideal ramp)
 void emu_fast_pre_shift(int on) { g_fast_shift = on != 0; }
+void emu_rows_per_chunk(int c) { g_rows_per_chunk = c > 0 ? c : 1; }
 
 // whole pipeline == tdm_process with host pointers
 int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq, int64_t stride,
@@ -365,7 +367,7 @@ int emu_process(double sample_rate, int64_t n, int rows, int fmt, const void *iq
     B.z = z.data();
     std::vector<double> partials((size_t)rows * (h.n_dec / kPowThreads + 16) * kMaxSps, nan);
     B.partials = partials.data();
-    RefIO io{iq, stride, pre_shift, freq_offset, hard, soft, n_soft, best_phase, min_margin, g_fast_shift ? 1 : 0};
+    RefIO io{iq, stride, pre_shift, freq_offset, hard, soft, n_soft, best_phase, min_margin, g_fast_shift ? 1 : 0, g_rows_per_chunk};
     EmuBackend be;
     run_ref(be, h, rows, fmt, B, io);
     return 0;

@@ -21,8 +21,9 @@ def lib():
 FMT = {"cu8": 0, "cs8": 1, "cf32": 2, "cf64": 3}
 
 
-def process(sample_rate, iq, fmt, n, rows=1, stride=None, pre_shift=None, freq_offset=None):
+def process(sample_rate, iq, fmt, n, rows=1, stride=None, pre_shift=None, freq_offset=None, rows_per_chunk=1):
     L = lib()
+    L.emu_rows_per_chunk(int(rows_per_chunk))
     ms = C.c_int32()
     L.emu_process(C.c_double(sample_rate), C.c_int64(n), rows, FMT[fmt], None, C.c_int64(0), None, None,
                   None, None, None, None, None, C.byref(ms))

@@ -191,3 +191,27 @@ def test_emul_fast_pre_shift_against_exact_and_oracle():
         assert np.max(np.abs(b[1][r, :ns] - o.symbols)) <= 1e-9 * scale
         assert np.max(np.abs(a[1][r, :ns] - o.symbols)) <= 1e-10 * scale
         assert np.max(np.abs(a[1][r, :ns] - b[1][r, :ns])) > 0      # (it IS another phase)
+
+
+def test_emul_time_batched_shared_stream():
+    """Plan option "rows_per_chunk" (config 3 in time batches): T consecutive chunks of ONE stream x C carriers in one call --
+    plan row r reads input row r // C with its own pre-shift and offset, its phase starting at its chunk's first sample;
+    every row equals the oracle's p.process(p.frequency_shift(x_chunk, f), foff)."""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    n, T, Cc = 7000, 3, 2
+    u8 = synth.noise_cu8(n * T, 4343)
+    x = synth.cu8_to_c128(u8)
+    shifts = np.tile([-37500.0, 25000.0], T)
+    foffs = np.array([0.0, 1171.875, -500.0, 0.0, 250.0, -1171.875])
+    for fmt, arr in (("cu8", u8), ("cf64", x)):
+        hard, soft, n_soft, bp, mm = emul.process(2.4e6, arr, fmt, n, rows=T * Cc, stride=n, pre_shift=shifts,
+                                                  freq_offset=foffs, rows_per_chunk=Cc)
+        for r in range(T * Cc):
+            o = OracleSignalProcessor(2.4e6)
+            ref = o.process(o.frequency_shift(x[(r // Cc) * n:(r // Cc + 1) * n], shifts[r]), foffs[r])
+            ns = int(n_soft[r])
+            assert ns == len(o.symbols) and bp[r] == o.best_phase, (fmt, r)
+            np.testing.assert_array_equal(hard[r, :ns - 1], ref)
+            assert np.max(np.abs(soft[r, :ns] - o.symbols)) <= SOFT_TOL * np.max(np.abs(o.symbols))
+    emul.lib().emu_rows_per_chunk(1)

@@ -305,6 +305,55 @@ def test_bench_shared_workload_every_carrier_vs_oracle_and_digest():
     assert want is not None and bench.output_digest(hard, n_soft, bp) == want
 
 
+def test_config3_in_time_batches_T4():
+    """Config 3 as its callers run it -- chunk after chunk (ui/modern.py:1908-1912) -- four turns per call: plan option
+    "rows_per_chunk" = 64 on a plan of 4 x 64 rows over FOUR CONSECUTIVE 262144-sample chunks of one multicarrier stream;
+    every one of the 256 rows against the oracle's p.process(p.frequency_shift(x_chunk, f_k)), through the host-pointer
+    call and through the device-resident one with bench.py --shared --chunks 4's own workload and its pinned digest."""
+    import bench
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd import synth
+    from tetraear_amd.batch import BatchDemodulator
+    n, C_, T = 262144, 64, 4
+    offs = [(k - 31.5) * 25000.0 for k in range(C_)]
+    u8, _ = synth.multicarrier_cu8(n * T, 2.4e6, offs, seed0=100)
+    bd = BatchDemodulator(2.4e6, n, C_ * T, "cu8").set_rows_per_chunk(C_)
+    hards, softs, bp, mm = bd.process(u8, pre_shifts=np.tile(offs, T))
+    bd.close()
+    x = synth.cu8_to_c128(u8)
+    for r in range(0, C_ * T, 3):
+        o = OracleSignalProcessor(2.4e6)
+        ref = o.process(o.frequency_shift(x[(r // C_) * n:(r // C_ + 1) * n], offs[r % C_]))
+        assert bp[r] == o.best_phase, r
+        np.testing.assert_array_equal(hards[r], ref, err_msg=f"row {r}")
+        assert np.max(np.abs(softs[r] - o.symbols)) <= SOFT_TOL * np.max(np.abs(o.symbols))
+    # the bench's own workload, every row, and its digest
+    iq, _ = bench.make_shared_stream(n, T, "cu8", 0)
+    pre = np.tile(bench.shared_offsets(C_), T)
+    bd = BatchDemodulator(2.4e6, n, C_ * T, "cu8").set_rows_per_chunk(C_)
+    bd.alloc_device_io()
+    bd.upload(iq, freq_offsets=None, pre_shifts=pre)
+    bd.enqueue()
+    hard, soft, n_soft, bp, mm = bd.download()
+    bd.close()
+    x = synth.cu8_to_c128(iq)
+    for r in range(C_ * T):
+        o = OracleSignalProcessor(2.4e6)
+        ref = o.process(o.frequency_shift(x[(r // C_) * n:(r // C_ + 1) * n], pre[r]))
+        ns = int(n_soft[r])
+        assert ns == len(o.symbols) and bp[r] == o.best_phase, r
+        np.testing.assert_array_equal(hard[r, :ns - 1], ref, err_msg=f"row {r}")
+        assert np.max(np.abs(soft[r, :ns] - o.symbols)) <= SOFT_TOL * np.max(np.abs(o.symbols))
+    want = bench.expected_digest(bench.digest_key(C_, n, "cu8", 2.4e6, 0, True) + ":chunks4")
+    assert want is not None and bench.output_digest(hard, n_soft, bp) == want
+    # a count that does not divide the rows is refused
+    from tetraear_amd._lib import TetraHipError
+    bd = BatchDemodulator(2.4e6, 4096, 6, "cu8")
+    with pytest.raises(TetraHipError):
+        bd.set_rows_per_chunk(4)
+    bd.close()
+
+
 def test_config5_10Msps_q41_all_400_grid_carriers():
     """BASELINE config 5 in reference mode at FULL size: one 10 MS/s cu8 stream of 1 048 576 samples (q = 41, filter memory
     8246 samples), ALL 400 carriers of the 25 kHz grid in ONE launch (grid.y = 400, per-carrier input-rate shift).

@@ -74,6 +74,13 @@ class BatchDemodulator:
         self.fast_pre_shift = bool(on)
         return self
 
+    def set_rows_per_chunk(self, c):
+        """tdm_plan_option "rows_per_chunk": the plan's rows are T x c -- c carriers out of each of T consecutive chunks of one
+        stream (rows r c ... r c + c - 1 read input row r); pre-shifts and offsets stay per plan row."""
+        check(self.lib.tdm_plan_option(self.handle, b"rows_per_chunk", int(c)))
+        self.rows_per_chunk = int(c)
+        return self
+
     def set_gardner_ff_start(self, on=True):
         """tdm_plan_option "gardner_ff_start" (MODE_TETRA_GARDNER): the first loop of every chunk starts at a feed-forward timing
         estimate (no hang-up half a symbol off the eye at the start of a chunk); the later pieces of a chunk always do."""
@@ -106,7 +113,7 @@ class BatchDemodulator:
         (hard_list, soft_list, best_phase, min_margin)."""
         rows, ms = self.n_carriers, self.info.max_soft
         iq = np.ascontiguousarray(iq)
-        need = (1 if shared_input else rows) * self.n_samples * FMT_BYTES[self.fmt]
+        need = (1 if shared_input else rows // getattr(self, "rows_per_chunk", 1)) * self.n_samples * FMT_BYTES[self.fmt]
         if iq.nbytes < need:
             raise ValueError(f"iq holds {iq.nbytes} bytes, plan needs {need}")
         fo = None if freq_offsets is None else np.ascontiguousarray(freq_offsets, dtype=np.float64)
@@ -153,7 +160,7 @@ class BatchDemodulator:
     def alloc_device_io(self, shared_input=False):
         rows, ms = self.n_carriers, self.info.max_soft
         d = {}
-        d["iq"] = DeviceBuffer(self.device, (1 if shared_input else rows) * self.n_samples * FMT_BYTES[self.fmt])
+        d["iq"] = DeviceBuffer(self.device, (1 if shared_input else rows // getattr(self, "rows_per_chunk", 1)) * self.n_samples * FMT_BYTES[self.fmt])
         d["foff"] = DeviceBuffer(self.device, rows * 8)
         d["pre"] = DeviceBuffer(self.device, rows * 8)
         d["hard"] = DeviceBuffer(self.device, rows * ms)
@@ -321,6 +328,11 @@ class PipelinedBatchDemodulator:
     def set_fast_pre_shift(self, on=True):
         for p in self.plans:
             p.set_fast_pre_shift(on)
+        return self
+
+    def set_rows_per_chunk(self, c):
+        for p in self.plans:
+            p.set_rows_per_chunk(c)
         return self
 
     def alloc_device_io(self, shared_input=False):

@@ -78,9 +78,12 @@ struct RawLoaderRT {
     // symbols within 1e-9 instead of 1e-10, and a hard decision can differ only where its margin is below that (the
     // per-carrier min_margin output says so; tetrahip.h tdm_plan_option "fast_pre_shift").
     int32_t fast_shift;
+    // rows_per_chunk > 1 (tdm_plan_option "rows_per_chunk"): that many consecutive plan rows read the SAME input row --
+    // C carriers shifted out of each of T consecutive chunks of one stream in one call (plan rows = T x C)
+    int32_t rows_per_chunk;
 
     TDM_HD int bytes() const { return (fmt == FMT_CU8 || fmt == FMT_CS8) ? 2 : (fmt == FMT_CF32 ? 8 : 16); }
-    TDM_HD const void *row_ptr(int row) const { return (const char *)iq + (int64_t)row * row_stride * bytes(); }
+    TDM_HD const void *row_ptr(int row) const { return (const char *)iq + (int64_t)(rows_per_chunk > 1 ? row / rows_per_chunk : row) * row_stride * bytes(); }
     TDM_HD double row_shift(int row) const { return (SHIFT && pre_shift) ? pre_shift[row] : 0.0; }
 
     TDM_HD void raw(const void *rowp, int64_t k, double &re, double &im) const

@@ -44,6 +44,7 @@ struct RefIO {
     int32_t *best_phase;
     double *min_margin;
     int32_t fast_shift = 0;   // pre_shift as the ideal phase ramp (RawLoaderRT::fast_shift)
+    int32_t rows_per_chunk = 1;   // > 1: that many consecutive plan rows read the same input row (tdm_plan_option "rows_per_chunk")
 };
 
 // parallel-form decimator: one kernel per decimation factor, wire format as a run-time switch
@@ -78,8 +79,9 @@ void run_pz_raw(BE &be, const RefPlanHost &h, const ZpParams &P, const void *iq,
 template <class BE, int FMT, bool SHIFT>
 void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, const RefIO &io)
 {
-    RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate};
-    const bool use_raw = h.raw_S > 0 && FMT == FMT_CU8 && !SHIFT && (int64_t)rows * h.dec.p.nb >= h.raw_min_blocks;
+    RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate, io.rows_per_chunk};
+    // (the raw-byte kernel addresses its rows itself: a plan whose rows share input rows stays on the loaders)
+    const bool use_raw = h.raw_S > 0 && FMT == FMT_CU8 && !SHIFT && io.rows_per_chunk <= 1 && (int64_t)rows * h.dec.p.nb >= h.raw_min_blocks;
     // (the one-kernel low-rate stage forms the block carries inside its carry-response items: no carry launch)
     const bool inline_carry = h.lp2.ok && kLp2InlineCarry;
     if (use_raw) {
@@ -88,7 +90,7 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     } else if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
         if (h.pz_S) {
-            RawLoaderRT<SHIFT> lr{io.iq, io.carrier_stride, SHIFT ? io.pre_shift : nullptr, h.sample_rate, FMT, io.fast_shift};
+            RawLoaderRT<SHIFT> lr{io.iq, io.carrier_stride, SHIFT ? io.pre_shift : nullptr, h.sample_rate, FMT, io.fast_shift, io.rows_per_chunk};
             run_pz_block(be, h, B.dec_params, lr, rows);
         } else {
             be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);

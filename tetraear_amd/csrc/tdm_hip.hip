@@ -418,6 +418,7 @@ struct tdm_plan {
     double sample_rate = 0.0;
     bool allow_raw = true;
     int32_t fast_pre_shift = 0;   // tdm_plan_option "fast_pre_shift"
+    int32_t rows_per_chunk = 1;   // tdm_plan_option "rows_per_chunk"
     int64_t raw_min_blocks = 0;
     std::map<int64_t, std::unique_ptr<Variant>> variants;
     Variant *cur = nullptr;
@@ -936,6 +937,12 @@ int tdm_plan_option(tdm_plan *plan, const char *key, int64_t value)
         plan->fast_pre_shift = value ? 1 : 0;
         return TDM_OK;
     }
+    if (std::strcmp(key, "rows_per_chunk") == 0) {
+        if (plan->mode != TDM_MODE_REFERENCE) return fail(TDM_ERR_UNSUPPORTED, "rows_per_chunk is a reference-mode option");
+        if (value < 1 || plan->rows % value != 0) return fail(TDM_ERR_INVALID, "rows_per_chunk: a divisor of the plan's carrier count (1 = every row its own input row)");
+        plan->rows_per_chunk = (int32_t)value;
+        return TDM_OK;
+    }
     if (std::strcmp(key, "gardner_ff_start") == 0) {
         if (plan->mode != TDM_MODE_TETRA_GARDNER) return fail(TDM_ERR_UNSUPPORTED, "gardner_ff_start is an option of TDM_MODE_TETRA_GARDNER plans");
         if (value && plan->gardner_fused_ok != 1) return fail(TDM_ERR_UNSUPPORTED, "gardner_ff_start needs the fused Gardner kernel, which does not serve this plan");
@@ -1109,7 +1116,7 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
     B.lp2 = v.lp2;
     B.dec_raw_params = v.dec_raw;
     B.lp2_raw = v.lp2_raw;
-    RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin, plan->fast_pre_shift};
+    RefIO io{iq, carrier_stride_samples, pre_shift_hz, freq_offset_hz, hard, soft, n_soft, best_phase, min_margin, plan->fast_pre_shift, plan->rows_per_chunk};
     run_ref(be, v.h, plan->rows, plan->fmt, B, io);
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));
     return TDM_OK;
@@ -1193,8 +1200,10 @@ int tdm_process(tdm_plan *plan, const void *iq, int64_t carrier_stride_samples, 
     if (!plan->cur) return fail(TDM_ERR_INVALID, "plan has no current length");
     const RefPlanHost &h = plan->h();
     const int rows = plan->rows;
+    // (input rows: one per plan row, or one per rows_per_chunk of them)
+    const int in_rows = plan->mode == TDM_MODE_REFERENCE ? rows / plan->rows_per_chunk : rows;
     const size_t span = carrier_stride_samples == 0 ? (size_t)h.n
-                                                    : (size_t)(rows - 1) * carrier_stride_samples + h.n;
+                                                    : (size_t)(in_rows - 1) * carrier_stride_samples + h.n;
     const size_t bytes = span * fmt_bytes(plan->fmt);
     if (plan->d_iq_bytes < bytes) {
         if (plan->d_iq) (void)hipFree(plan->d_iq);
@@ -1477,10 +1486,10 @@ int tdm_hbm_ceiling(int32_t device, size_t bytes, int32_t reps, double *gbs)
     }
     hipStream_t st = g_cur_stream;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipMemsetAsync(a, 0, n16 * 16, st);
-    hipMemsetAsync(b, 0, n16 * 16, st);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipMemsetAsync(a, 0, n16 * 16, st);
+    (void)hipMemsetAsync(b, 0, n16 * 16, st);
     gbs[0] = gbs[1] = gbs[2] = 0.0;
     hipError_t err = hipSuccess;
     // grid-stride kernels, 16 bytes per lane, 8 workgroups of 256 threads per compute unit (2048) and twice that; the best of
@@ -1502,20 +1511,20 @@ int tdm_hbm_ceiling(int32_t device, size_t bytes, int32_t reps, double *gbs)
                 else hipLaunchKernelGGL(k_ceiling_write, dim3(grid), dim3(256), 0, st, b, n16);
             };
             for (int i = 0; i < 3; ++i) launch();
-            hipEventRecord(e0, st);
+            (void)hipEventRecord(e0, st);
             for (int i = 0; i < reps; ++i) launch();
-            hipEventRecord(e1, st);
+            (void)hipEventRecord(e1, st);
             err = hipEventSynchronize(e1);
             if (err != hipSuccess) break;
             float ms = 0.f;
-            hipEventElapsedTime(&ms, e0, e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
             const double moved = (what == 0 ? 2.0 : 1.0) * (double)(n16 * 16) * reps;
             const double rate = moved / ((double)ms * 1e-3) / 1e9;
             if (rate > gbs[what]) gbs[what] = rate;
         }
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     (void)hipFree(a);
     (void)hipFree(b);
     if (err != hipSuccess) return fail(TDM_ERR_HIP, std::string("tdm_hbm_ceiling: ") + hipGetErrorString(err));

@@ -243,13 +243,14 @@ struct RawLoader {
     int64_t row_stride;        // samples between rows (0 = shared stream)
     const double *pre_shift;   // per row [Hz]; read only when SHIFT
     double fs;
+    int32_t rows_per_chunk;    // > 1: that many consecutive plan rows read the same input row (RawLoaderRT::rows_per_chunk)
 
     static constexpr int kBytes = (FMT == FMT_CU8 || FMT == FMT_CS8) ? 2 : (FMT == FMT_CF32 ? 8 : 16);
     static constexpr bool kStaged = false;  // lanes load their own segment straight from memory
 
     TDM_HD const void *row_ptr(int row) const
     {
-        return (const char *)iq + (int64_t)row * row_stride * kBytes;
+        return (const char *)iq + (int64_t)(rows_per_chunk > 1 ? row / rows_per_chunk : row) * row_stride * kBytes;
     }
     TDM_HD double row_shift(int row) const { return (SHIFT && pre_shift) ? pre_shift[row] : 0.0; }
     TDM_HD void sample(const void *rowp, int64_t k, double f, double &re, double &im) const

@@ -46,29 +46,32 @@ def check_batch(carriers, chunk, rank, rate=bench.SAMPLE_RATE, want_rows=False):
     return res + ((hard, n_soft, bp),) if want_rows else res
 
 
-def check_shared(carriers, chunk, rate=bench.SAMPLE_RATE):
-    """bench.py --shared: ONE stream, every carrier shifted out of it; every carrier against
-    p.process(p.frequency_shift(x, f_k)) of the oracle"""
-    iq, _ = bench.make_batch(1, chunk, "cu8", 0)
-    pre = bench.shared_offsets(carriers)
-    bd = BatchDemodulator(rate, chunk, carriers, "cu8")
-    bd.alloc_device_io(shared_input=True)
+def check_shared(carriers, chunk, rate=bench.SAMPLE_RATE, tchunks=1):
+    """bench.py --shared [--chunks T]: ONE stream, every carrier shifted out of (every one of T consecutive chunks of) it;
+    every plan row against p.process(p.frequency_shift(x_chunk, f_k)) of the oracle"""
+    iq, _ = bench.make_shared_stream(chunk, tchunks, "cu8", 0)
+    pre = np.tile(bench.shared_offsets(carriers), tchunks)
+    bd = BatchDemodulator(rate, chunk, carriers * tchunks, "cu8")
+    if tchunks > 1:
+        bd.set_rows_per_chunk(carriers)
+    bd.alloc_device_io(shared_input=tchunks == 1)
     bd.upload(iq, freq_offsets=None, pre_shifts=pre)
     bd.enqueue()
     bd.sync()
     hard, soft, n_soft, bp, mm = bd.download()
     bd.close()
-    x = synth.cu8_to_c128(iq)
+    xs = synth.cu8_to_c128(iq)
     worst = 0.0
-    for r in range(carriers):
+    for r in range(carriers * tchunks):
         o = OracleSignalProcessor(rate)
+        x = xs[(r // carriers) * chunk: (r // carriers + 1) * chunk]
         ref = o.process(o.frequency_shift(x, pre[r]))
         ns = int(n_soft[r])
         assert ns == len(o.symbols) and bp[r] == o.best_phase, r
         assert np.array_equal(hard[r, :ns - 1], ref), r
         worst = max(worst, float(np.max(np.abs(soft[r, :ns] - o.symbols)) / np.max(np.abs(o.symbols))))
     assert worst <= 1e-10, worst
-    return bench.output_digest(hard, n_soft, bp), carriers, worst
+    return bench.output_digest(hard, n_soft, bp), carriers * tchunks, worst
 
 
 if __name__ == "__main__":
@@ -101,5 +104,8 @@ if __name__ == "__main__":
     d, n_or, worst = check_shared(64, 262144)
     res[bench.digest_key(64, 262144, "cu8", bench.SAMPLE_RATE, 0, True)] = d
     print(f"shared: 64 carriers equal to {n_or} oracle runs, soft err {worst:.2e}, sha256 {d[:16]}", flush=True)
+    d, n_or, worst = check_shared(64, 262144, tchunks=4)
+    res[bench.digest_key(64, 262144, "cu8", bench.SAMPLE_RATE, 0, True) + ":chunks4"] = d
+    print(f"shared, 4 consecutive chunks: 64 x 4 rows equal to {n_or} oracle runs, soft err {worst:.2e}, sha256 {d[:16]}", flush=True)
     with open(out, "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
