@@ -75,3 +75,26 @@ def test_gpu_streaming_reader_pipe_and_array(tmp_path):
         proc.wait()
     _check(outs)
     _check(demodulate_recording(u8, 2.4e6, chunk=CHUNK, freq_offset=FOFF, rows_per_batch=7))
+
+
+@pytest.mark.gpu
+def test_gpu_streaming_reader_many_carriers_out_of_one_recording():
+    """BASELINE config 3 read chunk after chunk: a wideband recording with four carriers in it, `iter_recording(...,
+    pre_shifts=[...])` -- every read demodulated once per carrier, `rows_per_batch` reads x 4 carriers per call (plan option
+    rows_per_chunk) -- against the oracle's p.process(p.frequency_shift(read, f_k), freq_offset) for every read and carrier,
+    including a last read that is shorter than the others, and a remainder batch."""
+    from oracle.oracle import OracleSignalProcessor
+    from tetraear_amd.ingest import iter_recording
+    chunk, offs, foff = 32768, [-312500.0, -37500.0, 62500.0, 287500.0], 1171.875
+    n = 7 * chunk + 9001                       # 2 batches of 3 reads, a remainder batch of 1 read, a short read
+    u8, _ = synth.multicarrier_cu8(n, 2.4e6, offs, seed0=400)
+    outs = list(iter_recording(u8, 2.4e6, chunk, foff, rows_per_batch=3, pre_shifts=offs))
+    assert len(outs) == 8 and all(len(o) == 4 for o in outs)
+    x = synth.cu8_to_c128(u8)
+    for i, per_carrier in enumerate(outs):
+        seg = x[i * chunk:(i + 1) * chunk]
+        for k, f in enumerate(offs):
+            o = OracleSignalProcessor(2.4e6)
+            ref = o.process(o.frequency_shift(seg, f), foff)
+            np.testing.assert_array_equal(per_carrier[k], ref, err_msg=f"read {i} carrier {k}")
+    assert len(outs[-1][0]) == (9001 // 10 + 1) // 13 - 1

@@ -51,13 +51,19 @@ def _fill(readinto, view):
     return got
 
 
-def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0, rows_per_batch=64, device=0):
+def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0, rows_per_batch=64, device=0, pre_shifts=None):
     """source: path of a cu8 file, an object with readinto() (open file, pipe), or a uint8 array of interleaved I,Q.
     Yields, in order, one uint8 symbol array per read of `chunk` samples -- what process() returned per read in the
-    reference's loop -- and last the shorter final read, if the recording does not end on a read boundary."""
+    reference's loop -- and last the shorter final read, if the recording does not end on a read boundary.
+
+    pre_shifts (a list of C input-rate offsets in Hz): the recording is a wideband stream with C carriers in it -- BASELINE
+    config 3 read chunk after chunk.  Every read is then demodulated C times, once per carrier, as the reference's
+    `p.process(p.frequency_shift(samples, f_k), freq_offset)` would, `rows_per_batch` reads x C carriers per call (plan option
+    rows_per_chunk), and what is yielded per read is a LIST of C symbol arrays."""
     readinto, close = _open(source)
     lib = _lib.load()
     rows = int(rows_per_batch)
+    ncar = 0 if pre_shifts is None else len(pre_shifts)
     batch_bytes = 2 * chunk * rows
     bufs = [np.zeros(batch_bytes, dtype=np.uint8) for _ in range(2)]
     pinned = []
@@ -67,8 +73,11 @@ def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0,
         for b in bufs:
             check(lib.tdm_host_register(device, ptr(b), b.nbytes))
             pinned.append(b)
-        bd = BatchDemodulator(sample_rate, chunk, rows, "cu8", device=device)
-        foffs = [float(freq_offset)] * rows
+        bd = BatchDemodulator(sample_rate, chunk, rows * max(ncar, 1), "cu8", device=device)
+        if ncar:
+            bd.set_rows_per_chunk(ncar)
+        foffs = [float(freq_offset)] * (rows * max(ncar, 1))
+        pre = None if not ncar else np.tile(np.asarray(pre_shifts, dtype=np.float64), rows)
         # reader thread: fills the buffer the GPU is not working on
         filled = [0, 0]
         state = {"err": None}
@@ -96,17 +105,17 @@ def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0,
             if n_reads:
                 if n_reads < rows:
                     bufs[slot][2 * chunk * n_reads + 2 * tail:] = 128     # blank rows (mid-scale bytes); their output is dropped
-                hards, _, _, _ = bd.resize(chunk).process(bufs[slot], freq_offsets=foffs)
+                hards, _, _, _ = bd.resize(chunk).process(bufs[slot], freq_offsets=foffs, pre_shifts=pre)
                 for r in range(n_reads):
-                    yield hards[r]
+                    yield hards[r] if not ncar else hards[r * ncar:(r + 1) * ncar]
             if tail:
                 # the last, shorter read of the recording: same plan, another chunk length, row 0
                 seg = bufs[slot][2 * chunk * n_reads: 2 * (chunk * n_reads + tail)].copy()
                 bufs[slot][:] = 128
                 bufs[slot][:2 * tail] = seg
                 bd.resize(tail)
-                hards, _, _, _ = bd.process(bufs[slot][:2 * tail * rows], freq_offsets=foffs)
-                yield hards[0]
+                hards, _, _, _ = bd.process(bufs[slot][:2 * tail * rows], freq_offsets=foffs, pre_shifts=pre)
+                yield hards[0] if not ncar else hards[:ncar]
             if t is None:
                 break
             t.join()
@@ -128,6 +137,7 @@ def iter_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0,
             close()
 
 
-def demodulate_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0, rows_per_batch=64, device=0):
-    """the whole recording at once: a list with one uint8 symbol array per read (see iter_recording)"""
-    return list(iter_recording(source, sample_rate, chunk, freq_offset, rows_per_batch, device))
+def demodulate_recording(source, sample_rate=2.4e6, chunk=256 * 1024, freq_offset=0.0, rows_per_batch=64, device=0, pre_shifts=None):
+    """the whole recording at once: a list with one uint8 symbol array (or, with pre_shifts, one list of them) per read (see
+    iter_recording)"""
+    return list(iter_recording(source, sample_rate, chunk, freq_offset, rows_per_batch, device, pre_shifts))
