@@ -109,8 +109,7 @@ TDM_API int tdm_last_error(char *buf, size_t buflen);
  *   "gardner_segments" what tdm_plan_option "gardner_segments" sets per plan, for TDM_MODE_TETRA_GARDNER plans created from
  *                     now on: 0 whole chunks, 1 the default, K > 1 at most K pieces, -1 fitted to the batch   (default 1)
  *   "pfb_direct"      1: channeliser plans created from now on use the direct-DFT kernel                     (default 0)
- *   "pfb_rounds"      > 0: rounds per channeliser workgroup, for plans created from now on                  (default 0: computed)
- *   "pfb_halftile"    1: half-tile channeliser kernel for 8-bit formats, plans created from now on          (default 0) */
+ *   "pfb_rounds"      > 0: rounds per channeliser workgroup, for plans created from now on                  (default 0: computed) */
 TDM_API int tdm_debug_set(const char *key, int64_t value);
 TDM_API int tdm_debug_get(const char *key, int64_t *value);
 

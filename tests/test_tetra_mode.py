@@ -320,38 +320,6 @@ def test_gpu_channeliser_direct_kernel_agrees():
 
 
 @pytest.mark.gpu
-def test_gpu_channeliser_half_tile_kernel_agrees():
-    """k_pfb_h2 (round-4 experiment, opt-in by tdm_debug_set("pfb_halftile", 1): fp16 window, branch sums fused with a radix-2 split of
-    pass 1, half the exchange tile, two workgroups per compute unit -- measured slower, kept off) against the full-tile
-    kernel and the fp64 definition, 8-bit wire formats, lengths that end inside a round and inside a workgroup's rounds"""
-    from oracle import pfb_np
-    from tetraear_amd._lib import debug_option
-    from tetraear_amd.channeliser import channelise
-    M, D, fs = 400, 125, 10e6
-    for n, fmt in ((7000, "cu8"), (125 * 32 * 7 + 61, "cu8"), (40000, "cs8")):
-        x, _ = _wideband(n, fs, [1, M // 3, M - 2], M, seed0=900)
-        x = x / (4.0 * np.max(np.abs(x)))
-        if fmt == "cu8":
-            raw = synth.quantise_cu8(x, scale=1.0)
-            xq = synth.cu8_to_c128(raw)
-        else:
-            raw = np.empty(2 * n, dtype=np.int8)
-            raw[0::2] = np.clip(np.rint(128 * x.real), -128, 127)
-            raw[1::2] = np.clip(np.rint(128 * x.imag), -128, 127)
-            xq = (raw[0::2].astype(np.float64) + 1j * raw[1::2].astype(np.float64)) / 128.0
-        y_full = channelise(raw, fmt, M, D)
-        with debug_option("pfb_halftile", 1):
-            y_half = channelise(raw, fmt, M, D)
-        probe = [0, 1, M // 3, M // 2 + 3, M - 2, M - 1]
-        ref = pfb_np.channelise(xq, M, D, channels=probe)
-        scale = np.max(np.abs(ref))
-        assert y_half.shape == y_full.shape
-        assert np.max(np.abs(y_half - y_full)) < 2e-6 * scale, (n, fmt)
-        for i, k in enumerate(probe):
-            assert np.max(np.abs(y_half[k] - ref[i])) < 2e-5 * scale, (n, fmt, k)
-
-
-@pytest.mark.gpu
 def test_gpu_wideband_to_symbols():
     """2.4 MS/s wideband -> 96-channel filter bank (75 kS/s per channel) -> TETRA-mode demodulation;
     every occupied channel must give back the transmitted dibits."""

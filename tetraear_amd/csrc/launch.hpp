@@ -21,11 +21,5 @@ void launch_pz_raw(const ZpParams &P, const void *iq, int64_t stride, int b_tail
 template <class Src>
 void launch_lp2(const Lp2Params &P, const Src &src, int rows, hipStream_t st);
 
-#ifdef TDM_ZP_TIMING
-void zp_timing_dump();
-#endif
-#ifdef TDM_LP2_TIMING
-void lp2_timing_dump();
-#endif
 
 }  // namespace tdm

@@ -23,21 +23,6 @@
 #include "lp2_tables.hpp"
 #include "pz_kernels.hpp"
 
-// TDM_LP2_TIMING builds: s_memtime per phase (thread 0 of every 16th workgroup) summed into g_lp2_dbg
-#if defined(TDM_LP2_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-extern __device__ unsigned long long g_lp2_dbg[16];
-#define LP2_T(i)                                                          \
-    do {                                                                  \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
-        if (cm.tid() == 0 && (chunk & 3) == 1) atomicAdd(&g_lp2_dbg[i], t_ - lp2_tprev_); \
-        lp2_tprev_ = t_;                                                  \
-    } while (0)
-#define LP2_T0() unsigned long long lp2_tprev_ = __builtin_amdgcn_s_memtime()
-#else
-#define LP2_T(i)
-#define LP2_T0()
-#endif
-
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TDM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -51,10 +36,8 @@ namespace tdm {
 // neighbouring lanes hit sixteen different 16-byte bank groups) and the coalesced one (slot = base + lane with base a
 // multiple of 16: XOR with a constant).  (One pad slot per 32 -- the cascade engine's layout, made for 8-sample lanes --
 // left this kernel's 16-sample lanes with two-way conflicts: 37 % of its LDS cycles.)
-// (8-sample lanes, -DTDM_LP2_LA=8: slot = 8 lane + i; the lane's low bit already selects the upper or lower eight bank
-// groups, lane bits 1..3 = slot bits 4..6 are XORed into i)
 TDM_HD int lp2_slot(int s) { return s ^ ((s >> 4) & (kLp2La - 1)); }
-static_assert(kLp2La == 16 || kLp2La == 8, "lp2_slot swizzles inside a lane's run of slots");
+static_assert(kLp2La == 16, "lp2_slot swizzles inside a lane's run of sixteen slots");
 static_assert(kLp2Lanes <= (1 << kLp2GBits), "item word layout");
 
 struct Lp2Lds {
@@ -85,8 +68,6 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     ZpParams dec;
     const double *freq_offset;   // per row or null
     double fs_out;
-    int inline_carry;            // 1: the items form the block carries themselves from the decimator's block-local end
-                                 //    states (pz_carry_compute): no carry launch between the decimator and this kernel
     static constexpr bool kFix = true;
     TDM_HD double foff(int row) const { return freq_offset ? freq_offset[row] : 0.0; }
     TDM_HD const f64x2 *raw_row(int row) const { return (const f64x2 *)(dec.y0 + (int64_t)row * dec.n_out * 2); }
@@ -113,17 +94,9 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
         const f64x2 *sd = (const f64x2 *)(P.seeds + ((size_t)(last ? P.seed_groups : 0) + t) * kLp2SeedDoubles) + (dir ? 2 * ND : 0);   // (rows 16t, 16t+1 or 16t+14, 16t+15)
 #pragma unroll
         for (int k = 0; k < 2 * ND; ++k) sdv[k] = sd[k];
-        if (kLp2InlineCarry && inline_carry) {   // (compiled out unless -DTDM_LP2_INLINE_CARRY: see lp2_tables.hpp)
-            double c0[D], c1[D];
-            pz_carry_compute<ND, false>(dec, row, b, 0, dir, c0);
-            pz_carry_compute<ND, false>(dec, row, b, 1, dir, c1);
+        const f64x2 *cy = (const f64x2 *)((dir ? dec.Hb : dec.Gf) + ((int64_t)row * dec.nb + b) * D * 2);
 #pragma unroll
-            for (int k = 0; k < D; ++k) cyv[k] = f64x2{c0[k], c1[k]};
-        } else {
-            const f64x2 *cy = (const f64x2 *)((dir ? dec.Hb : dec.Gf) + ((int64_t)row * dec.nb + b) * D * 2);
-#pragma unroll
-            for (int k = 0; k < 2 * ND; ++k) cyv[k] = cy[k];
-        }
+        for (int k = 0; k < 2 * ND; ++k) cyv[k] = cy[k];
     }
     // Two steps around the issue of the sample loads: the item's two words first (unconditional: a chunk's list is padded
     // to one item per thread), so that they are the OLDEST loads in flight when the samples' sixteen follow; then, once
@@ -140,7 +113,7 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
     }
     TDM_HD void prefetch_operands(const Lp2Params &P, int row, Pref &o) const
     {
-        if (!kLp2Lean && o.mine) item_operands(P, row, o.w0, o.w1, o.sd, o.cy);   // (lean build: requested where they are used)
+        if (o.mine) item_operands(P, row, o.w0, o.w1, o.sd, o.cy);
     }
     // The decimator's carry responses (y = y0 + T1.Gf + T2.Hb), added to the staged samples in place.  For the La
     // consecutive outputs of a group they are, per pole pair and direction, a second-order recurrence at the decimated
@@ -208,15 +181,7 @@ struct Lp2SrcDec {     // block-local output of the parallel-form decimator + ca
         constexpr int ND = PzLayout::kMaxPairs;
         const int32_t *it = P.items + (size_t)chunk * P.items_stride;
         const int cnt1 = it[0], cnt2 = it[1];
-        if (kLp2Lean) {
-            if (pf.mine) {
-                f64x2 sdv[2 * ND], cyv[2 * ND];
-                item_operands(P, row, pf.w0, pf.w1, sdv, cyv);
-                run_item(P, stage, pf.w0, sdv, cyv);
-            }
-        } else if (pf.mine) {
-            run_item(P, stage, pf.w0, pf.sd, pf.cy);   // (operands requested while the samples were staged)
-        }
+        if (pf.mine) run_item(P, stage, pf.w0, pf.sd, pf.cy);   // (operands requested while the samples were staged)
 #pragma unroll 1
         for (int k = cm.tid() + kLp2Lanes; k < cnt1; k += kLp2Lanes) {
             f64x2 sdv[2 * ND], cyv[2 * ND];
@@ -267,11 +232,7 @@ TDM_HD void lp2_issue_samples(const Lp2Params &P, const Src &src, Comm &cm, int 
     for (int i = 0; i < La; ++i) {
         const int j = jw32 + i * kWave;
         const int jj = j < 0 ? 0 : (j >= n32 ? n32 - 1 : j);
-#ifdef TDM_LP2_FAKE_LOADS   // experiment: every load hits the same cache-resident kilobytes (results are wrong, timing only)
-        L.v[i] = src.raw_row(0)[jj & 1023];
-#else
         L.v[i] = rowp[jj];
-#endif
     }
     if (Src::kFix) src.prefetch_operands(P, row, L.pref);
 }
@@ -294,7 +255,6 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     // chunks that hold an end of the row: odd extension and start states (workgroup-uniform)
     const bool wg_edge = (jc < 0) || (jc + (int64_t)kLp2Span > n);
     typename Src::Pref &pref = L.pref;
-    LP2_T0();
     {
         const int64_t jw = jc + (int64_t)wave * (kWave * La);
         const int jw32 = (int)jw + lane, n32 = (int)n;
@@ -312,13 +272,7 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
         }
     }
     cm.sync();
-    LP2_T(0);
-#ifdef TDM_LP2_MEMONLY   // experiment: loads, staging and stores only (results are wrong, timing only)
-    if (false)
-#else
-    if (Src::kFix)
-#endif
-    {
+    if (Src::kFix) {
         src.fix_phase(P, row, chunk, stage, cm, pref);
         cm.sync();
     }
@@ -332,13 +286,9 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     // lanes that hold signal samples: NCO (for a lane that is only partly inside the row the values at positions outside
     // it are meaningless here and are replaced by the odd extension below; lanes outside the row hold zeros)
     const bool inside = (js >= 0 && js + La <= n);
-#ifdef TDM_LP2_MEMONLY
-    if (false) {
-#else
     if (any_sig && Src::kFix) {
-#endif
         const double f = src.foff(row);
-        if (f != 0.0 && kLp2FastNco) {
+        if (f != 0.0) {
             // the lane's first phasor from the workgroup's tables (lp2_body): anchor x W^(64 La wave) x W^(La lane), then one
             // complex multiplication by W per sample
             const double *t = nco_w;
@@ -356,20 +306,8 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
                 c = nc;
                 sn = ns;
             }
-        } else if (f != 0.0) {
-            NcoRunT<1> nco;
-            nco.init_with(js, f, src.fs_out, nco_w[0], nco_w[1]);
-#pragma unroll
-            for (int i = 0; i < La; ++i) {
-                double c = nco.ar, sn = nco.ai;
-                if (i > 0) nco.next(f, src.fs_out, c, sn);
-                const double a = yr[i], b = yi[i];
-                yr[i] = a * c - b * sn;
-                yi[i] = a * sn + b * c;
-            }
         }
     }
-    LP2_T(1);
     auto Y = [&](int64_t j) { return stage[lp2_slot((int)(j - jc))]; };
     // the empty lanes next to the ends of the extended row carry the start states of the two banks (lp2_tables.hpp)
     const int64_t t_head = ((-(int64_t)edge - jc) >= 0 ? (-(int64_t)edge - jc) / La : -((jc + edge + La - 1) / La)) - 1;   // empty lane before position -edge
@@ -378,12 +316,6 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     const bool has_head = wg_edge && (t_head >= 0 && t_head < kLp2Lanes);
     const bool has_tail = wg_edge && (n + edge - 1 - jc >= 0 && t_tail < kLp2Lanes && t_l1 >= 0);
     double e0r = 0, e0i = 0, xlr = 0, xli = 0;
-    if (kLp2Lean && !wg_edge) {
-        // (lean build: the rotated samples go back to the lane's own slots and are read again for pass 2, so that they do
-        // not sit in registers across the scans)
-#pragma unroll
-        for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{yr[i], yi[i]};
-    }
     if (wg_edge) {
     // a chunk that holds an end of the row: publish the finished samples; the odd extension (scipy odd_ext: 2 x[0] - x[-j],
     // 2 x[n-1] - x[2n-2-j]) of the lanes around the end reads them from there.  (Interior chunks -- six of the eight of a
@@ -409,10 +341,6 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
             }
         }
     }
-    if (kLp2Lean && !inside) {   // (only positions outside the row changed: nobody reads those slots through Y())
-#pragma unroll
-        for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{yr[i], yi[i]};
-    }
     if (has_head && tid == t_head) {
         const f64x2 a = Y(0), b = Y(edge);
         e0r = 2 * a.x - b.x;
@@ -425,14 +353,7 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
     }
     }   // wg_edge
 
-#ifdef TDM_LP2_MEMONLY
-    double or_[La], oi[La];
-#pragma unroll
-    for (int i = 0; i < La; ++i) { or_[i] = yr[i]; oi[i] = yi[i]; }
-    (void)e0r; (void)e0i; (void)xlr; (void)xli; (void)has_head; (void)lane;
-#else
-    // C^(La (k+1)), k = lane's distance to the previous / next row of 16 lanes: what the scans' last step multiplies with.
-    // kLp2Lean (eight-sample lanes, 128 registers): requested inside each direction's scan, not here
+    // C^(La (k+1)), k = lane's distance to the previous / next row of 16 lanes: what the scans' last step multiplies with
     double lmf[NP][4], lmb[NP][4];
     auto load_lm = [&](auto dir_c) __attribute__((always_inline)) {
         constexpr int dir = decltype(dir_c)::value;
@@ -445,10 +366,9 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
             lm[s][0] = a0.x; lm[s][1] = a0.y; lm[s][2] = a1.x; lm[s][3] = a1.y;
         }
     };
-    if (!kLp2Lean) {   // (requested here, used by the scans: the latency overlaps pass 1)
-        load_lm(std::integral_constant<int, 0>{});
-        load_lm(std::integral_constant<int, 1>{});
-    }
+    // (requested here, used by the scans: the latency overlaps pass 1)
+    load_lm(std::integral_constant<int, 0>{});
+    load_lm(std::integral_constant<int, 1>{});
     // ---------------- pass 1: recurrences from zero state, lane end states ----------------
     double zr[NP][2], zq[NP][2];   // causal end state (w[La-1], w[La-2]), re / im
     double ur[NP][2], uq[NP][2];   // anticausal end state (w'[0], w'[1])
@@ -475,7 +395,6 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
             zq[s][0] = hv[s * 2] * e0i; zq[s][1] = hv[s * 2 + 1] * e0i;
         }
     }
-    LP2_T(2);
     // ---------------- scans.  dir 0: causal (inclusive from the left); dir 1: anticausal (from the right) ----------------
     // Per direction: (1) four Kogge-Stone steps inside each row of 16 lanes (DPP row shifts), the row's total to LDS;
     // (2) after ONE barrier every lane forms the state that enters its row from the totals of the P.scan_rows rows before
@@ -513,14 +432,12 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
                 vq[s][1] = fma(M[2], jq[s][0], fma(M[3], jq[s][1], q1));
             }
         }
-        LP2_T(7 + 4 * dir);
         // the row's total: [dir][row of the workgroup][pair][4]
         if ((lane & 15) == (dir == 0 ? 15 : 0)) {
             double *o = small + Lp2Lds::oTot + ((dir * kRows + (tid >> 4)) * NP) * 4;
 #pragma unroll
             for (int s = 0; s < NP; ++s) { o[s * 4] = vr[s][0]; o[s * 4 + 1] = vr[s][1]; o[s * 4 + 2] = vq[s][0]; o[s * 4 + 3] = vq[s][1]; }
         }
-        LP2_T(8 + 4 * dir);
     };
     auto scan_apply = [&](auto dir_c) __attribute__((always_inline)) {
         constexpr int dir = decltype(dir_c)::value;
@@ -552,11 +469,6 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
                 pr[s][0] = a0; pr[s][1] = a1; pq[s][0] = b0; pq[s][1] = b1;
             }
         }
-        LP2_T(9 + 4 * dir);
-        if (kLp2Lean) {
-            TDM_SCHED_FENCE();
-            load_lm(dir_c);
-        }
         // every lane: true inclusive state = in-row value + C^(La (position in the row + 1)) * (state entering the row)
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
@@ -584,25 +496,14 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
             vr[s][0] = at_edge ? pr[s][0] : sr[s][0]; vr[s][1] = at_edge ? pr[s][1] : sr[s][1];
             vq[s][0] = at_edge ? pq[s][0] : sq[s][0]; vq[s][1] = at_edge ? pq[s][1] : sq[s][1];
         }
-        LP2_T(10 + 4 * dir);
     };
     using D0 = std::integral_constant<int, 0>;
     using D1 = std::integral_constant<int, 1>;
-    if (!has_tail && kLp2Lean) {
-        // (lean build: one direction start to end, then the other -- a barrier more, sixteen registers fewer)
-        scan_rows(D0{});
-        cm.sync();
-        scan_apply(D0{});
-        TDM_SCHED_FENCE();
-        scan_rows(D1{});
-        cm.sync();
-        scan_apply(D1{});
-    } else if (!has_tail) {
+    if (!has_tail) {
         scan_rows(D0{});
         TDM_SCHED_FENCE();   // (one direction after the other: interleaved, their temporaries overflow the register file)
         scan_rows(D1{});
         cm.sync();
-        LP2_T(15);
         scan_apply(D0{});
         TDM_SCHED_FENCE();
         scan_apply(D1{});
@@ -627,16 +528,7 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
         cm.sync();
         scan_apply(D1{});
     }
-    LP2_T(3);
     // ---------------- pass 2: recurrences from the true start states, outputs accumulated ----------------
-    if (kLp2Lean) {
-#pragma unroll
-        for (int i = 0; i < La; ++i) {
-            const f64x2 v = stage[lp2_slot(tid * La + i)];
-            yr[i] = v.x;
-            yi[i] = v.y;
-        }
-    }
     double or_[La], oi[La];
     {
         const double dx = P.dx;
@@ -661,19 +553,13 @@ TDM_HD void lp2_compute(const Lp2Params &P, const Src &src, Comm &cm, int chunk,
             a2r = a1r; a1r = vr_; a2q = a1q; a1q = vq_;
         }
     }
-#endif   // TDM_LP2_MEMONLY
-    LP2_T(4);
     // ---------------- output: through LDS; one thread per (timing phase, group) stores its phase's samples and sums their powers ----------------
     // (No barrier here: a lane writes the slots only it has read since the carry responses were added; the one place
     // where lanes read their neighbours' slots -- the odd extension in a chunk that holds an end of the row -- lies before
     // the scans' barrier.  Round 2 and the first half of round 3 had one, "all lanes have taken their input out".)
-#ifdef TDM_LP2_MEMONLY
-    cm.sync();
-#endif
 #pragma unroll
     for (int i = 0; i < La; ++i) stage[lp2_slot(tid * La + i)] = f64x2{or_[i], oi[i]};
     cm.sync();
-    LP2_T(5);
 }
 
 // the chunk's filter output from the staging area to memory, phase-major, with the chunk's power sums per timing phase;
@@ -709,11 +595,7 @@ TDM_HD void lp2_store(const Lp2Params &P, Comm &cm, int chunk, int row)
             f64x2 *po = zt + (int64_t)p2 * P.zt_k + (k0 + g2);
             for (; j < jhi; j += step, po += ngrp) {
                 const f64x2 v = stage[lp2_slot(j - jc32)];
-#ifdef TDM_LP2_ONEPHASE   // experiment: only one timing phase's samples are stored (results are wrong, timing only)
-                if (p2 == 3) *po = v;
-#else
                 *po = v;
-#endif
                 if (j < lim) acc += fma(v.x, v.x, v.y * v.y);
             }
             small[Lp2Lds::oPow + g2 * kMaxSps + p2] = acc;
@@ -743,13 +625,13 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
     // last wavefront (the one with the fewest items) forms it and leaves it in LDS for all lanes (round 2: every lane's
     // own sincos, 120 instructions in each of the four wavefronts)
     double *nco_w = cm.small() + Lp2Lds::oPow + 16;     // (the power partials' area is free until the output stage)
-    if (Src::kFix && kLp2FastNco) {
+    if (Src::kFix) {
         // frequency_shift(samples, freq_offset) at the low rate (processor.py:260-261) as the ideal phase ramp from ONE exactly
         // anchored sample per workgroup: exp(i theta_j) = A0 W^(j - jc), A0 = the reference's own exp(i theta_jc)
         // (nco_phasor: theta = fl(ci fl(j / fs))), W = exp(i ci / fs).  The reference's theta_j differs from the ramp by its
         // own rounding -- at most 1.5e-13 rad at 1.2 kHz x 0.11 s, the level of the filters' arithmetic noise (reproducing it
         // sample by sample, NcoRunT, cost 25 instructions per sample and a sincos per lane: 600 of this kernel's 2947
-        // instructions per lane; TDM_LP2_FAST_NCO=0 builds that).  Two wavefronts form the tables while the samples are on
+        // instructions per lane; rounds 1-4 did).  Two wavefronts form the tables while the samples are on
         // their way: [0,1] W, [2,3] A0, [4 + 2 w] W^(64 La w) per wavefront, [16 + 2 l] W^(La l) per lane.
         const int wave = cm.tid() >> 6, lane = cm.tid() & 63;
         const double f = src.foff(row);
@@ -769,13 +651,6 @@ TDM_HD void lp2_body(const Lp2Params &P, const Src &src, Comm &cm, int chunk, in
                 const phasor a = nco_phasor(jc, f, src.fs_out);
                 if (lane == 0) { nco_w[2] = a.c; nco_w[3] = a.s; }
             }
-        }
-    } else if (Src::kFix && (cm.tid() >> 6) == kLp2Waves - 1) {
-        const double f = src.foff(row);
-        if (f != 0.0) {
-            double wre, wim;
-            NcoRunT<1>::step_phasor(f, src.fs_out, wre, wim);
-            if ((cm.tid() & 63) == 0) { nco_w[0] = wre; nco_w[1] = wim; }
         }
     }
     lp2_compute(P, src, cm, chunk, row, L, nco_w);

@@ -12,49 +12,17 @@
 
 namespace tdm {
 
-// -DTDM_LP2_LA=8: eight-sample lanes in eight wavefronts (the same 4096-position span and 64 KB of staging, twice the
-// threads: 16 wavefronts per compute unit if the kernel fits 128 VGPRs).  Results equal (CPU lock-step emulation, the
-// bench batch's digest).  Measured on MI355X: round 3, 81 spilled VGPRs (288 B of scratch per lane): 0.658 ms against 0.331;
-// round 5 found what made it THAT slow -- not the doubled per-lane work (1.31x the instructions per sample) but the spills
-// themselves: ~0.5 MB of scratch traffic per chunk against 128 KB of samples, from a 75 MB scratch footprint that no cache
-// holds -- and trimmed them (kLp2Lean below: the rotated samples wait in LDS between the filter passes, per-lane scan
-// matrices and item operands requested where they are used, the two scan directions one after the other): 29 spills
-// 0.404 ms, 18 spills 0.365 ms, 4 spills 0.341 ms -- level with the sixteen-sample lanes' 0.330-0.334 ms: twice the
-// wavefronts per compute unit buy exactly the 1.31x instructions per sample that the shorter lanes cost (scans, NCO
-// anchor and item operands are per lane).  Kept as a build switch, off.
-#ifndef TDM_LP2_LA
-#define TDM_LP2_LA 16
-#endif
-constexpr int kLp2La = TDM_LP2_LA;            // samples per lane (16; 8: see above)
-#ifndef TDM_LP2_WAVES
-#define TDM_LP2_WAVES (64 / TDM_LP2_LA)
-#endif
-constexpr int kLp2Waves = TDM_LP2_WAVES;      // wavefronts per workgroup: the span is 4096 positions = 64 KB of staging (8 with 16-sample lanes: 8192, 128 KB)
+// A lane owns 16 consecutive low-rate samples, a workgroup of 4 wavefronts a span of 4096 positions (64 KB of staging).
+// (Measured alternatives, all slower or level and no longer in the source -- docs/HISTORY.md, profiles/r05_ab/: eight-sample
+// lanes in eight wavefronts, 0.341 ms against 0.330-0.334 once their spills were trimmed; eight wavefronts on a span of 8192
+// positions, 0.336 against 0.305; the carry-response items forming the decimator's block carries themselves instead of a
+// carry launch, 0.481 against 0.361 + 0.015; the first dispatch round's workgroups started staggered: no change.)
+constexpr int kLp2La = 16;                    // samples per lane
+constexpr int kLp2Waves = 4;                  // wavefronts per workgroup
 constexpr int kLp2GBits = 9;                  // item word 0: group in the span (< 512) | direction << 9 | pair mask << 10
 constexpr int kLp2Lanes = kLp2Waves * kWave;
 constexpr int kLp2Span = kLp2Lanes * kLp2La;   // positions a workgroup covers (chunk + both halos)
-// -DTDM_LP2_INLINE_CARRY: the low-rate kernel's carry-response items form the decimator's block carries themselves
-// (pz_carry_compute) and the carry launch between the decimator and the low-rate kernel falls away.  Measured on MI355X:
-// the launch it saves is 0.015 ms, the low-rate kernel grows from 0.361 to 0.481 ms (92 spilled SGPRs, dependent loads
-// ahead of the staging) -- kept as a build switch, off.
-#ifdef TDM_LP2_INLINE_CARRY
-constexpr bool kLp2InlineCarry = true;
-#else
-constexpr bool kLp2InlineCarry = false;
-#endif
-// lean register use (eight-sample lanes: 128 registers per lane, four wavefronts per SIMD): the rotated samples wait in LDS
-// between the two filter passes and the scans' per-lane matrices are requested where they are used
-#ifndef TDM_LP2_LEAN
-#define TDM_LP2_LEAN (TDM_LP2_LA == 8)
-#endif
-constexpr bool kLp2Lean = TDM_LP2_LEAN;
-// the low-rate frequency shift as the ideal phase ramp from one exactly anchored sample per workgroup (lp2_kernels.hpp
-// lp2_body); 0: the reference's rounding of theta reproduced sample by sample (rounds 1-4)
-#ifndef TDM_LP2_FAST_NCO
-#define TDM_LP2_FAST_NCO 1
-#endif
-constexpr bool kLp2FastNco = TDM_LP2_FAST_NCO != 0;
-static_assert(!kLp2FastNco || TDM_LP2_WAVES >= 2, "two wavefronts form the NCO's tables");
+static_assert(kLp2Waves >= 2 && 4 + 2 * kLp2Waves <= 16, "two wavefronts form the NCO's tables; the per-wavefront entries end where the per-lane ones start (lp2_body)");
 constexpr int kLp2Pairs = 2;
 constexpr int kLp2D = 2 * kLp2Pairs;
 // what a chunk may ignore of its neighbours: the states are O(10) per unit input, so the neglected part is below 1e-20 of

@@ -37,16 +37,7 @@ struct PfbParams {
     unsigned long long *dbg;  // TDM_PFB_TIMING builds: per-phase cycle sums
 };
 
-#ifdef TDM_PFB_TIMING
-#define PFB_T(i)                                                                         \
-    do {                                                                                 \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
-        if (threadIdx.x == 0) atomicAdd(&Q.dbg[i], t_ - tprev_);                         \
-        tprev_ = t_;                                                                     \
-    } while (0)
-#else
 #define PFB_T(i)
-#endif
 
 __device__ __forceinline__ float2 pfb_load(const void *iq, int fmt, int64_t n)
 {
@@ -221,29 +212,6 @@ struct PfbUnit {   // cu8 (FMT 0) / cs8 (FMT 1): 8 bytes
         if (FMT == 0) return cv((float)(h & 255u), (float)((h >> 8) & 255u)) * (1.f / 127.5f) - cv(1.f, 1.f);
         return cv((float)(int8_t)(h & 255u), (float)(int8_t)((h >> 8) & 255u)) * (1.f / 128.f);
     }
-    // the four samples as (re, im) pairs of fp16, OFFSET and UNSCALED: cu8 -> u - 127.5 (a half-integer below 128: exact in
-    // fp16), cs8 -> the integer itself; the wire format's scale (1/127.5, 1/128) rides on the filter taps (k_pfb_h2)
-    __device__ __forceinline__ static uint32_t conv16(uint32_t h)
-    {
-        float a, b;
-        if (FMT == 0) {
-            a = (float)(h & 255u) - 127.5f;
-            b = (float)((h >> 8) & 255u) - 127.5f;
-        } else {
-            a = (float)(int8_t)(h & 255u);
-            b = (float)(int8_t)((h >> 8) & 255u);
-        }
-        return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
-    }
-    __device__ __forceinline__ void store16(uint32_t *dst) const
-    {
-        uint4 w;
-        w.x = (ok & 1u) ? conv16(v.x) : 0u;
-        w.y = (ok & 2u) ? conv16(v.x >> 16) : 0u;
-        w.z = (ok & 4u) ? conv16(v.y) : 0u;
-        w.w = (ok & 8u) ? conv16(v.y >> 16) : 0u;
-        *(uint4 *)dst = w;
-    }
     __device__ __forceinline__ void store(cf32v *dst) const
     {
         cf32v s0 = conv(v.x), s1 = conv(v.x >> 16), s2 = conv(v.y), s3 = conv(v.y >> 16);
@@ -339,11 +307,7 @@ __device__ __forceinline__ void pfb_pass2(const cf32v *A, cf32v *out, int64_t ou
         const int64_t step = (int64_t)M1 * out_stride;
 #pragma unroll
         for (int k2 = 0; k2 < M2; ++k2) {
-#ifdef TDM_PFB_NOSTORE   // experiment: the transforms without their stores (one store that never happens keeps them alive)
-            if (a[k2].x == 123456.789f) __builtin_nontemporal_store(a[k2], po);
-#else
             __builtin_nontemporal_store(a[k2], po);
-#endif
             po += step;
         }
     }
@@ -394,9 +358,6 @@ __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb
         const int64_t m0 = (round0 + g) * TB;
         if (m0 >= Q.n_out) break;
         const int64_t nbase = m0 * D - (L - 1);
-#ifdef TDM_PFB_TIMING
-        unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
-#endif
         if (g == 0) {
 #pragma unroll
             for (int k = 0; k < NPF; ++k)
@@ -442,173 +403,8 @@ __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb
     }
 }
 
-// ---- half-tile variant for 8-bit wire formats (round 4): TWO workgroups per compute unit ---------------------------------
-// k_pfb_fft keeps a round's whole exchange tile (TB output times x M values x 8 bytes: 103 KB at M = 400) beside a
-// 41 KB window of converted samples: one 146 KB workgroup per compute unit, whose three phases -- branch sums, pass 1,
-// pass 2 and its stores -- run one after the other with nothing to overlap them (vector issue ~35 %, LDS ~35 %, HBM ~50 %
-// busy).  This kernel halves both:
-//   * the window stays in fp16 pairs (4 bytes per sample; the 8-bit samples are exact there, the format's scale is folded
-//     into the taps, which live in LDS too because a thread's branches change with the output time);
-//   * stage A and pass 1 are fused in registers -- thread (output time, n2) forms its column's M1 branch sums itself -- and
-//     pass 1 is split by the parity of k1 (radix-2 decimation in frequency: the even outputs are the M1/2-point transform of
-//     u[n] + u[n + M1/2], the odd ones of (u[n] - u[n + M1/2]) w^n), so the exchange tile holds HALF the rows at a time,
-//     still for all TB output times: pass 2 keeps its TB x 8-byte = 256-byte runs per channel row.
-// 80 KB of LDS and TB*M2/2 threads: two workgroups share a compute unit, one's transforms and stores run beside the
-// other's branch sums.
-template <int M1, int M2, int P, int TB>
-constexpr size_t pfb_h2_lds_bytes(int D)
-{
-    const size_t nu = ((size_t)(TB - 1) * D + (size_t)M1 * M2 * P + 3) / 4;
-    return (4 * nu + (size_t)M1 * M2 * P) * 4 + ((size_t)M1 * M2 + (size_t)TB * (((M1 / 2) * M2) | 1)) * 8;
-}
-
-template <int M1, int M2, int P, int TB, int FMT>
-__global__ __launch_bounds__(TB *M2 / 2, pfb_waves_per_simd(TB *M2 / 2, 2)) void k_pfb_h2(
-    const void *__restrict__ iq_, cf32v *__restrict__ out_, int64_t out_stride, const PfbParams Q)
-{
-    static_assert(M1 == M2 && M1 % 2 == 0 && TB % 2 == 0, "pass 2 of one half uses all TB*M1/2 threads");
-    static_assert(FMT == 0 || FMT == 1, "8-bit wire formats");
-    constexpr int M = M1 * M2, L = M * P, NT = TB * M2 / 2, H1 = M1 / 2, FSH = (H1 * M2) | 1;
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    extern __shared__ uint32_t smem_u[];
-    const int D = Q.D;
-    const int nxs = (TB - 1) * D + L;
-    const int nu = (nxs + 3) >> 2;
-    const int dmod = D % M;
-    uint32_t *xs = smem_u;                      // [4 nu] (re, im) as fp16 pairs
-    float *hs = (float *)(xs + 4 * nu);         // [L] taps times the wire format's scale
-    cf32v *wml = (cf32v *)(hs + L);             // [M1][M2] middle twiddles
-    cf32v *A = wml + M;                         // [TB][FSH]: row kh (k1 = 2 kh + parity) of an output time at kh*M2
-    const char *iq = (const char *)iq_ + (int64_t)blockIdx.y * Q.in_stride;
-    cf32v *out = out_ + (int64_t)blockIdx.y * Q.out_batch;
-    const int tid = threadIdx.x;
-    {
-        const float scale = FMT == 0 ? (float)(1.0 / 127.5) : (float)(1.0 / 128.0);
-        for (int i = tid; i < L; i += NT) hs[i] = Q.h[i] * scale;
-        for (int i = tid; i < M; i += NT) {
-            const float2 w = Q.WM[i];
-            wml[i] = cv(w.x, w.y);
-        }
-    }
-    const int64_t round0 = (int64_t)blockIdx.x * Q.G;
-    // a round's window: wire bytes -> fp16 pairs -> LDS, four samples per turn.  No register prefetch of the next round's
-    // window (k_pfb_fft's): the co-resident workgroup fills this one's wait
-    auto land = [&](int64_t nb_) {
-        constexpr int NL = 4;   // units in flight per thread (all of a 10 MS/s window's)
-#pragma unroll 1
-        for (int u0 = tid; u0 < nu; u0 += NL * NT) {
-            PfbUnit<FMT> t[NL];
-#pragma unroll
-            for (int k = 0; k < NL; ++k)
-                if (u0 + k * NT < nu) t[k].load(iq, nb_ + 4 * (int64_t)(u0 + k * NT), Q.n_in);
-#pragma unroll
-            for (int k = 0; k < NL; ++k)
-                if (u0 + k * NT < nu) t[k].store16(xs + 4 * (u0 + k * NT));
-        }
-    };
-    for (int g = 0; g < Q.G; ++g) {
-        const int64_t m0 = (round0 + g) * TB;
-        if (m0 >= Q.n_out) break;
-        const int64_t nbase = m0 * D - (L - 1);
-        // (the thread's roles, derived afresh every round from an opaque copy of its index: nothing that depends on them is
-        // hoisted out of the round loop into registers that then spill)
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        const int mi0 = tv / M2, n2 = tv - mi0 * M2;   // fused stage: output times mi0 and mi0 + TB/2, column n2
-        const int khb = tv / TB, mib = tv - khb * TB;  // pass 2: row khb of the half, output time mib
-#ifdef TDM_PFB_TIMING
-        unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
-#endif
-        if (g == 0) land(nbase);
-        PFB_T(0);
-        __syncthreads();   // window (and, first round, taps and twiddles) in LDS; the tile is free
-        PFB_T(1);
-        const bool more = g + 1 < Q.G && m0 + TB < Q.n_out;
-        // ---- branch sums of the thread's two columns, first butterfly, even half of pass 1
-        const int s0 = (int)((m0 * (int64_t)D) % M);
-        // (one column at a time, its branch sums formed in the pairs the butterfly takes: 2 x M1/2 values live, not 2 x M1)
-        auto column = [&](int mi, cf32v (&od)[H1]) __attribute__((always_inline)) {
-            int n2v = n2;
-            asm volatile("" : "+v"(n2v));   // (keeps the per-branch index arithmetic inside the round instead of hoisted into spilled registers)
-            const int s = (int)(((uint32_t)s0 + (uint32_t)mi * (uint32_t)dmod) % (uint32_t)M) + n2v;
-            const uint32_t *px = xs + mi * D + (L - 1);
-            auto branch = [&](int n1) __attribute__((always_inline)) {
-                int rr = M2 * n1 + s;   // the branch that lands at position M2 n1 + n2 of this output time
-                rr -= rr >= M ? M : 0;
-                float ax = 0.f, ay = 0.f;
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const h2v w = __builtin_bit_cast(h2v, px[-rr - p * M]);
-                    const float hv = hs[rr + p * M];
-                    const uint32_t wu = __builtin_bit_cast(uint32_t, w);
-                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(ax) : "v"(wu), "v"(hv));
-                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ay) : "v"(wu), "v"(hv));
-                }
-                return cv(ax, ay);
-            };
-            cf32v e[H1];
-            dftc::static_for<0, H1>([&](auto nn) {
-                constexpr int n = decltype(nn)::value;
-                const cf32v ua = branch(n), ub = branch(n + H1);
-                e[n] = ua + ub;
-                od[n] = mul_tw<M1, n>(ua - ub);
-                if constexpr (n % 2 == 1) __builtin_amdgcn_sched_barrier(0);   // (four branches' loads in flight, not forty)
-            });
-            SmallDft<H1>::run(e);
-            cf32v *col = A + mi * FSH + n2;
-#pragma unroll
-            for (int k = 0; k < H1; ++k) col[k * M2] = cmulv(e[k], wml[(2 * k) * M2 + n2]);
-        };
-        cf32v od0[H1], od1[H1];
-        column(mi0, od0);
-        __builtin_amdgcn_sched_barrier(0);
-        column(mi0 + TB / 2, od1);
-        PFB_T(2);
-        __syncthreads();   // even rows in the tile; nobody reads the window any more
-        PFB_T(3);
-        // the next round's window lands in LDS BEFORE this round's stores are issued (loads and stores share vmcnt)
-        if (more) land(nbase + (int64_t)TB * D);
-        __builtin_amdgcn_sched_barrier(0);
-        auto pass2 = [&](int parity) {
-            cf32v a[M2];
-            const cf32v *row = A + mib * FSH + khb * M2;
-#pragma unroll
-            for (int j = 0; j < M2; ++j) a[j] = row[j];
-            SmallDft<M2>::run(a);
-            const int64_t m = m0 + mib;
-            if (m < Q.n_out) {
-                int khv = 2 * khb + parity;
-                asm volatile("" : "+v"(khv));   // (the twenty row pointers are formed here, not hoisted out of the round loop and spilled)
-                cf32v *po = out + (int64_t)khv * out_stride + m;
-                const int64_t step = (int64_t)M1 * out_stride;
-#pragma unroll
-                for (int k2 = 0; k2 < M2; ++k2) {
-                    __builtin_nontemporal_store(a[k2], po);
-                    po += step;
-                }
-            }
-        };
-        PFB_T(4);
-        __builtin_amdgcn_sched_barrier(0);
-        pass2(0);
-        __builtin_amdgcn_sched_barrier(0);
-        PFB_T(5);
-        __syncthreads();   // tile free
-        PFB_T(6);
-        auto odd_rows = [&](int mi, cf32v (&od)[H1]) __attribute__((always_inline)) {
-            SmallDft<H1>::run(od);
-            cf32v *col = A + mi * FSH + n2;
-#pragma unroll
-            for (int k = 0; k < H1; ++k) col[k * M2] = cmulv(od[k], wml[(2 * k + 1) * M2 + n2]);
-        };
-        odd_rows(mi0, od0);
-        odd_rows(mi0 + TB / 2, od1);
-        PFB_T(7);
-        __syncthreads();   // odd rows in the tile
-        PFB_T(8);
-        pass2(1);
-        PFB_T(9);
-    }
-}
+// (Round 4 also built a half-tile variant for the 8-bit formats -- fp16 window, branch sums fused with a radix-2 split of pass 1,
+// 80 KB of LDS, two workgroups per compute unit: correct, 0.335 ms against this kernel's 0.237 -- and round 5 one with 16 output
+// times per round: 0.340.  Both removed from the source in round 6; docs/HISTORY.md A.2, profiles/r04r_*.)
 
 }  // namespace tdm

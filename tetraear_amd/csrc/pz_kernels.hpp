@@ -26,9 +26,7 @@
 #endif
 // one sample step of all chains at a time: keeps the scheduler from hoisting the independent halves of later
 // steps (and their operands) far ahead, which costs more registers than the file has
-#ifndef TDM_STEP_FENCE
 #define TDM_STEP_FENCE() TDM_SCHED_FENCE()
-#endif
 // makes a value's computation happen here in program order (the instruction selector otherwise defers the output
 // accumulations to the end of the kernel and keeps their operands alive, which spills)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -525,7 +523,7 @@ TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 //   WIDE = true  : the first block and the block(s) holding the tail extension: samples as int16 pairs, because the odd
 //                  extension 2 u[0] - u[k] does not fit a byte; extension lanes are filled through a small LDS buffer
 // ------------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_OPAQUE)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define TDM_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #else
 #define TDM_OPAQUE_V(x)
@@ -550,7 +548,7 @@ TDM_HD void pz_raw_slot_init(double &x)
     TDM_OPAQUE_V(x);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_OPAQUE)
+#if defined(__HIP_DEVICE_COMPILE__)
 // byte BYTE of w into byte 1 of the slot's high dword (selector bytes: 7, 6 = the slot's own 0x40, 0xB0; BYTE; 0x0c = zero).
 // volatile: never merged with the other direction's conversion of the same byte, which would keep 240 converted values
 // alive across the loop
@@ -576,7 +574,7 @@ TDM_HD void pz_raw_cvt(const uint32_t *raw, int i, double &re, double &im)
         im = (double)((int32_t)w >> 16);
     } else {
         const uint32_t w = raw[i / 2];
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TDM_NO_OPAQUE)
+#if defined(__HIP_DEVICE_COMPILE__)
         if (OPAQUE) {
             if (FMT8 == FMT_CU8) {
                 if (i % 2 == 0) { pz_raw_perm<0>(re, w); pz_raw_perm<1>(im, w); }

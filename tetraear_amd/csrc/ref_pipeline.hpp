@@ -82,11 +82,9 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
     RawLoader<FMT, SHIFT> ld{io.iq, io.carrier_stride, io.pre_shift, h.sample_rate, io.rows_per_chunk};
     // (the raw-byte kernel addresses its rows itself: a plan whose rows share input rows stays on the loaders)
     const bool use_raw = h.raw_S > 0 && FMT == FMT_CU8 && !SHIFT && io.rows_per_chunk <= 1 && (int64_t)rows * h.dec.p.nb >= h.raw_min_blocks;
-    // (the one-kernel low-rate stage forms the block carries inside its carry-response items: no carry launch)
-    const bool inline_carry = h.lp2.ok && kLp2InlineCarry;
     if (use_raw) {
         run_pz_raw(be, h, B.dec_raw_params, io.iq, io.carrier_stride, rows);
-        if (!inline_carry) be.template zp_carry<2, 4>(B.dec_raw_params, h.dec_raw.p.nb, rows);
+        be.template zp_carry<2, 4>(B.dec_raw_params, h.dec_raw.p.nb, rows);
     } else if (h.decimated) {
         // scipy.signal.decimate(samples, q)  (processor.py:254): block-local part + carries
         if (h.pz_S) {
@@ -95,7 +93,7 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         } else {
             be.template zp_block<2, 4, kLDec, kEdgeSos>(B.dec_params, ld, h.dec.p.nb, rows);
         }
-        if (!(inline_carry && h.pz_S)) be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
+        be.template zp_carry<2, 4>(B.dec_params, h.dec.p.nb, rows);
         if (!h.lpf)  // (n_dec <= 15) nothing downstream finishes the decimator output: do it here
             be.template zp_fixup<8, kLDec>(B.dec_params, h.dec.p.nb, rows, B.y, h.n_dec, io.freq_offset, h.rate_dec);
     } else {
@@ -125,10 +123,10 @@ void run_ref_fmt(BE &be, const RefPlanHost &h, int rows, const RefBuffers &B, co
         fa.zt = B.lp2.zt;
         fa.zt_k = B.lp2.zt_k;
         if (use_raw) {
-            Lp2SrcDec src{B.dec_raw_params, io.freq_offset, h.rate_dec, inline_carry ? 1 : 0};
+            Lp2SrcDec src{B.dec_raw_params, io.freq_offset, h.rate_dec};
             be.lp2_finish(L, src, fa, rows);
         } else if (h.decimated) {
-            Lp2SrcDec src{B.dec_params, io.freq_offset, h.rate_dec, (inline_carry && h.pz_S) ? 1 : 0};
+            Lp2SrcDec src{B.dec_params, io.freq_offset, h.rate_dec};
             be.lp2_finish(L, src, fa, rows);
         } else {
             Lp2SrcPlain src{B.y, h.n_dec};

@@ -11,13 +11,9 @@
 
 namespace tdm {
 
-#ifndef TDM_LDEC
 #define TDM_LDEC 32
-#endif
 constexpr int kLDec = TDM_LDEC;  // samples per lane, decimator stage (4 biquads)
-#ifndef TDM_LLPF
 #define TDM_LLPF 8
-#endif
 constexpr int kLLpf = TDM_LLPF;  // samples per lane, channel-filter stage (order 4 = 2 biquads; LDS-staged I/O)
 constexpr int kEdgeSos = 27;  // sosfiltfilt pad for 4 sections: 3*(2*4+1)
 constexpr int kEdgeTf = 15;   // filtfilt pad for order 4: 3*5

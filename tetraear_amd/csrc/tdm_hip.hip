@@ -51,7 +51,6 @@ static DebugSwitch g_debug[] = {
     {"gardner_fused", {1}, 1},           // 0: Gardner mode as three launches (matched filter -> HBM -> loop -> decisions)
     {"pfb_direct", {0}, 0},              // 1: channeliser plans made from now on use the direct-DFT kernel
     {"pfb_rounds", {0}, 0},              // > 0: rounds per channeliser workgroup (plans made from now on)
-    {"pfb_halftile", {0}, 0},
     {"gardner_segments", {1}, 1},        // tdm_plan_option "gardner_segments" for TDM_MODE_TETRA_GARDNER plans made from now on (0, 1, K, -1)
 };
 static DebugSwitch *debug_find(const char *key)
@@ -761,11 +760,7 @@ static void plan_free(tdm_plan *p)
 
 extern "C" {
 
-#ifdef TDM_EXPERIMENT
-int tdm_version(void) { return -TDM_VERSION; }   // a build with timing-only switches: never mistaken for the product
-#else
 int tdm_version(void) { return TDM_VERSION; }
-#endif
 
 int tdm_device_count(void)
 {
@@ -974,15 +969,6 @@ int tdm_gardner_geometry(double sample_rate, int64_t n_samples, int32_t pieces, 
 
 int tdm_plan_destroy(tdm_plan *plan)
 {
-#ifdef TDM_LP2_TIMING
-    lp2_timing_dump();
-#endif
-#ifdef TDM_TETRA_TIMING
-    if (plan && plan->mode == TDM_MODE_TETRA) tetra_timing_dump();
-#endif
-#ifdef TDM_ZP_TIMING
-    zp_timing_dump();
-#endif
     plan_free(plan);
     return TDM_OK;
 }
@@ -2126,8 +2112,7 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
     const bool force_direct = debug_value("pfb_direct") == 1;
     if (!force_direct && D <= 4 * M) {
         const int64_t rounds = (n_out + TB - 1) / TB;
-        // rounds per workgroup: `per_cu` workgroups per compute unit are resident (one of k_pfb_fft's 146 KB at M = 400, two of
-        // k_pfb_h2's 80 KB), so the launch runs in ceil(workgroups / slots) waves of G rounds each plus a start-up of about
+        // rounds per workgroup: `per_cu` workgroups per compute unit are resident (one of k_pfb_fft's 146 KB at M = 400), so the launch runs in ceil(workgroups / slots) waves of G rounds each plus a start-up of about
         // a third of a round per workgroup; the G that minimises that (32 streams x 263 rounds, one per CU: G = 3 -> 2816
         // workgroups = exactly 11 waves, 0.235 ms; round 2's G = 4 -> 8.25 waves, 0.244 ms)
         static int cu_count[64] = {0};   // (per device, asked once)
@@ -2148,40 +2133,6 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
             if (debug_value("pfb_rounds") > 0) G = (int)debug_value("pfb_rounds");   // experiments
             return G;
         };
-        if constexpr (M1 == M2 && M1 % 2 == 0 && TB % 2 == 0 && WGS == 1) {
-            // 8-bit wire formats, tdm_debug_set("pfb_halftile", 1): the half-tile kernel, two workgroups per compute unit (pfb_kernels.hpp:
-            // correct, measured slower than the full-tile kernel -- 0.335 against 0.237 ms per 32 x 1 Mi samples -- and off)
-            const size_t lds2 = pfb_h2_lds_bytes<M1, M2, P, TB>(D);
-            if ((fmt == TDM_CU8 || fmt == TDM_CS8) && lds2 <= 80 * 1024 && debug_value("pfb_halftile") == 1) {
-                void (*kern)(const void *, cf32v *, int64_t, const PfbParams) =
-                    fmt == TDM_CU8 ? k_pfb_h2<M1, M2, P, TB, 0> : k_pfb_h2<M1, M2, P, TB, 1>;
-                Q.G = pick_rounds(2);
-                HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                const unsigned blocks = (unsigned)((rounds + Q.G - 1) / Q.G);
-#ifdef TDM_PFB_TIMING
-                static unsigned long long *dbg2 = nullptr;
-                if (!dbg2) HIP_TRY(hipMalloc(&dbg2, 128));
-                HIP_TRY(hipMemset(dbg2, 0, 128));
-                Q.dbg = dbg2;
-#endif
-                hipLaunchKernelGGL(kern, dim3(blocks, n_streams), dim3(TB * M2 / 2), lds2, st, iq, (cf32v *)out, pitch, Q);
-                HIP_TRY(hipGetLastError());
-#ifdef TDM_PFB_TIMING
-                {
-                    unsigned long long hd[16];
-                    HIP_TRY(hipMemcpy(hd, dbg2, 128, hipMemcpyDeviceToHost));
-                    const double rt = (double)rounds * n_streams;
-                    int occ = -1;
-                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, TB * M2 / 2, lds2);
-                    fprintf(stderr, "pfb_h2: %d workgroups per CU by the occupancy query, %zu B of LDS each, G = %d, %u x %d workgroups\n", occ, lds2, Q.G, blocks, n_streams);
-                    fprintf(stderr, "pfb_h2 phases (memtime ticks/round, thread 0): land0 %.0f bar1 %.0f fused %.0f bar2 %.0f land %.0f pass2e %.0f bar3 %.0f odd %.0f bar4 %.0f pass2o %.0f\n",
-                            hd[0] / rt, hd[1] / rt, hd[2] / rt, hd[3] / rt, hd[4] / rt, hd[5] / rt, hd[6] / rt, hd[7] / rt, hd[8] / rt, hd[9] / rt);
-                }
-#endif
-                if (sync) HIP_TRY(hipStreamSynchronize(st));
-                return TDM_OK;
-            }
-        }
         Q.G = pick_rounds(1);
         const size_t lds = pfb_fft_lds<M1, M2, P, TB>(D) * sizeof(float2);
         if (lds <= 160 * 1024) {
@@ -2198,25 +2149,8 @@ int launch_pfb(int device, const void *iq, int fmt, int64_t n_in, int D, float2 
             }
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const unsigned blocks = (unsigned)((rounds + Q.G - 1) / Q.G);
-#ifdef TDM_PFB_TIMING
-            static unsigned long long *dbg = nullptr;
-            if (!dbg) HIP_TRY(hipMalloc(&dbg, 128));
-            HIP_TRY(hipMemset(dbg, 0, 128));
-            Q.dbg = dbg;
-#endif
             hipLaunchKernelGGL(kern, dim3(blocks, n_streams), dim3(threads), lds, st, iq, (cf32v *)out, pitch, Q);
             HIP_TRY(hipGetLastError());
-#ifdef TDM_PFB_TIMING
-            {
-                unsigned long long hdbg[16];
-                HIP_TRY(hipMemcpy(hdbg, dbg, 128, hipMemcpyDeviceToHost));
-                const double rounds_total = (double)rounds * n_streams;
-                fprintf(stderr, "pfb phases (memtime ticks/round): load %.0f bar %.0f A %.0f bar %.0f p1 %.0f bar %.0f p2: lds %.0f land %.0f fft+st %.0f\n",
-                        hdbg[0] / rounds_total, hdbg[1] / rounds_total, hdbg[2] / rounds_total, hdbg[3] / rounds_total,
-                        hdbg[4] / rounds_total, hdbg[5] / rounds_total, hdbg[7] / rounds_total, hdbg[8] / rounds_total,
-                        hdbg[6] / rounds_total);
-            }
-#endif
             if (sync) HIP_TRY(hipStreamSynchronize(st));
             return TDM_OK;
         }
@@ -2260,18 +2194,10 @@ int tdm_channelise_batch(const void *iq, int32_t in_fmt, int64_t n_in, int32_t n
     const bool sync = !device_pointers;
     switch (M) {
     // device pointers: enqueue on the default stream and return (tdm_dev_sync waits)
-#ifndef TDM_PFB96
 #define TDM_PFB96 16, 4
-#endif
-#ifndef TDM_PFB72
 #define TDM_PFB72 48, 2
-#endif
-#ifndef TDM_PFB128
 #define TDM_PFB128 16, 4
-#endif
-#ifndef TDM_PFB80
 #define TDM_PFB80 32, 3
-#endif
     case 96: rc = launch_pfb<8, 12, 3, TDM_PFB96>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, device_pointers ? g_cur_stream : nullptr, sync); break;
     case 72: rc = launch_pfb<8, 9, 3, TDM_PFB72>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, device_pointers ? g_cur_stream : nullptr, sync); break;
     case 80: rc = launch_pfb<8, 10, 3, TDM_PFB80>(device, src, in_fmt, n_in, D, dst, no, pitch, n_streams, device_pointers ? g_cur_stream : nullptr, sync); break;

@@ -6,20 +6,8 @@
 
 namespace tdm {
 
-#ifdef TDM_ZP_TIMING
-__device__ unsigned long long g_zp_dbg[16];
-void zp_timing_dump()
-{
-    unsigned long long h[16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_zp_dbg), sizeof(h)) != hipSuccess) return;
-    fprintf(stderr, "zp phases (memtime ticks, summed over waves): dec load %llu fwd %llu bwd %llu out %llu | lpf load %llu fwd %llu bwd %llu out %llu \n",
-            h[0], h[1], h[2], h[3], h[8], h[9], h[10], h[11]);
-}
-#endif
 
-#ifndef TDM_BLOCK_WAVES
 #define TDM_BLOCK_WAVES 2  // waves per SIMD the block kernel is register-budgeted for
-#endif
 template <int K, int NSEC, int L, int EDGE, class Loader>
 __global__ __launch_bounds__(64, (L <= 16 ? 4 : (L <= 24 ? 3 : TDM_BLOCK_WAVES))) void k_zp_block(const ZpParams P, const Loader ld)
 {

@@ -6,17 +6,6 @@
 
 namespace tdm {
 
-#ifdef TDM_TETRA_TIMING
-void tetra_timing_dump()
-{
-    unsigned long long h[16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tetra_dbg), sizeof(h)) != hipSuccess) return;
-    static const char *names[12] = {"loop top", "barrier 1", "rrc", "statistic", "ring store", "barrier 2", "stage+fetch", "estimates", "-", "symbol range", "farrow", "finish"};
-    unsigned long long tot = 0;
-    for (int i = 0; i < 12; ++i) tot += h[i];
-    for (int i = 0; i < 12; ++i) fprintf(stderr, "tetra phase %-12s %5.1f %%\n", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
-}
-#endif
 
 bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, uint8_t *hard,
                   int32_t *n_soft, int32_t *timing_milli, double *min_margin, hipStream_t stream, const int32_t *row_list,

@@ -46,9 +46,7 @@
 
 namespace tdm {
 
-#ifndef TDM_MF_TPW
 #define TDM_MF_TPW 1   // tiles a workgroup walks, the next one's window in flight (measured: 1 -> 0.371 ms, 2 -> 0.377, 4 -> 0.390, 8 -> 0.424)
-#endif
 constexpr int kMfThreads = 256, kMfPer = 8, kMfTile = kMfThreads * kMfPer, kMfTilesPerWg = TDM_MF_TPW;
 
 // The RRC stage on its own: y[n] = sum_t h[t] x[n + t - (NT-1)/2], zero outside the chunk (oracle/tetra_np.py
@@ -201,9 +199,7 @@ constexpr int kGProducers = 2;               // matched-filter wavefronts of the
 // SIMD's wavefront runs the loop depends on the parity of the workgroup's slot on its compute unit (HW_ID.TG_ID), so that the
 // two workgroups of a compute unit put their loops on DIFFERENT SIMDs (0 and 2) and their producers together on the other
 // two: a loop wavefront then has its SIMD to itself also when two workgroups share the unit
-#ifndef TDM_GARDNER_PLACE
 #define TDM_GARDNER_PLACE 1   // (measured: 4096 carriers 1.229 -> 1.204 ms, 8192 carriers 1.607 -> 1.418 ms)
-#endif
 constexpr int kGWaves = TDM_GARDNER_PLACE ? 4 : 1 + kGProducers;   // wavefronts a fused workgroup is launched with
 constexpr int kGQuota = 2;                   // chunks a producer makes between two hand-overs (a block of 16 symbols uses sps / 4)
 template <int NT> struct GardnerWindow {     // a producer's input window per carrier and chunk
@@ -265,7 +261,6 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
     const int lane = threadIdx.x & 63;
     if constexpr (FUSED) {
         for (int t = threadIdx.x; t < NT + 1; t += 64 * kGWaves) taps_s[t] = t < NT ? P.taps[t] : 0.f;
-#if TDM_GARDNER_PLACE
         // roles by SIMD (see kGWaves): 0 the loop, 1 and 2 the producers, 3 leaves
         __shared__ int sh_simd[4];
         const int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID, all 32 bits
@@ -277,10 +272,6 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
         const int rel = spread ? ((simd - 2 * slot) & 3) : widx;            // 0: the loop's SIMD, 2: the one that leaves
         const int wave = __builtin_amdgcn_readfirstlane(rel == 0 ? 0 : (rel == 1 ? 1 : (rel == 3 ? 2 : 3)));
         if (wave == 3) return;
-#else
-        __syncthreads();
-        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#endif
         if (wave > 0) {
             // ---- a producer: carriers 8 (wave - 1) .. + 7 of the workgroup; lane = (carrier j, group of eight outputs gI)
             typedef GardnerWindow<FUSED ? NT : 1> GW;

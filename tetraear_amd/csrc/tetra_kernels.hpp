@@ -120,16 +120,9 @@ __device__ __forceinline__ float atan2_turns(float y, float x)
 }
 
 // waves per SIMD the register allocation aims for (LDS holds four workgroups of 256 threads or two of 512)
-#ifndef TDM_TETRA_WAVES
 #define TDM_TETRA_WAVES(NT) 4
-#endif
 
-#ifdef TDM_TETRA_TIMING
-__device__ unsigned long long g_tetra_dbg[16];
-#define TT_MARK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tt[i] += t_ - tt_last; tt_last = t_; }
-#else
 #define TT_MARK(i)
-#endif
 
 // Split-bf16 arithmetic of the matched filter: a float is the sum of two bf16 (16 significant bits), a product of two
 // such sums keeps its three leading terms; the matrix cores multiply bf16 exactly and accumulate in fp32.
@@ -179,8 +172,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     __shared__ float tau_mid_s;
     __shared__ float sm[kRrcThreads / 64], sm2[kRrcThreads / 64];
     __shared__ float delta_s;
-    __shared__ float sc_s;        // power-of-two scale of the differential products (formed in the first round)
-    __shared__ int slow_s;        // a symbol took the direct path: the final passes run from the stored soft symbols
     // row_list (the wideband chain's occupancy gate, occupancy_kernels.hpp): workgroup i takes row row_list[i] of the batch
     // -- input row, output rows and all -- and the workgroups past the list's length leave at once
     int row = blockIdx.x;
@@ -232,13 +223,8 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // a loaded pair of consecutive samples (pair idx = staged samples 2 idx, 2 idx + 1) into the four planes
     auto put = [&](int idx, bool last_pair, float re0, float im0, float re1, float im1) __attribute__((always_inline)) {
         uint32_t w[4];
-#ifdef TDM_TETRA_NOSPLIT   // experiment: the input taken as if it arrived split already (results are wrong, timing only)
-        w[0] = __builtin_bit_cast(uint32_t, re0); w[1] = __builtin_bit_cast(uint32_t, im0);
-        w[2] = __builtin_bit_cast(uint32_t, re1); w[3] = __builtin_bit_cast(uint32_t, im1);
-#else
         split_bf16(re0, re1, w[0], w[1]);
         split_bf16(im0, im1, w[2], w[3]);
-#endif
         if (!last_pair || idx < NS / 2) {
 #pragma unroll
             for (int pl = 0; pl < 4; ++pl) xsb[pl * PLANE + idx] = w[pl];
@@ -333,25 +319,14 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(slo), "=s"(shi) : "v"(vlo), "v"(vhi));
         sps40 = ((uint64_t)shi << 32) | slo;
     }
-// TDM_TETRA_BYTECODE=1 (round-4 experiment, correct and OFF): differential products, 4th-power sums and provisional
-// decisions (dibit + 6-bit margin code, one byte per symbol) formed in the symbol stage, so that the final pass reads one
-// byte per symbol back instead of the 8-byte soft symbols (HBM traffic 1.24x -> 1.05x algorithmic).  Measured on MI355X,
-// 4096 x 32 768: 0.354 ms against 0.314 ms -- the ~30 vector instructions per symbol it adds to the tile loop (+15 % of the
-// loop's issue slots) cost more than the read-back it removes: the kernel is bound by instruction issue, and the final
-// passes' round trip to HBM is hidden by the other three workgroups of the compute unit.  (The soft symbols are read back
-// ONCE as it is: the products of up to 8192 symbols stay in registers between the estimate and the decisions.)
-#ifndef TDM_TETRA_BYTECODE
-#define TDM_TETRA_BYTECODE 0
-#endif
-    constexpr bool BC = TDM_TETRA_BYTECODE != 0;
+// (Round 4 also built this kernel with differential products, 4th-power sums and provisional one-byte decisions formed in the
+// symbol stage, so that the final pass read one byte per symbol back instead of the 8-byte soft symbols: traffic 1.24x -> 1.05x
+// algorithmic, 0.354 ms against 0.314 -- the ~30 vector instructions per symbol it added to the tile loop cost more than the
+// read-back it removed.  Removed from the source in round 6; docs/HISTORY.md A.2.)
     constexpr int NW = kRrcThreads / 64;
-    // Symbols per wavefront and turn of the symbol stage.  BC: 63 -- lane 0 of every wavefront forms the symbol BEFORE its
-    // wavefront's first one again (the last one of the wavefront to its left, of the previous turn or of the previous
-    // round), so that every lane finds the predecessor of its symbol in the lane to its left: the differential product
-    // needs no exchange through LDS and no barrier, at 1/64 more interpolations.
-    constexpr int WSYM = BC ? 63 : 64;
+    constexpr int WSYM = 64;                                     // symbols per wavefront and turn of the symbol stage
     constexpr int TSYM = WSYM * NW;                              // symbols per turn of the workgroup
-    const int off = WSYM * wv + lane;                            // BC: the thread's symbol is k = kb - 1 + off + TSYM u
+    const int off = WSYM * wv + lane;                            // the thread's symbol is k = kb + off + TSYM u
     uint64_t ptid = (uint64_t)(uint32_t)off * sps40;             // the thread's share of its symbols' nominal positions
     {
         // (opaque: otherwise the compiler folds it back into (k_uniform + tid) * sps40, a 64-bit vector multiply per symbol)
@@ -362,15 +337,9 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     float tau_prev = 0.f;   // (wave 0) last unwrapped estimate
     int b_done = 0;         // sub-blocks whose estimate is final
     int k_lo = 0, k_begin = 0, ns = 0;
-    // BC: running sums of d^4 = (p + 2 i q)^2 (p = Re d^2, q = Im d^2 / 2), smallest margin code, scale (see the symbol stage)
-    float a_pp = 0.f, a_qq = 0.f, a_pq = 0.f, sc = 1.f;
-    uint32_t qmin = 63u;
+    float a_pp = 0.f, a_qq = 0.f, a_pq = 0.f, sc = 1.f;   // running sums of d^4 and the products' power-of-two scale (final passes)
     uint8_t *const hr = hard + (int64_t)row * P.max_soft;
-    if (tid == 0) slow_s = 0;
 
-#ifdef TDM_TETRA_TIMING
-    unsigned long long tt[12] = {0}, tt_last = __builtin_readcyclecounter();
-#endif
     static_assert(kTimingHalfWin <= kTileBlocks, "the slots below sub-block 0 must be free during the first tile");
     if (tid < kCstRing) Cst[tid] = make_float2(0.f, 0.f);   // (made visible by the first barrier of the loop)
     fetch(0);
@@ -393,9 +362,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             cre[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
             cim[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-#ifndef TDM_TETRA_MFMA_REPS
 #define TDM_TETRA_MFMA_REPS 1   // (experiment hook: 0 / 2 / 3 price the matched filter's share of the kernel)
-#endif
 #pragma unroll
         for (int s_ = 0; s_ < KS * TDM_TETRA_MFMA_REPS; ++s_) {
             const int s = s_ % KS;
@@ -496,39 +463,16 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         // quarter of this work) while the other three stage the next tile; a third barrier hands the estimates over.
         // (Round 2 had every wavefront compute them, identically: no barrier, but ~75 vector instructions per wavefront and
         // tile, an eighth of the loop, spent three times over.)
-#ifndef TDM_TETRA_EST_ALL
         const bool est_duty = wv == (i & (kRrcThreads / 64 - 1));
-#else
-        const bool est_duty = true;
-#endif
         const int b_known = last ? nb - 1 : (i + 1) * kTileBlocks - 1 - kTimingHalfWin;
-#ifndef TDM_TETRA_EST_ALL
         if (!est_duty && !last) {
-#else
-        if (!last) {
-#endif
             stage(i + 1);
             if (i + 2 < ntiles) fetch(i + 2);
         }
         TT_MARK(6)
         if (est_duty) {
-#ifndef TDM_TETRA_EST_ALL
             if (b_done > 0) tau_prev = tau[(b_done - 1) & (kTauRing - 1)].x;   // (the last estimate of the previous duty wavefront)
-#endif
             const int lane = tid & 63;
-            if (BC && i == 0) {
-                // Scale of the differential products: their 4th power is the 8th power of the input's scale, so symbols enter
-                // the products times a power of two -- exact: estimate, decisions and margin are what they would be without it
-                // -- that brings the largest of 64 matched-filter outputs spread over the chunk's first 512 to [0.5, 1):
-                // inputs anywhere in fp32's range (int16-scaled IQ, 1e-6-scaled IQ) neither overflow nor flush to zero.
-                const float2 y = yring[rrc_slot(lane * min(8, n >> 6))];
-                float a = fmaxf(fabsf(y.x), fabsf(y.y));
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) a = fmaxf(a, __shfl_xor(a, d, 64));
-                int ex = 0;
-                if (a > 0.f && a < 3.0e38f) (void)frexpf(a, &ex);
-                if (lane == 0) sc_s = ldexpf(1.f, -ex);
-            }
             const int cnt = b_known - b_done + 1;   // <= kTileBlocks + kTimingHalfWin
             const int b = b_done + lane;
             float cr = 0.f, ci = 0.f;
@@ -564,13 +508,11 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             }
         }
         b_done = b_known + 1;
-#ifndef TDM_TETRA_EST_ALL
         __syncthreads();   // estimates visible
         if (est_duty && !last) {
             stage(i + 1);
             if (i + 2 < ntiles) fetch(i + 2);
         }
-#endif
         TT_MARK(7)
         TT_MARK(8)
         // ---- symbols whose two timing estimates are final: t_k = (k + tau(k sps)) sps, in [1, n-3]
@@ -635,15 +577,8 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 mm[u] = clamp_med3<1>(mk[u] + (int)fl, m_max);
             }
         };
-        if (BC && i == 0) sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc_s)));
         bool any_direct = false;
-        // kq = index of the symbol of lane 0 of wavefront 0, turn u = 0: the thread's symbols are kq + off + TSYM u.  BC: kq =
-        // kb - 1 (lane 0 of a wavefront repeats its left neighbour's last symbol, see WSYM); the position of "symbol -1" of
-        // a carrier whose first symbol is symbol 0 wraps around -- every use of it is clamped into the ring, and the lane
-        // that holds it owns no symbol.
-        constexpr int KQ = BC ? 1 : 0;
-        const bool own_lane = !BC || lane >= 1;
-        uint64_t ub = (uint64_t)(uint32_t)k_begin * sps40 - (BC ? sps40 : 0);
+        uint64_t ub = (uint64_t)(uint32_t)k_begin * sps40;
         for (int kb = k_begin; kb < k_end; kb += TSYM * SU, ub += sps40 * (TSYM * SU)) {
             FarrowTaps f[SU];
             int mm[SU];
@@ -654,8 +589,8 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 f[u].mu = mu[u];
                 // position of the symbol's first filter output in the ring's window; outside it -> direct path below
                 const int q = mm[u] - 1 - ring_lo;
-                const int k = kb - KQ + off + u * TSYM;
-                any_direct |= (unsigned)q > (unsigned)span4 && k < k_end && (!BC || k >= k_lo);
+                const int k = kb + off + u * TSYM;
+                any_direct |= (unsigned)q > (unsigned)span4 && k < k_end;
                 const int p = clamp_med3<0>(q, span4) + ring_off;                  // < 2 kRing
                 const int p0 = (int)min((unsigned)p, (unsigned)(p - kRing));       // p >= kRing ? p - kRing : p
                 const float2 *yp = yring + rrc_slot(p0);
@@ -664,62 +599,25 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 f[u].y1 = yp[2];
                 f[u].y2 = yp[3];
             }
-            float2 *so = sr + (kb - KQ - k_lo);   // (uniform base, the thread's own offset)
-            if (!BC) {
+            float2 *so = sr + (kb - k_lo);   // (uniform base, the thread's own offset)
 #pragma unroll
-                for (int u = 0; u < SU; ++u)
-                    if (kb + off + u * TSYM < k_end) so[off + u * TSYM] = farrow_eval(f[u]);
-            } else {
-                // ---- the symbol, its differential product d = s conj(predecessor), the running sums of d^4 for the carrier-offset
-                // estimate, and a PROVISIONAL decision: the dibit of d itself (estimate taken as zero) with the symbol's margin
-                // -- min(|re|,|im|) / max(|re|,|im|), the tangent of its angular distance to the nearest decision boundary --
-                // in six bits.  The final pass (after the last tile, estimate delta known) reads these bytes back (1 byte per symbol
-                // instead of the 8 of the soft symbols, which by then have left the L2) and looks again only at the symbols whose
-                // margin is within reach of the rotation by delta or of the smallest margin.
-                uint8_t *ho = hr + (kb - KQ - k_lo - 1);
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const float2 sv = farrow_eval(f[u]);
-                    const int k = kb - 1 + off + u * TSYM;
-                    const bool own = own_lane && k < k_end;
-                    if (own) so[off + u * TSYM] = sv;
-                    const float cx = sv.x * sc, cy = sv.y * sc;
-                    const float px = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cx), 0x138, 0xf, 0xf, false));   // wave_shr:1
-                    const float py = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cy), 0x138, 0xf, 0xf, false));
-                    const bool valid = own && k > k_lo;   // (the carrier's first symbol has no predecessor: no product, no decision)
-                    const float dx = valid ? cx * px + cy * py : 0.f, dy = valid ? cy * px - cx * py : 0.f;
-                    const float p4 = fmaf(dx, dx, -(dy * dy)), q4 = dx * dy;
-                    a_pp = fmaf(p4, p4, a_pp);
-                    a_qq = fmaf(q4, q4, a_qq);
-                    a_pq = fmaf(p4, q4, a_pq);
-                    uint32_t h = __builtin_bit_cast(uint32_t, dy) >> 31;
-                    h = __builtin_amdgcn_alignbit(h, __builtin_bit_cast(uint32_t, dx), 31);   // (h << 1) | sign of Re
-                    const float lo = fminf(fabsf(dx), fabsf(dy)), hi = fmaxf(fabsf(dx), fabsf(dy));
-                    // (0 / 0 and NaN symbols convert to code 0: the final pass looks at them again)
-                    const uint32_t qc = min((uint32_t)(lo * 63.f * __builtin_amdgcn_rcpf(hi)), 63u);
-                    if (valid) {
-                        ho[off + u * TSYM] = (uint8_t)((h << 6) | qc);
-                        qmin = min(qmin, qc);
-                    }
-                }
-            }
+            for (int u = 0; u < SU; ++u)
+                if (kb + off + u * TSYM < k_end) so[off + u * TSYM] = farrow_eval(f[u]);
         }
         if (any_direct) {
             // the timing estimate has carried some instants out of the ring (more than 48 symbols from their nominal
             // positions): their four filter outputs again from the input.  Rare, rolled, and kept apart from the loop
             // above so that its loads never order that loop's registers; the explicit wait leaves nothing pending.
-            // (BC: such a carrier's final passes run from the stored soft symbols, as up to round 3.)
-            if (BC) slow_s = 1;
             for (int kb = k_begin; kb < k_end; kb += TSYM * SU) {
                 int mm[SU];
                 float mu[SU];
-                instants((uint64_t)(uint32_t)kb * sps40 - (BC ? sps40 : 0), mm, mu);
+                instants((uint64_t)(uint32_t)kb * sps40, mm, mu);
 #pragma unroll 1
                 for (int u = 0; u < SU; ++u) {
                     // (selects, not mm[u] / mu[u]: a dynamically indexed private array is promoted to LDS, 2 KB per workgroup)
                     static_assert(SU == 2, "select");
-                    const int m = u ? mm[1] : mm[0], k = kb - KQ + off + u * TSYM;
-                    if ((m - 1 >= ring_lo && m + 2 < ring_hi) || k >= k_end || !own_lane) continue;
+                    const int m = u ? mm[1] : mm[0], k = kb + off + u * TSYM;
+                    if ((m - 1 >= ring_lo && m + 2 < ring_hi) || k >= k_end) continue;
                     float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f, a3x = 0.f, a3y = 0.f;
                     float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;   // sliding window x[idx - 3 .. idx - 1]
                     const int first = m - 1 - H2;
@@ -760,8 +658,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     // (margin 0 by the definition's atan2(0, 0)) never wins a strict comparison and is caught by the smallest hi instead;
     // a NaN symbol fails every comparison.
     float mlo = 3.0e38f, mhi = 1.f, hmin = 3.0e38f;
-    const bool slow = !BC || __builtin_amdgcn_readfirstlane(slow_s) != 0;
-    if (slow) {
+    {
         // ---- differential products d_i = s_i conj(s_{i-1}), the 4th-power carrier-offset estimate over them, then the quadrant
         // decisions.  A thread owns CH consecutive symbols of a chunk of CH * 256: four 16-byte loads (the carrier's soft
         // symbols come back from L2), the predecessor of its first symbol from the lane to its left (one wavefront shift), one
@@ -822,7 +719,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
         };
         // sum of d^4 = (p + 2 i q)^2 with p = Re d^2 = x^2 - y^2, q = Im d^2 / 2 = x y:  p^2 - 4 q^2 + 4 i p q, the three sums
         // kept apart (one multiply-add each per symbol) and combined once per thread
-        a_pp = 0.f; a_qq = 0.f; a_pq = 0.f;   // (the sums of the symbol stage, if any, are dropped)
         auto power4 = [&](const float2 (&d)[CH]) __attribute__((always_inline)) {
     #pragma unroll
             for (int u = 0; u < CH; ++u) {
@@ -913,98 +809,11 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             products_chunk(c0, d);
             decide_chunk(c0, d);
         }
-    } else {
-        // ---- BC: the 4th-power estimate from the sums of the symbol stage, the smallest margin code of the carrier, then ONE
-        // pass over the provisional decisions (1 byte per symbol, L2-resident: 8 KB per carrier).
-        constexpr int NWF = kRrcThreads / 64;
-        {
-            float a4r = wave_sum(fmaf(-4.f, a_qq, a_pp));
-            float a4i = wave_sum(4.f * a_pq);
-            uint32_t qm = qmin;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) qm = min(qm, (uint32_t)__shfl_xor((int)qm, d, 64));
-            if (lane == 0) { sm[wv] = a4r; sm2[wv] = a4i; ((uint32_t *)Cst)[wv] = qm; }   // (the statistic's ring is free now)
-            __syncthreads();
-            if (tid == 0) {
-                float r = 0.f, q = 0.f;
-                for (int w = 0; w < NWF; ++w) { r += sm[w]; q += sm2[w]; }
-                delta_s = (r == 0.f && q == 0.f) ? 0.f : atan2f(-q, -r) * 0.25f;
-            }
-            __syncthreads();
-        }
-        uint32_t qstar = ((const uint32_t *)Cst)[0];
-#pragma unroll
-        for (int w = 1; w < NWF; ++w) qstar = min(qstar, ((const uint32_t *)Cst)[w]);
-        const float delta = delta_s;
-        float rs, rc;
-        __sincosf(-delta, &rs, &rc);   // |delta| <= pi/4
-        // Which symbols need a second look?  With m_k the margin of symbol k before the rotation (its code q_k says
-        // tan m_k in [q_k / 63, (q_k + 1) / 63)), the rotation by delta moves every margin by at most |delta|: the decision of
-        // a symbol with m_k > |delta| stands, and the carrier's smallest margin after the rotation is at most
-        // m* + |delta| (m* = the smallest before), so no symbol with m_k > m* + 2 |delta| can be the one that attains it.
-        // Both sets lie below one code: q_cut = 63 tan(atan((q* + 1) / 63) + 2 |delta| + slack).  A NaN estimate (non-finite
-        // input) sends every symbol through the exact path.
-        uint32_t q_cut = 63u;
-        {
-            const float thr = atanf((float)(qstar + 1u) * (1.f / 63.f)) + 2.f * fabsf(delta) + 2.0e-3f;
-            if (thr < 0.78f) q_cut = min(63u, (uint32_t)(63.f * __tanf(thr)) + 1u);
-        }
-        q_cut = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_cut);
-        const uint32_t t_rep = 0x80808080u | (q_cut * 0x01010101u);
-        // the exact decision of symbol i (1 <= i < ns) from the stored soft symbols, as the slow path forms it
-        auto exact = [&](int i) -> uint32_t {
-            const float2 s0 = sr[i - 1], s1 = sr[i];
-            const float px = s0.x * sc, py = s0.y * sc, cx = s1.x * sc, cy = s1.y * sc;
-            const float dx = cx * px + cy * py, dy = cy * px - cx * py;
-            const float ddx = dx * rc - dy * rs, ddy = dx * rs + dy * rc;
-            uint32_t h = __builtin_bit_cast(uint32_t, ddy) >> 31;
-            h = __builtin_amdgcn_alignbit(h, __builtin_bit_cast(uint32_t, ddx), 31);
-            const float lo = fminf(fabsf(ddx), fabsf(ddy)), hi = fmaxf(fabsf(ddx), fabsf(ddy));
-            hmin = fminf(hmin, hi);
-            const bool take = lo * mhi < mlo * hi;
-            mlo = take ? lo : mlo;
-            mhi = take ? hi : mhi;
-            return h;
-        };
-        constexpr int CH = 8, CSYM = CH * kRrcThreads;
-        for (int c0 = 0; c0 < ns; c0 += CSYM) {
-            const int i0 = c0 + CH * tid;          // symbols i0 .. i0 + 7; symbol i's byte is hr[i - 1]
-            if (i0 >= 1 && i0 + CH <= ns) {
-                const u32x2 w = *(const u32x2_a1 *)(hr + i0 - 1);
-                uint32_t wq[2] = {w.x, w.y}, out[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    out[j] = (wq[j] >> 6) & 0x03030303u;
-                    // bit 7 of a byte: its code is <= q_cut (no borrow crosses a byte: 0x80 + q_cut - q >= 0x41)
-                    uint32_t cand = (t_rep - (wq[j] & 0x3f3f3f3fu)) & 0x80808080u;
-                    while (cand) {   // (rare: a handful of symbols per carrier)
-                        const int bit = __builtin_ctz(cand);
-                        cand &= cand - 1u;
-                        const int u = 4 * j + (bit >> 3);
-                        const uint32_t h = exact(i0 + u);
-                        out[j] = (out[j] & ~(3u << (bit - 7))) | (h << (bit - 7));
-                    }
-                }
-                *(u32x2_a1 *)(hr + i0 - 1) = u32x2{out[0], out[1]};
-            } else {
-#pragma unroll 1
-                for (int u = 0; u < CH; ++u) {
-                    const int i = i0 + u;
-                    if (i < 1 || i >= ns) continue;
-                    const uint32_t b = hr[i - 1];
-                    hr[i - 1] = (uint8_t)((b & 63u) <= q_cut ? exact(i) : (b >> 6));
-                }
-            }
-        }
     }
     const float mratio = hmin == 0.f ? 0.f : mlo * __builtin_amdgcn_rcpf(mhi);   // (no decision, ns <= 1 or all NaN: 3e38)
     float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;   // (a NaN ratio never replaces the running minimum)
     margin = block_min(margin, sm);
     TT_MARK(11)
-#ifdef TDM_TETRA_TIMING
-    if ((tid & 63) == 0 && row % 64 == 0)
-        for (int q = 0; q < 12; ++q) atomicAdd(&g_tetra_dbg[q], tt[q]);
-#endif
     if (tid == 0) {
         n_soft[row] = ns;
         if (timing_milli) timing_milli[row] = (int32_t)rintf(tau_mid_s * 1000.f);

@@ -1,7 +1,6 @@
 // TETRA mode: constants, kernel parameters and the launch entry (the kernels live in tetra_kernels.hpp, compiled in
 // tdm_tetra.hip; the rest of the library sees only this header).
 #pragma once
-#include "experiment_guard.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -10,13 +9,9 @@
 namespace tdm {
 
 constexpr int kRrcMaxTaps = 96;
-#ifndef TDM_TETRA_THREADS
 #define TDM_TETRA_THREADS 256
-#endif
 constexpr int kRrcThreads = TDM_TETRA_THREADS;            // 256: three workgroups per CU fit in LDS (0.465 ms per 4096 x 32768); 512: two (0.48 ms)
-#ifndef TDM_TETRA_PER
 #define TDM_TETRA_PER 8
-#endif
 constexpr int kRrcPerThread = TDM_TETRA_PER;              // outputs per thread and tile (8: a wavefront owns 512 consecutive outputs)
 constexpr int kRrcTile = kRrcThreads * kRrcPerThread;     // samples per round of a workgroup
 constexpr int kTimingBlock = 256;                         // samples per timing sub-block (TB)
@@ -50,9 +45,6 @@ struct TetraParams {
 };
 
 // one launch of the fused receiver on `rows` carriers; returns false when no kernel is instantiated for tp.ntaps
-#ifdef TDM_TETRA_TIMING
-void tetra_timing_dump();
-#endif
 // row_list / n_rows (device, or null): the launch covers the rows listed -- workgroup i takes row row_list[i], workgroups
 // past *n_rows leave at once -- instead of all `rows`
 bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, uint8_t *hard,

@@ -32,7 +32,6 @@
 #define TDM_CPTR(p) (p)
 #endif
 
-#include "experiment_guard.hpp"
 
 namespace tdm {
 

@@ -17,19 +17,8 @@
 #include "zp_common.hpp"
 
 // TDM_ZP_TIMING builds: per-phase s_memtime sums of the block kernel (lane 0 of each wave) into g_zp_dbg
-#if defined(TDM_ZP_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-extern __device__ unsigned long long g_zp_dbg[16];
-#define ZP_T(i)                                                                    \
-    do {                                                                           \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                \
-        if (lane == 0 && (blk & 15) == 0) atomicAdd(&g_zp_dbg[(Loader::kStaged ? 8 : 0) + (i)], t_ - zp_tprev_); \
-        zp_tprev_ = t_;                                                            \
-    } while (0)
-#define ZP_T0() unsigned long long zp_tprev_ = __builtin_amdgcn_s_memtime()
-#else
 #define ZP_T(i)
 #define ZP_T0()
-#endif
 
 namespace tdm {
 
@@ -573,9 +562,7 @@ struct StagedLoader {
 #else
 #define TDM_OPAQUE_SPTR(p)
 #endif
-#ifndef TDM_ZIR_CHUNK
 #define TDM_ZIR_CHUNK 2   // positions per scalar load (2 coefficients each)
-#endif
 template <int K, int L, bool REV>
 TDM_HD void zir_from_table(const double *tab, const double *sr, const double *sq, double *xr, double *xi)
 {
@@ -683,15 +670,11 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
         for (int k = 0; k < K; ++k)
             if (lane == 0) { sr[k] = 0; sq[k] = 0; }
         // add the zero-input response of the start state
-#ifdef TDM_ZIR_TABLE
-        zir_from_table<K, L, false>(P.zirh + (size_t)s * L * K, sr, sq, xr, xi);
-#else
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             xr[i] += zir_step<K>(a, sr);
             xi[i] += zir_step<K>(a, sq);
         }
-#endif
     }
     // positions past the end of the extended signal must not feed the backward pass
     if (blk == P.nb - 1) {
@@ -745,15 +728,11 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (lane == kWave - 1) { sr[k] = 0; sq[k] = 0; }
-#ifdef TDM_ZIR_TABLE
-        zir_from_table<K, L, true>(P.zirh + (size_t)s * L * K, sr, sq, xr, xi);
-#else
 #pragma unroll
         for (int i = L - 1; i >= 0; --i) {
             xr[i] += zir_step<K>(a, sr);
             xi[i] += zir_step<K>(a, sq);
         }
-#endif
     }
     ZP_T(2);
     // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------
@@ -1051,9 +1030,7 @@ struct FinishArgs {
 constexpr int kMaxSps = 32;       // phases a partial-power record holds
 constexpr int kPowThreads = 256;  // threads (= samples) per partial-power block
 constexpr int kPowSub = 8;        // partial-power blocks per workgroup
-#ifndef TDM_LLPF
 #define TDM_LLPF 8
-#endif
 constexpr int kFixBn = kWave * TDM_LLPF;  // block length of the channel filter (ref_plan.hpp kLLpf)
 
 TDM_HD uint8_t dqpsk_decide(double cr, double ci, double pr, double pi_, double &margin)
@@ -1062,11 +1039,7 @@ TDM_HD uint8_t dqpsk_decide(double cr, double ci, double pr, double pi_, double 
     const double br = pr, bi = -pi_;
     const double dr = sub_rn(mul_rn(cr, br), mul_rn(ci, bi));
     const double di = add_rn(mul_rn(cr, bi), mul_rn(ci, br));
-#ifdef TDM_FINISH_NOATAN   // experiment: what the exact arctangent costs the finish kernel (wrong results, timing only)
-    const double ph = di + dr;
-#else
     const double ph = atan2(di, dr);
-#endif
     const double t0 = -5 * M_PI / 8, t1 = -3 * M_PI / 8, t2 = 3 * M_PI / 8, t3 = 5 * M_PI / 8;
     uint8_t sym;
     if (ph < t0) sym = 3;
