@@ -34,10 +34,8 @@ struct PfbParams {
     int32_t pad2_;
     int64_t in_stride;    // bytes between the input streams of a batch (grid.y)
     int64_t out_batch;    // float2 elements between the outputs of a batch
-    unsigned long long *dbg;  // TDM_PFB_TIMING builds: per-phase cycle sums
 };
 
-#define PFB_T(i)
 
 __device__ __forceinline__ float2 pfb_load(const void *iq, int fmt, int64_t n)
 {
@@ -368,22 +366,16 @@ __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb
                 t.store(xs + 4 * u);
             }
         }
-        PFB_T(0);
         __syncthreads();
-        PFB_T(1);
         if (g + 1 < Q.G) {
 #pragma unroll
             for (int k = 0; k < NPF; ++k)
                 if (tid + k * NT < nu) pf[k].load(iq, nbase + (int64_t)TB * D + 4 * (int64_t)(tid + k * NT), Q.n_in);
         }
         pfb_stage_a<M1, M2, P, TB>(xs, A, hv, tid, D, dmod, (int)((m0 * (int64_t)D) % M));
-        PFB_T(2);
         __syncthreads();
-        PFB_T(3);
         pfb_pass1<M1, M2>(A, wml, mi, n2);
-        PFB_T(4);
         __syncthreads();
-        PFB_T(5);
         // The next round's window lands in LDS here, BEFORE this round's stores are issued: loads and stores
         // share vmcnt and retire out of order with respect to each other, so waiting for a load while
         // stores are in flight means waiting for every store acknowledgement.
@@ -397,9 +389,7 @@ __global__ __launch_bounds__(TB *M2, pfb_waves_per_simd(TB *M2, WGS)) void k_pfb
                 t.store(xs + 4 * u);
             }
         }
-        PFB_T(8);
         if (tid < TB * M1) pfb_pass2<M1, M2>(A, out, out_stride, m0, Q.n_out, k1b, mib);
-        PFB_T(6);
     }
 }
 

@@ -122,7 +122,6 @@ __device__ __forceinline__ float atan2_turns(float y, float x)
 // waves per SIMD the register allocation aims for (LDS holds four workgroups of 256 threads or two of 512)
 #define TDM_TETRA_WAVES(NT) 4
 
-#define TT_MARK(i)
 
 // Split-bf16 arithmetic of the matched filter: a float is the sum of two bf16 (16 significant bits), a product of two
 // such sums keeps its three leading terms; the matrix cores multiply bf16 exactly and accumulate in fp32.
@@ -348,9 +347,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     for (int i = 0; i < ntiles; ++i) {
         const bool last = i == ntiles - 1;
         const int base = i * kRrcTile;
-        TT_MARK(0)
         __syncthreads();   // tile i staged; the previous round's ring reads are done
-        TT_MARK(1)
         // (a wavefront whose 512 outputs of the last tile all lie past the end of the chunk has no filter output, no
         // statistic and nothing for the ring: a chunk of 8389 samples -- the 10 MS/s channeliser's -- ends 197 samples
         // into its fifth tile, and three of the four wavefronts skip it)
@@ -382,7 +379,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i1, h1, cim[bb], 0, 0, 0);
             }
         }
-        TT_MARK(2)
         // ---- square-law timing statistic of the wavefront's two sub-blocks, C_b = sum |y[g]|^2 exp(-2 pi i g / sps): the
         // phasor of a lane's four outputs of a sub-block is a constant table times the lane's own
         {
@@ -439,7 +435,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             if (lane < 4) ((float *)Cst)[2 * (b & (kCstRing - 1)) + (lane >> 1)] = b < nb ? z : 0.f;
             if (last && lane < 4) ((float *)Cst)[2 * ((b + kTileBlocks) & (kCstRing - 1)) + (lane >> 1)] = 0.f;
         }
-        TT_MARK(3)
         // ---- matched-filter output into the ring (the ring is a whole number of sub-blocks: a sub-block's 256 outputs
         // never straddle its end)
 #pragma unroll
@@ -455,9 +450,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             ((float *)Cst)[2 * (b & (kCstRing - 1)) + (lane >> 1)] = 0.f;
             ((float *)Cst)[2 * ((b + kTileBlocks) & (kCstRing - 1)) + (lane >> 1)] = 0.f;
         }
-        TT_MARK(4)
         __syncthreads();   // ring, statistic visible; staging buffer free
-        TT_MARK(5)
         // ---- timing estimates that are final now: vector average over +-TW sub-blocks, argument, unwrap.  ONE wavefront
         // computes them (the duty rotates with the tile, so that over a carrier every SIMD of the compute unit does a
         // quarter of this work) while the other three stage the next tile; a third barrier hands the estimates over.
@@ -469,7 +462,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             stage(i + 1);
             if (i + 2 < ntiles) fetch(i + 2);
         }
-        TT_MARK(6)
         if (est_duty) {
             if (b_done > 0) tau_prev = tau[(b_done - 1) & (kTauRing - 1)].x;   // (the last estimate of the previous duty wavefront)
             const int lane = tid & 63;
@@ -513,8 +505,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             stage(i + 1);
             if (i + 2 < ntiles) fetch(i + 2);
         }
-        TT_MARK(7)
-        TT_MARK(8)
         // ---- symbols whose two timing estimates are final: t_k = (k + tau(k sps)) sps, in [1, n-3]
         if (i == 0) {
             while (k_lo < 8 && ((double)k_lo + (double)tau_at(tau, nb, k_lo * sps)) * sps < 1.0) ++k_lo;
@@ -534,7 +524,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             // symbol into the next round)
             k_end = min((int)(((double)b_known + 0.5) * (double)kTimingBlock * P.inv_sps), k_lo + P.max_soft);
         }
-        TT_MARK(9)
         k_end = __builtin_amdgcn_readfirstlane(k_end);       // (uniform by construction: scalar loop control and store bases)
         k_begin = __builtin_amdgcn_readfirstlane(k_begin);
         const int ring_lo = max(0, base + kRrcTile - kRing), ring_hi = base + kRrcTile;
@@ -647,7 +636,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
         }
         k_begin = max(k_begin, k_end);
-        TT_MARK(10)
     }
     __syncthreads();   // the carrier's soft symbols are visible to the whole workgroup
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -813,7 +801,6 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     const float mratio = hmin == 0.f ? 0.f : mlo * __builtin_amdgcn_rcpf(mhi);   // (no decision, ns <= 1 or all NaN: 3e38)
     float margin = mratio <= 1.f ? atanf(mratio) : 3.4e38f;   // (a NaN ratio never replaces the running minimum)
     margin = block_min(margin, sm);
-    TT_MARK(11)
     if (tid == 0) {
         n_soft[row] = ns;
         if (timing_milli) timing_milli[row] = (int32_t)rintf(tau_mid_s * 1000.f);

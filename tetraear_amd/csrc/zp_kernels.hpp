@@ -16,10 +16,6 @@
 
 #include "zp_common.hpp"
 
-// TDM_ZP_TIMING builds: per-phase s_memtime sums of the block kernel (lane 0 of each wave) into g_zp_dbg
-#define ZP_T(i)
-#define ZP_T0()
-
 namespace tdm {
 
 // ------------------------------------------------------------------------------------------
@@ -610,9 +606,7 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
     constexpr int Bn = kWave * L;
     double xr[L], xi[L];
     const int64_t seg = (int64_t)blk * Bn + (int64_t)lane * L;
-    ZP_T0();
     ld.template load<L>(cm, row, blk, lane, P, xr, xi);
-    ZP_T(0);
 
     constexpr int P0 = (L - EDGE % L) % L;  // == P.P0
     const bool inject = (blk == 0 && lane == 0);
@@ -686,7 +680,6 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             if (g > last) { xr[i] = 0; xi[i] = 0; }
         }
     }
-    ZP_T(1);
     // ---------------- backward: same cascade, time reversed ----------------
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
@@ -734,7 +727,6 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             xi[i] += zir_step<K>(a, sq);
         }
     }
-    ZP_T(2);
     // ---------------- block-local outputs at padded-ext positions k0L + j*stride ----------------
     if (Loader::kStaged) {
         // stride-1 stage: transpose back through LDS and store 16 B per lane, coalesced
@@ -780,7 +772,6 @@ TDM_HD void zp_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lan
             }
         }
     }
-    ZP_T(3);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -26,6 +26,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pfb_fe
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_pfb_write -o write -- python bench.py --mode pfb --carriers 12800 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_pfb_write.err
 python bench.py --carriers 1 --no-cpu-baseline --no-extra > $OUT/bench_single.json 2> /dev/null
 python bench.py --shared --carriers 64 --no-cpu-baseline --no-extra > $OUT/bench_shared64.json 2> /dev/null
+python bench.py --shared --carriers 64 --chunks 4 --no-cpu-baseline --no-extra > $OUT/bench_shared64_chunks4.json 2> /dev/null
+for c in 128 256 512; do python bench.py --carriers $c --no-cpu-baseline --no-extra > $OUT/bench_carriers$c.json 2> /dev/null; done
+python bench.py --depth 1 --no-cpu-baseline --no-extra > $OUT/bench_depth1.json 2> /dev/null
 TDM_FORCE_DIST=1 MASTER_PORT=29517 python bench.py --no-cpu-baseline --no-extra > $OUT/bench_forcedist_rccl.json 2> /dev/null
 python bench.py --no-cpu-baseline --no-extra --total-carriers 1024 > $OUT/bench_strong1024.json 2> /dev/null
 python bench.py --mode wideband --carriers 12800 --steps 100 --warmup 60 > $OUT/bench_wideband.json 2> /dev/null

@@ -39,7 +39,8 @@ def main():
     src = os.path.join(HERE, "gpurun_out", tag)
     dst = os.path.join(HERE, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for name in ("hbm_ceiling", "bench", "bench_forcedist_rccl", "bench_strong1024", "bench_tetra", "bench_pfb", "bench_single", "bench_cf64_256", "bench_shared64", "bench_wideband"):
+    for name in ("hbm_ceiling", "bench", "bench_forcedist_rccl", "bench_strong1024", "bench_tetra", "bench_pfb", "bench_single", "bench_cf64_256", "bench_shared64", "bench_wideband",
+                 "bench_shared64_chunks4", "bench_carriers128", "bench_carriers256", "bench_carriers512", "bench_depth1"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(dst, f"{tag}_{name}.json"))
@@ -58,14 +59,23 @@ def main():
                 d = [x[1] / 1e6 for x in sorted(v)]
                 if len(d) <= warm:
                     continue
-                timed = d[warm:]
+                steps = (len(d) - warm) // 2 if out == "reference" else 0   # reference bench: timed region, then the per-kernel pass
+                timed = d[warm:warm + steps] if steps else d[warm:]
                 rows[k] = {"launches": len(d), "warmup_launches": warm, "warmup_avg_ms": sum(d[:warm]) / warm,
                            "warmup_max_ms": max(d[:warm]), "timed_avg_ms": sum(timed) / len(timed),
                            "timed_min_ms": min(timed), "timed_max_ms": max(timed), "first_10_ms": [round(x, 4) for x in d[:10]]}
+                if steps:
+                    alone = d[warm + steps:warm + 2 * steps]
+                    rows[k].update({"per_kernel_pass_avg_ms": sum(alone) / len(alone), "per_kernel_pass_min_ms": min(alone),
+                                    "per_kernel_pass_max_ms": max(alone)})
             with open(os.path.join(dst, f"{tag}_{out}_kernel_timed.json"), "w") as fo:
                 json.dump({"note": "launch durations from the rocprofv3 kernel trace of the bench command, in launch order: "
                                    "the first `warmup_launches` are bench.py's untimed settling + warm-up passes (GPU clocks ramp for ~40 "
-                                   "launches after idle), `timed_*` are the launches of the timed region",
+                                   "launches after idle); `timed_*` are the launches of the timed region -- since round 6 up to three steps "
+                                   "are in flight there (PipelinedBatchDemodulator), so a launch shares the device with the neighbouring "
+                                   "steps' kernels and takes longer than alone; `per_kernel_pass_*` are the same number of steps again with "
+                                   "the steps ordered one after the other on the device (tdm_plan_wait_for): every launch alone -- the "
+                                   "figure bench.py's `roofline.avg_launch_ms` / `stage_ms_per_launch` report from HIP events",
                            "kernels": rows}, fo, indent=1)
     prof = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py "
                        "[--mode tetra --carriers 4096 | --mode pfb --carriers 12800] --steps 2 --warmup 1",
