@@ -1191,6 +1191,52 @@ def leg_gardner(rows, base, chk, steps):
             "output_check": check}
 
 
+def leg_tetra_int8(rows, base, steps):
+    """The same carriers as cu8 bytes (north_star: "coalesced complex-int8/float loads"; round 6): quantised at a quarter of full
+    scale, demodulated by a cu8 TDM_MODE_TETRA plan -- 2 instead of 8 bytes per sample in, ONE bf16 plane per component, two
+    matrix-core products per step instead of four.  Algorithmic bytes R*2 + 8 + 1 per symbol (17 at R = 4).  Output check: every
+    row's decisions equal to those of the cf32 kernel on the samples the bytes mean (u / 127.5 - 1), soft symbols within 1e-5."""
+    from tetraear_amd import synth
+    from tetraear_amd._lib import MODE_TETRA
+    from tetraear_amd.batch import BatchDemodulator
+    fs, n = TETRA_FS, TETRA_N
+    raws, xqs = [], []
+    for x in base:
+        x = np.asarray(x).astype(np.complex128)
+        raw = synth.quantise_cu8(x / (4.0 * np.max(np.abs(x))), scale=1.0)
+        raws.append(raw)
+        xqs.append(synth.cu8_to_c128(raw).astype(np.complex64))
+    outs = {}
+    for fmt, rows_in in (("cf32", xqs), ("cu8", raws)):
+        bd = BatchDemodulator(fs, n, rows, fmt, mode=MODE_TETRA)
+        bd.alloc_device_io()
+        bd.upload(np.concatenate([rows_in[i % TETRA_DISTINCT] for i in range(rows)]))
+        for _ in range(max(25, steps)):
+            bd.enqueue()
+        bd.sync()
+        bd.time_begin()
+        for _ in range(steps):
+            bd.enqueue()
+        ms = bd.time_end() / steps
+        outs[fmt] = (ms, bd.stage_times(), bd.download())
+        bd.close()
+    ms8, st8, (h8, s8, n8, t8, m8) = outs["cu8"]
+    msf, stf, (hf, sf, nf, tf, mf) = outs["cf32"]
+    same = bool(np.array_equal(n8, nf)) and all(np.array_equal(h8[r, :max(int(n8[r]) - 1, 0)], hf[r, :max(int(nf[r]) - 1, 0)]) for r in range(rows))
+    err = max(float(np.max(np.abs(s8[r, :n8[r]] - sf[r, :nf[r]])) / np.max(np.abs(sf[r, :nf[r]]))) for r in range(min(rows, TETRA_DISTINCT))) if same else float("nan")
+    nsym = int(np.sum(np.maximum(n8.astype(np.int64) - 1, 0)))
+    k_ms = st8.get("tetra_fused", ms8)
+    bytes_alg = rows * n * 2 + int(np.sum(n8.astype(np.int64))) * 9
+    return {"what": "the fused receiver on cu8 input: bytes converted where the window is staged, one exact bf16 plane per component, "
+                    "two matrix-core products per step instead of four",
+            "ms_per_step": ms8, "value": nsym / (ms8 * 1e-3) / 1e6, "unit": "Msym/s", "cf32_on_the_same_samples_ms_per_step": msf,
+            "output_check": {"against": "the cf32 kernel on the dequantised samples (u / 127.5 - 1), every row", "soft_max_err_rel": err,
+                             "status": "decisions equal to the cf32 kernel's on the same samples, soft within 1e-5" if (same and err < 1e-5) else "DIFFERS from the cf32 kernel"},
+            "roofline": hbm_roofline("k_tetra_fused<33, cu8>", bytes_alg, k_ms, read_bytes=rows * n * 2, bytes_per_symbol=bytes_alg / max(nsym, 1),
+                                     note="2 + 2.25 algorithmic bytes per input sample: with a quarter of the input bytes the kernel is bound by "
+                                          "instruction issue, not by HBM -- the fraction is reported all the same")}
+
+
 def leg_tetra(carriers, steps, warmup):
     """TETRA-mode leg (no reference oracle; SURVEY 8(d) 'tetra mode'): `carriers` channelised carriers,
     cf32 at 72 kS/s (4 samples/symbol), chunks of 32768 samples.  ONE kernel (matched filter -> timing ->
@@ -1246,6 +1292,12 @@ def leg_tetra(carriers, steps, warmup):
             gardner = leg_gardner(rows, base, chk, max(5, steps // 5))
         except Exception as e:  # noqa: BLE001 -- a side leg never breaks the line
             gardner = {"error": str(e)}
+    int8 = None
+    if not PMC_CHILD:
+        try:
+            int8 = leg_tetra_int8(rows, base, max(5, steps // 5))
+        except Exception as e:  # noqa: BLE001 -- a side leg never breaks the line
+            int8 = {"error": str(e)}
     out = {"metric": "Msymbols/s demodulated (TETRA mode: RRC + feed-forward timing + Farrow + quadrant slicer)",
            "value": nsym * steps / dt / 1e6, "unit": "Msym/s", "n_gpus": 1, "steps": steps,
            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -1256,6 +1308,7 @@ def leg_tetra(carriers, steps, warmup):
            "output_check": check,
            "rrc_stage": rrc_stage,
            "gardner_mode": gardner,
+           "int8_input": int8,
            "roofline": hbm_roofline("k_tetra_fused<33> (RRC matched filter on the matrix cores (split-bf16 products, fp32 accumulate) -> timing -> Farrow -> slicer, one pass over the input)",
                                     bytes_alg, rrc_ms, read_bytes=rows * n * 8, traffic=traffic, traffic_src=traffic_src,
                                     traffic_detail=traffic_detail, bytes_per_symbol=bytes_alg / max(nsym, 1))}

@@ -586,3 +586,83 @@ def test_gpu_occupancy_gate_matches_definition_and_gated_receiver_equals_ungated
                 assert t1[r] == t0[r] and m1[r] == m0[r]
             else:
                 assert n1[r] == 0
+
+
+def _quantise8(x, fmt):
+    """a complex baseband signal at a quarter of full scale as wire bytes, and the samples those bytes MEAN (what the
+    definition is evaluated on): cu8 u / 127.5 - 1 (pyrtlsdr, the channeliser), cs8 s / 128"""
+    x = x / (4.0 * np.max(np.abs(x)))
+    if fmt == "cu8":
+        raw = synth.quantise_cu8(x, scale=1.0)
+        return raw, synth.cu8_to_c128(raw)
+    raw = np.empty(2 * len(x), dtype=np.int8)
+    raw[0::2] = np.clip(np.rint(128 * x.real), -128, 127)
+    raw[1::2] = np.clip(np.rint(128 * x.imag), -128, 127)
+    return raw, (raw[0::2].astype(np.float64) + 1j * raw[1::2].astype(np.float64)) / 128.0
+
+
+@pytest.mark.gpu
+def test_gpu_tetra_int8_input_matches_definition_on_the_dequantised_samples():
+    """north_star: "coalesced complex-int8/float loads".  TDM_MODE_TETRA plans on cu8 / cs8 input (round 6: the bytes are
+    converted where the kernels stage their window; in the fused receiver an 8-bit sample is ONE exact bf16 plane, two
+    matrix-core products per step instead of four): hard decisions, symbol counts, timing and margin equal to the fp64
+    definition evaluated on the samples the bytes mean, soft symbols within 1e-5 of it, no error against what was sent,
+    and the same decisions as a cf32 plan fed with those samples; rows at odd byte offsets (a pitch that is no multiple of
+    four bytes); the RRC stage alone (tdm_plan_rrc_filter) on 8-bit input against the definition's matched filter; the
+    Gardner mode on 8-bit input (three launches: its matched filter converts)."""
+    from tetraear_amd._lib import MODE_TETRA, MODE_TETRA_GARDNER, check, ptr
+    from tetraear_amd.batch import BatchDemodulator
+    for fmt in ("cu8", "cs8"):
+        for fs, n, seed, toff, coff, snr in CASES[:5]:
+            rows = 3
+            sig = [make_signal(n, fs, seed * 10 + r, toff + 0.05 * r, coff, snr) for r in range(rows)]
+            raws, xqs = zip(*[_quantise8(s[0].astype(np.complex128), fmt) for s in sig])
+            bd = BatchDemodulator(fs, n, rows, fmt, mode=MODE_TETRA)
+            hards, softs, timing, margin = bd.process(np.concatenate(raws))
+            y8 = bd.rrc_filter(np.concatenate(raws))
+            bd.close()
+            bf = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA)
+            hf, sf, tf, mf = bf.process(np.concatenate([q.astype(np.complex64) for q in xqs]))
+            bf.close()
+            for r in range(rows):
+                ref_hard, _, info = tetra_np.demod(xqs[r], fs)
+                assert len(softs[r]) == info["n_sym"], (fmt, fs, r)
+                np.testing.assert_array_equal(hards[r], ref_hard)
+                np.testing.assert_array_equal(hards[r], hf[r])
+                scale = np.max(np.abs(info["sym"]))
+                assert np.max(np.abs(softs[r] - info["sym"])) < 1e-5 * scale, (fmt, fs, r)
+                assert best_ber(hards[r], sig[r][1])[0] <= (0.0 if snr >= 20.0 else 3e-3)
+                assert abs(timing[r] / 1000.0 - info["tau"][len(info["tau"]) // 2]) < 2e-3
+                assert abs(margin[r] - info["margin"]) < 1e-3
+                ref_y = tetra_np.matched_filter(xqs[r], tetra_np.rrc_taps(fs / 18000.0))
+                assert np.max(np.abs(y8[r] - ref_y)) < 2e-6 * np.max(np.abs(ref_y)), (fmt, fs, r)
+    # rows with a pitch of an odd number of samples (2-byte aligned rows only), through the C-ABI
+    fs, n, rows, pitch = 72000.0, 8191, 3, 8193
+    sig = [make_signal(n, fs, 900 + r, 0.1 * r, 25.0, 22.0) for r in range(rows)]
+    raws, xqs = zip(*[_quantise8(s[0].astype(np.complex128), "cu8") for s in sig])
+    buf = np.full((rows, 2 * pitch), 77, dtype=np.uint8)
+    for r in range(rows):
+        buf[r, :2 * n] = raws[r]
+    bd = BatchDemodulator(fs, n, rows, "cu8", mode=MODE_TETRA)
+    ms = bd.info.max_soft
+    hard = np.zeros((rows, ms), np.uint8); soft = np.zeros((rows, ms), np.complex64)
+    ns = np.zeros(rows, np.int32); tm = np.zeros(rows, np.int32); mm = np.zeros(rows)
+    check(bd.lib.tdm_process(bd.handle, ptr(buf), pitch, None, None, ptr(hard), ptr(soft), ptr(ns), ptr(tm), ptr(mm)))
+    bd.close()
+    for r in range(rows):
+        ref_hard, _, info = tetra_np.demod(xqs[r], fs)
+        assert ns[r] == info["n_sym"]
+        np.testing.assert_array_equal(hard[r, :ns[r] - 1], ref_hard)
+    # the Gardner mode on bytes: three launches (whole chunks), decisions as the definition's loop
+    fs, n, rows = 72000.0, 12000, 4
+    sig = [make_signal(n, fs, 950 + r, 0.07 * r - 0.1, 30.0, 22.0) for r in range(rows)]
+    raws, xqs = zip(*[_quantise8(s[0].astype(np.complex128), "cu8") for s in sig])
+    bd = BatchDemodulator(fs, n, rows, "cu8", mode=MODE_TETRA_GARDNER)
+    assert bd.info.gardner_segments == 1
+    hards, softs, timing, margin = bd.process(np.concatenate(raws))
+    bd.close()
+    for r in range(rows):
+        ref_hard, _, info = tetra_np.demod_gardner(xqs[r], fs)
+        assert abs(len(softs[r]) - len(info["t"])) <= 1
+        m = min(len(hards[r]), len(ref_hard))
+        assert np.mean(hards[r][:m] != ref_hard[:m]) <= 1e-3, r

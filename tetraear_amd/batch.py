@@ -211,8 +211,12 @@ class BatchDemodulator:
                                            self.n_samples if stride is None else int(stride), y_buf.ptr, int(y_pitch), None))
 
     def rrc_filter(self, iq):
-        """host in, host out: complex64 [n_carriers][n_samples] -> the matched filter's output, same shape"""
-        iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(self.n_carriers, self.n_samples)
+        """host in, host out: [n_carriers][n_samples] in the plan's wire format (complex64; for cu8 / cs8 plans interleaved
+        bytes) -> the matched filter's output as complex64, same shape"""
+        if self.fmt in (FMT_CU8, FMT_CS8):
+            iq = np.ascontiguousarray(iq).view(np.uint8).reshape(self.n_carriers, 2 * self.n_samples)
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(self.n_carriers, self.n_samples)
         pitch = (self.n_samples + 1) & ~1
         din, dout = DeviceBuffer(self.device, iq.nbytes), DeviceBuffer(self.device, self.n_carriers * pitch * 8)
         try:

@@ -635,6 +635,7 @@ static int plan_select(tdm_plan *plan, double sample_rate, int64_t n)
 }
 
 static size_t fmt_bytes(int fmt) { return fmt == TDM_CU8 || fmt == TDM_CS8 ? 2 : (fmt == TDM_CF32 ? 8 : 16); }
+static int tetra_fmt8(int fmt) { return fmt == TDM_CU8 ? 1 : (fmt == TDM_CS8 ? 2 : 0); }   // the TETRA-mode kernels' FMT8
 
 static void sync_scratch_release(int device, hipStream_t st);   // (find_sync's per-stream scratch, below)
 
@@ -694,7 +695,7 @@ static int gardner_choose_pieces(tdm_plan *p, long long allow)
             const double cost = (double)g.n_v * (wgs > cus ? 1.18 : 1.0);
             if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best = g; }
         }
-    } else if (allow != 0 && per_cu >= 2 && debug_value("gardner_fused") != 0) {
+    } else if (allow != 0 && per_cu >= 2 && p->gardner_fused_ok == 1 && debug_value("gardner_fused") != 0) {   // (fused_ok: cf32 input; with per_cu >= 2 it does not depend on the row count)
         for (int K = 2; K <= 8 && (allow == 1 || K <= allow); K *= 2) {
             GardnerGeom g;
             if (!gardner_geometry(tp.n, tp.sps, p->gardner_ntaps_design, K, &g)) break;
@@ -812,7 +813,9 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
     p->mode = mode;
     if (mode == TDM_MODE_TETRA || mode == TDM_MODE_TETRA_GARDNER) {
         // channelised baseband in: sample_rate is the per-carrier rate, >= 2 samples per symbol
-        if (in_fmt != TDM_CF32) return fail(TDM_ERR_UNSUPPORTED, "TETRA mode takes cf32 channelised baseband");
+        // channelised baseband as cf32 (the channeliser's output), or straight off the wire as cu8 / cs8 (round 6: converted where
+        // the kernels stage their window; one bf16 plane per component in the fused receiver)
+        if (in_fmt == TDM_CF64) return fail(TDM_ERR_UNSUPPORTED, "TETRA mode takes cf32, cu8 or cs8 baseband");
         const double sps = sample_rate / kSymbolRate;
         if (sps < 2.0 || sps > 8.0) return fail(TDM_ERR_UNSUPPORTED, "TETRA mode needs 2..8 samples per symbol");
         if (n_samples < 64 || n_samples > (int64_t)kMaxTimingBlocks * kTimingBlock)
@@ -874,7 +877,8 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         if (mode == TDM_MODE_TETRA_GARDNER) {
             p->rows = n_carriers;
             p->device = device;
-            p->gardner_fused_ok = (debug_value("gardner_fused") != 0 && tetra_gardner_fused_available(tp.ntaps, n_carriers)) ? 1 : 0;
+            // (the fused Gardner kernel's producers read cf32; 8-bit input takes the three launches, whose matched filter converts)
+            p->gardner_fused_ok = (in_fmt == TDM_CF32 && debug_value("gardner_fused") != 0 && tetra_gardner_fused_available(tp.ntaps, n_carriers)) ? 1 : 0;
             p->gardner_ntaps_design = ntaps_design;
             {
                 // (no memory for the pieces' temporaries: the plan is made all the same and walks whole chunks)
@@ -1067,7 +1071,7 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
                 HIP_TRY(hipMalloc((void **)&plan->d_gy, (size_t)plan->rows * plan->gy_pitch * sizeof(float2)));
             if (three && (stages & 1)) {
                 HipBackend::Scope s(be, ST_TETRA_MF);
-                if (!tetra_mf_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))
+                if (!tetra_mf_launch(tp, plan->rows, iq, tetra_fmt8(plan->fmt), carrier_stride_samples, plan->d_gy, plan->gy_pitch, be.stream))
                     return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
             }
             if (three && (stages & 2)) {
@@ -1084,7 +1088,7 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
         {
             // one kernel: matched filter, timing, Farrow, carrier-offset estimate and decisions; one workgroup per carrier
             HipBackend::Scope s(be, ST_TETRA);
-            if (!tetra_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, hard, n_soft, best_phase,
+            if (!tetra_launch(tp, plan->rows, iq, tetra_fmt8(plan->fmt), carrier_stride_samples, (float2 *)soft, hard, n_soft, best_phase,
                               min_margin, be.stream, row_list, n_rows))
                 return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
         }
@@ -1136,7 +1140,7 @@ int tdm_plan_rrc_filter(tdm_plan *plan, const void *iq, int64_t carrier_stride_s
     be.timer = &plan->timer;
     {
         HipBackend::Scope s(be, ST_TETRA_MF);
-        if (!tetra_mf_launch(plan->tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)y, y_pitch, be.stream))
+        if (!tetra_mf_launch(plan->tp, plan->rows, iq, tetra_fmt8(plan->fmt), carrier_stride_samples, (float2 *)y, y_pitch, be.stream))
             return fail(TDM_ERR_UNSUPPORTED, "no RRC kernel instantiated for this tap count");
     }
     if (be.err != hipSuccess) return fail(TDM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(be.err));

@@ -7,24 +7,34 @@
 namespace tdm {
 
 
-bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, uint8_t *hard,
+bool tetra_launch(const TetraParams &tp, int rows, const void *x, int fmt8, int64_t in_stride, float2 *soft, uint8_t *hard,
                   int32_t *n_soft, int32_t *timing_milli, double *min_margin, hipStream_t stream, const int32_t *row_list,
                   const int32_t *n_rows)
 {
     switch (tp.ntaps) {
-#define TDM_RRC_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_fused<NT>), dim3(rows), dim3(kRrcThreads), 0, stream, x, in_stride, tp, soft, hard, n_soft, timing_milli, min_margin, row_list, n_rows); return true;
+#define TDM_RRC_ARGS dim3(rows), dim3(kRrcThreads), 0, stream, x, in_stride, tp, soft, hard, n_soft, timing_milli, min_margin, row_list, n_rows
+#define TDM_RRC_CASE(NT) case NT:                                                      \
+        if (fmt8 == 1) hipLaunchKernelGGL((k_tetra_fused<NT, 1>), TDM_RRC_ARGS);         \
+        else if (fmt8 == 2) hipLaunchKernelGGL((k_tetra_fused<NT, 2>), TDM_RRC_ARGS);    \
+        else hipLaunchKernelGGL((k_tetra_fused<NT, 0>), TDM_RRC_ARGS);                   \
+        return true;
         TDM_RRC_CASE(17) TDM_RRC_CASE(25) TDM_RRC_CASE(33) TDM_RRC_CASE(35) TDM_RRC_CASE(41) TDM_RRC_CASE(49) TDM_RRC_CASE(57) TDM_RRC_CASE(65)
 #undef TDM_RRC_CASE
+#undef TDM_RRC_ARGS
     default: return false;
     }
 }
 
-bool tetra_mf_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *y, int64_t y_pitch, hipStream_t stream)
+bool tetra_mf_launch(const TetraParams &tp, int rows, const void *x, int fmt8, int64_t in_stride, float2 *y, int64_t y_pitch, hipStream_t stream)
 {
     const int tiles = (tp.n + kMfTile - 1) / kMfTile;
     const dim3 grid((unsigned)((tiles + kMfTilesPerWg - 1) / kMfTilesPerWg), (unsigned)rows);
     switch (tp.ntaps) {
-#define TDM_MF_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_mf<NT>), grid, dim3(kMfThreads), 0, stream, x, in_stride, tp, y, y_pitch); return true;
+#define TDM_MF_CASE(NT) case NT:                                                                                                             \
+        if (fmt8 == 1) hipLaunchKernelGGL((k_tetra_mf<NT, 1>), grid, dim3(kMfThreads), 0, stream, x, in_stride, tp, y, y_pitch);              \
+        else if (fmt8 == 2) hipLaunchKernelGGL((k_tetra_mf<NT, 2>), grid, dim3(kMfThreads), 0, stream, x, in_stride, tp, y, y_pitch);         \
+        else hipLaunchKernelGGL((k_tetra_mf<NT, 0>), grid, dim3(kMfThreads), 0, stream, x, in_stride, tp, y, y_pitch);                        \
+        return true;
         TDM_MF_CASE(17) TDM_MF_CASE(25) TDM_MF_CASE(33) TDM_MF_CASE(35) TDM_MF_CASE(41) TDM_MF_CASE(49) TDM_MF_CASE(57) TDM_MF_CASE(65)
 #undef TDM_MF_CASE
     default: return false;

@@ -64,10 +64,23 @@ constexpr int kMfThreads = 256, kMfPer = 8, kMfTile = kMfThreads * kMfPer, kMfTi
 //   * ONE tile per workgroup: 0.371 ms = 5.79 TB/s = 0.72 of 8 TB/s.  (A workgroup walking 2 / 4 / 8 tiles with the next
 //     window in flight: 0.377 / 0.390 / 0.424 ms -- with seven workgroups per compute unit the dispatcher's interleaving
 //     hides the load phase better than a static walk does.)
-template <int NT>
-__global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restrict__ x, int64_t in_stride, const TetraParams P,
+// FMT8: 0 = cf32 input (above); 1 = cu8, 2 = cs8 (north_star: "coalesced complex-int8/float loads"): the window arrives as
+// 2-byte samples -- 10 instead of 16 bytes per sample through HBM -- and is converted where it is staged,
+// cu8 as pyrtlsdr and the channeliser do (u * fl(1/127.5) - 1 in fp32), cs8 as s / 128; everything behind the staging is the
+// cf32 kernel.  (2-byte loads, one per sample and thread: a row of bytes has no alignment to speak of, and at 2 of the
+// kernel's 10 bytes per sample the load instructions are not what bounds it.)
+template <int FMT8>
+__device__ __forceinline__ float2 mf_convert8(uint32_t h)   // low 16 bits: I, Q
+{
+    if (FMT8 == 1) return make_float2((float)(h & 255u) * (1.f / 127.5f) - 1.f, (float)((h >> 8) & 255u) * (1.f / 127.5f) - 1.f);
+    return make_float2((float)(int8_t)(h & 255u) * (1.f / 128.f), (float)(int8_t)((h >> 8) & 255u) * (1.f / 128.f));
+}
+
+template <int NT, int FMT8 = 0>
+__global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const void *__restrict__ x_, int64_t in_stride, const TetraParams P,
                                                          float2 *__restrict__ y, int64_t y_pitch)
 {
+    const float2 *x = (const float2 *)x_;
     constexpr int H = (NT - 1) / 2, W = kMfTile + NT - 1, WIN = kMfPer + NT - 1;   // WIN: samples under a thread's outputs
     constexpr int NLD = (W + kMfThreads - 1) / kMfThreads;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -76,6 +89,7 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
     auto slot = [](int s) { return s + 2 * (s >> 3); };
     const int row = blockIdx.y, tid = threadIdx.x, n = P.n;
     const float2 *xr = x + (int64_t)row * in_stride;
+    const uint16_t *xr8 = (const uint16_t *)x_ + (int64_t)row * in_stride;   // (FMT8: one 2-byte sample per element)
     float2 *yr = y + (int64_t)row * y_pitch;
     // a workgroup walks kMfTilesPerWg consecutive tiles with the NEXT tile's window already on its way from HBM while it
     // works on the current one: the memory pipes never wait for a workgroup's arithmetic phase
@@ -87,7 +101,16 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
     typedef f32x4 __attribute__((aligned(8))) f32x4_a8;   // (rows are 8-byte aligned: pitched channeliser rows)
     f32x4 vp[NLP];
     auto interior = [&](int base) { return base - H >= 0 && base - H + W <= n; };
+    uint32_t v8[NLD];   // (FMT8) the thread's samples of the window as they arrive
     auto fetch = [&](int base) {
+        if (FMT8) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int g = base - H + tid + k * kMfThreads;
+                v8[k] = xr8[min(max(g, 0), n - 1)];          // (unconditional, clamped: all of a thread's loads in flight at once)
+            }
+            return;
+        }
         if (interior(base)) {
             const f32x4_a8 *pb = (const f32x4_a8 *)(xr + (base - H));
 #pragma unroll
@@ -106,6 +129,14 @@ __global__ __launch_bounds__(kMfThreads) void k_tetra_mf(const float2 *__restric
         }
     };
     auto stage = [&](int base) {
+        if (FMT8) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + k * kMfThreads, g = base - H + i;
+                if (i < W) xs[slot(i)] = (g >= 0 && g < n) ? mf_convert8<FMT8>(v8[k]) : make_float2(0.f, 0.f);
+            }
+            return;
+        }
         if (interior(base)) {
 #pragma unroll
             for (int k = 0; k < NLP; ++k) {

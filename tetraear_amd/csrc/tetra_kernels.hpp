@@ -141,8 +141,24 @@ __device__ __forceinline__ void split_bf16(float a, float b, uint32_t &hi, uint3
     lo = pk_bf16(a - a1, b - b1);
 }
 
-template <int NT>
-__global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fused(const float2 *__restrict__ x, int64_t in_stride,
+// FMT8 (round 6; north_star: "coalesced complex-int8/float loads"): 0 = cf32 input; 1 = cu8, 2 = cs8 -- 2 bytes per sample
+// through HBM instead of 8 (algorithmic bytes per symbol at 4 samples/symbol: 17 instead of 41).  An 8-bit sample is EXACT in
+// one bf16 -- cu8 as the odd integer 2u - 255 (|.| <= 255: eight significant bits), cs8 as it is -- so the staged window has
+// ONE plane per component instead of a leading and a trailing one and the matched filter two matrix-core products per step
+// instead of four; the format's scale (1/255: x = u / 127.5 - 1 = (2u - 255) / 255; 1/128) multiplies the soft symbols where
+// they are stored -- everything between (timing statistic, estimates, interpolation) does not depend on the scale.
+template <int FMT8>
+struct TetraIn8 {
+    static constexpr float scale = FMT8 == 1 ? 1.f / 255.f : (FMT8 == 2 ? 1.f / 128.f : 1.f);
+    __device__ __forceinline__ static float2 conv(uint32_t h)   // low 16 bits: I, Q -> the integers the filter runs on
+    {
+        if (FMT8 == 1) return make_float2(fmaf((float)(h & 255u), 2.f, -255.f), fmaf((float)((h >> 8) & 255u), 2.f, -255.f));   // (v_cvt_f32_ubyteN + one fma: exact)
+        return make_float2((float)(int8_t)(h & 255u), (float)(int8_t)((h >> 8) & 255u));
+    }
+};
+
+template <int NT, int FMT8 = 0>
+__global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fused(const void *__restrict__ x_, int64_t in_stride,
                                                               const TetraParams P, float2 *__restrict__ soft,
                                                               uint8_t *__restrict__ hard, int32_t *n_soft,
                                                               int32_t *timing_milli, double *min_margin,
@@ -181,7 +197,8 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     const int tid = threadIdx.x;
     const int n = P.n;
     const double sps = P.sps;
-    const float2 *xr = x + (int64_t)row * in_stride;     // rows of the channeliser may carry a pitch
+    const float2 *xr = (const float2 *)x_ + (int64_t)row * in_stride;     // rows of the channeliser may carry a pitch
+    const uint16_t *xr8 = (const uint16_t *)x_ + (int64_t)row * in_stride;   // (FMT8: one 2-byte sample per element)
     float2 *sr = soft + (int64_t)row * P.max_soft;
     const int nb = (n + kTimingBlock - 1) / kTimingBlock;
     const int ntiles = (n + kRrcTile - 1) / kRrcTile;
@@ -200,10 +217,30 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     static_assert(NS / 2 - (NP - 1) * kRrcThreads <= 64, "the pairs of the last turn lie in wavefront 0");
     const bool last_turn = wv == 0;
     const int gmaxp = n - 2;                              // last pair start inside the chunk
-    const float2 x_first = xr[0], x_last = xr[n - 1];
+    const float2 x_first = FMT8 ? make_float2(0.f, 0.f) : xr[0], x_last = FMT8 ? make_float2(0.f, 0.f) : xr[n - 1];
     f32x4 pf[NP];
+    uint32_t pf8[NP];   // (FMT8) a pair of consecutive samples as it arrives: low half the first
     auto fetch = [&](int tile) {
         const int g0 = tile * kRrcTile - H2;
+        if (FMT8) {
+            if (g0 >= 0 && g0 + 2 * (NP * kRrcThreads - 1) + 1 <= n - 1 && (((uintptr_t)(xr8 + g0)) & 3) == 0) {
+                // an inner tile whose pairs are 4-byte aligned: one load per pair
+                const uint32_t *pb = (const uint32_t *)(xr8 + g0);
+#pragma unroll
+                for (int j = 0; j < NP - 1; ++j) pf8[j] = __builtin_nontemporal_load(pb + tid + j * kRrcThreads);
+                if (last_turn) pf8[NP - 1] = __builtin_nontemporal_load(pb + tid + (NP - 1) * kRrcThreads);
+                return;
+            }
+            // else two 2-byte loads per pair from clamped positions (a row of bytes has no alignment to speak of); stage() masks
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                if (j == NP - 1 && !last_turn) break;
+                const int g = g0 + 2 * (tid + j * kRrcThreads);
+                const uint32_t a = xr8[min(max(g, 0), n - 1)], b = xr8[min(max(g + 1, 0), n - 1)];
+                pf8[j] = a | (b << 16);
+            }
+            return;
+        }
         if (g0 >= 0 && g0 + 2 * (NP * kRrcThreads - 1) <= gmaxp) {
             // an inner tile: nothing to clamp, one scalar base and the thread's own offset (no vector address arithmetic)
             const f32x4_a8 *pb = (const f32x4_a8 *)(xr + g0);
@@ -231,6 +268,20 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
     };
     auto stage = [&](int tile) __attribute__((always_inline)) {
         const int g0 = tile * kRrcTile - H2;       // chunk position of the first pair
+        if (FMT8) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                if (j == NP - 1 && !last_turn) break;
+                const int idx = tid + j * kRrcThreads, g = g0 + 2 * idx;
+                const float2 e0 = (g >= 0 && g < n) ? TetraIn8<FMT8>::conv(pf8[j]) : make_float2(0.f, 0.f);
+                const float2 e1 = (g + 1 >= 0 && g + 1 < n) ? TetraIn8<FMT8>::conv(pf8[j] >> 16) : make_float2(0.f, 0.f);
+                if (j < NP - 1 || idx < NS / 2) {   // one plane per component: the integers are exact in bf16
+                    xsb[idx] = pk_bf16(e0.x, e1.x);
+                    xsb[2 * PLANE + idx] = pk_bf16(e0.y, e1.y);
+                }
+            }
+            return;
+        }
         if (g0 >= 0 && g0 + NS <= gmaxp) {         // every pair of the tile lies inside the chunk: no masks
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -369,10 +420,12 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                 const bf16x8 r1 = __builtin_bit_cast(bf16x8, ab[o]), r2 = __builtin_bit_cast(bf16x8, ab[PLANE / 4 + o]);
                 const bf16x8 i1 = __builtin_bit_cast(bf16x8, ab[2 * (PLANE / 4) + o]), i2 = __builtin_bit_cast(bf16x8, ab[3 * (PLANE / 4) + o]);
                 const bf16x8 h1 = __builtin_bit_cast(bf16x8, hB1[s]), h2 = __builtin_bit_cast(bf16x8, hB2[s]);
-                cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2, h2, cre[bb], 0, 0, 0);   // (smallest terms first)
-                cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i2, h2, cim[bb], 0, 0, 0);
-                cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2, h1, cre[bb], 0, 0, 0);
-                cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i2, h1, cim[bb], 0, 0, 0);
+                if (!FMT8) {   // (8-bit input: no trailing halves)
+                    cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2, h2, cre[bb], 0, 0, 0);   // (smallest terms first)
+                    cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i2, h2, cim[bb], 0, 0, 0);
+                    cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2, h1, cre[bb], 0, 0, 0);
+                    cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i2, h1, cim[bb], 0, 0, 0);
+                }
                 cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r1, h2, cre[bb], 0, 0, 0);
                 cim[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i1, h2, cim[bb], 0, 0, 0);
                 cre[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r1, h1, cre[bb], 0, 0, 0);
@@ -591,7 +644,11 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
             float2 *so = sr + (kb - k_lo);   // (uniform base, the thread's own offset)
 #pragma unroll
             for (int u = 0; u < SU; ++u)
-                if (kb + off + u * TSYM < k_end) so[off + u * TSYM] = farrow_eval(f[u]);
+                if (kb + off + u * TSYM < k_end) {
+                    float2 sv = farrow_eval(f[u]);
+                    if (FMT8) { sv.x *= TetraIn8<FMT8>::scale; sv.y *= TetraIn8<FMT8>::scale; }
+                    so[off + u * TSYM] = sv;
+                }
         }
         if (any_direct) {
             // the timing estimate has carried some instants out of the ring (more than 48 symbols from their nominal
@@ -614,7 +671,7 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                     for (int k2 = -3; k2 < NT; ++k2) {
                         const int idx = first + k2 + 3;
                         float2 q3 = make_float2(0.f, 0.f);
-                        if (idx >= 0 && idx < n) q3 = xr[idx];
+                        if (idx >= 0 && idx < n) q3 = FMT8 ? TetraIn8<FMT8>::conv(xr8[idx]) : xr[idx];
                         if (k2 >= 0) {   // tap k2 multiplies x[first + k2 + e] for output e
                             const float h = P.taps[k2];
                             a0x = fmaf(h, q0.x, a0x); a0y = fmaf(h, q0.y, a0y);
@@ -630,7 +687,9 @@ __global__ __launch_bounds__(kRrcThreads, TDM_TETRA_WAVES(NT)) void k_tetra_fuse
                     f.y0 = make_float2(a1x, a1y);
                     f.y1 = make_float2(a2x, a2y);
                     f.y2 = make_float2(a3x, a3y);
-                    sr[k - k_lo] = farrow_eval(f);
+                    float2 sv = farrow_eval(f);
+                    if (FMT8) { sv.x *= TetraIn8<FMT8>::scale; sv.y *= TetraIn8<FMT8>::scale; }
+                    sr[k - k_lo] = sv;
                 }
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)

@@ -47,13 +47,15 @@ struct TetraParams {
 // one launch of the fused receiver on `rows` carriers; returns false when no kernel is instantiated for tp.ntaps
 // row_list / n_rows (device, or null): the launch covers the rows listed -- workgroup i takes row row_list[i], workgroups
 // past *n_rows leave at once -- instead of all `rows`
-bool tetra_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, uint8_t *hard,
+// fmt8: 0 cf32 input, 1 cu8, 2 cs8 (tetra_kernels.hpp TetraIn8)
+bool tetra_launch(const TetraParams &tp, int rows, const void *x, int fmt8, int64_t in_stride, float2 *soft, uint8_t *hard,
                   int32_t *n_soft, int32_t *timing_milli, double *min_margin, hipStream_t stream, const int32_t *row_list = nullptr,
                   const int32_t *n_rows = nullptr);
 
 // TDM_MODE_TETRA_GARDNER (tetra_gardner_kernels.hpp): the three launches, each on its own so that the caller can time them.
 // y: [rows][y_pitch] cf32 matched-filter output (y_pitch even, >= tp.n); false when no kernel is instantiated for tp.ntaps
-bool tetra_mf_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *y, int64_t y_pitch, hipStream_t stream);
+// fmt8: 0 cf32 input, 1 cu8, 2 cs8 (converted where the window is staged)
+bool tetra_mf_launch(const TetraParams &tp, int rows, const void *x, int fmt8, int64_t in_stride, float2 *y, int64_t y_pitch, hipStream_t stream);
 void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y, int64_t y_pitch, float2 *soft, int32_t *n_soft,
                                int32_t *timing_milli, hipStream_t stream);
 // the matched filter and the loop in ONE kernel (the filter output stays in LDS); false when not instantiated for tp.ntaps
