@@ -1,5 +1,6 @@
 """Randomised TETRA-mode sweep on the GPU: random chunk lengths, sample rates (2..8 samples/symbol), row
-strides; clean pi/4-DQPSK at 25 dB must come back error-free and equal to the fp64 definition's decisions."""
+strides, wire formats (cf32; since round 6 cu8 / cs8 at a quarter of full scale, the definition evaluated on the samples the
+bytes mean); clean pi/4-DQPSK at 25 dB must come back error-free and equal to the fp64 definition's decisions."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -22,9 +23,25 @@ while time.time() - t0 < budget:
         x = x + np.sqrt(sps / 10 ** 2.5 / 2) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
         x = x * np.exp(2j * np.pi * float(rng.uniform(-100, 100)) * np.arange(n) / fs)
         xs.append(x.astype(np.complex64)); dibs.append(d)
-    bd = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA)
-    buf = np.full((rows, pitch), 9.0, dtype=np.complex64)
-    for r in range(rows): buf[r, :n] = xs[r]
+    fmt = str(rng.choice(["cf32", "cf32", "cu8", "cs8"]))
+    if fmt != "cf32":
+        buf = np.full((rows, 2 * pitch), 9, dtype=np.uint8 if fmt == "cu8" else np.int8)
+        for r in range(rows):
+            x = xs[r].astype(np.complex128)
+            x = x / (4.0 * np.max(np.abs(x)))
+            if fmt == "cu8":
+                raw = synth.quantise_cu8(x, scale=1.0)
+                xs[r] = synth.cu8_to_c128(raw)
+            else:
+                raw = np.empty(2 * n, dtype=np.int8)
+                raw[0::2] = np.clip(np.rint(128 * x.real), -128, 127); raw[1::2] = np.clip(np.rint(128 * x.imag), -128, 127)
+                xs[r] = (raw[0::2].astype(np.float64) + 1j * raw[1::2].astype(np.float64)) / 128.0
+            buf[r, :2 * n] = raw
+        fmts = fmts + 1 if "fmts" in dir() else 1
+    else:
+        buf = np.full((rows, pitch), 9.0, dtype=np.complex64)
+        for r in range(rows): buf[r, :n] = xs[r]
+    bd = BatchDemodulator(fs, n, rows, fmt, mode=MODE_TETRA)
     ms = bd.info.max_soft
     hard = np.zeros((rows, ms), np.uint8); soft = np.zeros((rows, ms), np.complex64); ns = np.zeros(rows, np.int32)
     check(bd.lib.tdm_process(bd.handle, ptr(buf), pitch, None, None, ptr(hard), ptr(soft), ptr(ns), None, None))
@@ -48,4 +65,4 @@ while time.time() - t0 < budget:
         if not ok:
             bad += 1; print("MISMATCH", fs, n, rows, pitch, ns[r], info["n_sym"], float(np.mean(h != rh)) if len(h) == len(rh) else -1)
     bd.close()
-print(f"{cnt} carriers, {bad} mismatches" + (f", {edge} end-of-chunk boundary cases (symbol count differs by one)" if "edge" in dir() else ""))
+print(f"{cnt} carriers ({fmts if 'fmts' in dir() else 0} plans on 8-bit input), {bad} mismatches" + (f", {edge} end-of-chunk boundary cases (symbol count differs by one)" if "edge" in dir() else ""))
