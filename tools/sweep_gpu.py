@@ -1,4 +1,6 @@
-"""Randomised length / rate sweep on the GPU: SignalProcessor.process_cu8 vs the C oracle."""
+"""Randomised length / rate sweep on the GPU: SignalProcessor.process_cu8 vs the C oracle; since round 6 one case in ten goes
+through process() as complex128 / complex64 with a NaN or an Inf put somewhere into the chunk (the reference's all-NaN chunk
+wherever a zero-phase filter runs: tests/test_nonfinite.py)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -20,6 +22,25 @@ while time.time() - t0 < budget:
     ref = OracleSignalProcessor(fs)
     r = ref.process(x, f)
     p = procs.setdefault(fs, SignalProcessor(fs))
+    if rng.random() < 0.1 and n > 1:
+        xx = x.astype(np.complex64) if rng.random() < 0.3 else x.copy()
+        for _ in range(int(rng.integers(1, 3))):
+            v = [np.nan, np.inf, -np.inf, complex(0.5, np.nan), complex(np.inf, -1.0)][int(rng.integers(5))]
+            xx[int(rng.integers(n))] = v
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = ref.process(xx.astype(np.complex128), f)
+            h = p.process(xx, freq_offset=f)
+        cnt += 1; nonfinite = nonfinite + 1 if "nonfinite" in dir() else 1
+        a, b = np.asarray(p.symbols, dtype=complex), np.asarray(ref.symbols, dtype=complex)
+        ok = len(h) == len(r) and np.array_equal(h, r) and len(a) == len(b) and np.array_equal(np.isnan(a.real), np.isnan(b.real)) and np.array_equal(np.isnan(a.imag), np.isnan(b.imag))
+        if ok and len(b) and np.isfinite(b).any():
+            fin = np.isfinite(b)
+            ok = np.array_equal(np.isfinite(a), fin) and np.max(np.abs(a[fin] - b[fin])) <= (5e-5 if xx.dtype == np.complex64 else 1e-10) * max(np.max(np.abs(b[fin])), 1e-300)
+        if not ok:
+            bad += 1; print("MISMATCH (non-finite)", fs, n, f, xx.dtype, len(h), len(r))
+        continue
     h = p.process_cu8(u8, freq_offset=f); cnt += 1
     ok = len(h) == len(r) and np.array_equal(h, r) and len(p.symbols) == len(ref.symbols)
     if ok and len(ref.symbols):
@@ -27,4 +48,4 @@ while time.time() - t0 < budget:
         ok = np.max(np.abs(p.symbols - ref.symbols)) <= 1e-10 * sc
     if not ok:
         bad += 1; print("MISMATCH", fs, n, f, len(h), len(r))
-print(f"{cnt} cases, {bad} mismatches")
+print(f"{cnt} cases ({nonfinite if 'nonfinite' in dir() else 0} of them with non-finite samples), {bad} mismatches")
