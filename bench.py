@@ -1219,6 +1219,21 @@ def leg_tetra_int8(rows, base, steps):
             bd.enqueue()
         ms = bd.time_end() / steps
         outs[fmt] = (ms, bd.stage_times(), bd.download())
+        if fmt == "cu8":
+            # the RRC stage alone on the bytes: 2 B in + 8 B out per sample
+            from tetraear_amd.batch import DeviceBuffer
+            pitch = (n + 1) & ~1
+            ybuf = DeviceBuffer(0, rows * pitch * 8)
+            try:
+                for _ in range(max(25, steps)):
+                    bd.enqueue_rrc_filter(ybuf, pitch)
+                bd.sync()
+                bd.time_begin()
+                for _ in range(steps):
+                    bd.enqueue_rrc_filter(ybuf, pitch)
+                rrc8_ms = bd.time_end() / steps
+            finally:
+                ybuf.free()
         bd.close()
     ms8, st8, (h8, s8, n8, t8, m8) = outs["cu8"]
     msf, stf, (hf, sf, nf, tf, mf) = outs["cf32"]
@@ -1232,6 +1247,8 @@ def leg_tetra_int8(rows, base, steps):
             "ms_per_step": ms8, "value": nsym / (ms8 * 1e-3) / 1e6, "unit": "Msym/s", "cf32_on_the_same_samples_ms_per_step": msf,
             "output_check": {"against": "the cf32 kernel on the dequantised samples (u / 127.5 - 1), every row", "soft_max_err_rel": err,
                              "status": "decisions equal to the cf32 kernel's on the same samples, soft within 1e-5" if (same and err < 1e-5) else "DIFFERS from the cf32 kernel"},
+            "rrc_stage": hbm_roofline("k_tetra_mf<33, cu8> (the RRC stage alone on cu8 input: bytes converted where the window is staged, cf32 out)",
+                                      rows * n * 10, rrc8_ms, read_bytes=rows * n * 2, bytes_per_sample=10),
             "roofline": hbm_roofline("k_tetra_fused<33, cu8>", bytes_alg, k_ms, read_bytes=rows * n * 2, bytes_per_symbol=bytes_alg / max(nsym, 1),
                                      note="2 + 2.25 algorithmic bytes per input sample: with a quarter of the input bytes the kernel is bound by "
                                           "instruction issue, not by HBM -- the fraction is reported all the same")}
