@@ -1246,6 +1246,10 @@ int tdm_process_pipelined(tdm_plan *plan, const void *iq, int64_t n_batches, con
     if (!plan->cur) return fail(TDM_ERR_INVALID, "plan has no current length");
     const RefPlanHost &h = plan->h();
     const int rows = plan->rows;
+    // (a batch's input: one row per plan row, or one per rows_per_chunk of them -- the rows of a time-batched plan carry
+    //  pre-shifts, which this entry point does not take: such a plan goes through tdm_process)
+    if (plan->mode == TDM_MODE_REFERENCE && plan->rows_per_chunk > 1)
+        return fail(TDM_ERR_UNSUPPORTED, "tdm_process_pipelined: the plan has rows_per_chunk > 1 (use tdm_process / tdm_process_device)");
     const size_t in_bytes = (size_t)rows * h.n * fmt_bytes(plan->fmt);
     const size_t soft_elem = plan->mode != TDM_MODE_REFERENCE ? 2 * sizeof(float) : 2 * sizeof(double);
     const size_t hard_bytes = (size_t)rows * h.max_soft, soft_bytes = (size_t)rows * h.max_soft * soft_elem;
