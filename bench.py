@@ -863,7 +863,24 @@ def leg_single(carriers, steps, warmup):
     hard, soft, n_soft, bp, mm = bd.download()
     bd.close()
     nsym = int(np.maximum(n_soft - 1, 0).sum())
+    # the drop-in call itself, host arrays in and out (PCIe and the Python shim included; never `value`): what a caller of
+    # tetraear.signal.SignalProcessor.process sees per 262144-sample read
+    from tetraear_amd import synth
+    from tetraear_amd.signal import SignalProcessor
+    sp = SignalProcessor(SAMPLE_RATE)
+    u8 = np.ascontiguousarray(iq[:2 * 262144])
+    x128 = synth.cu8_to_c128(u8)
+    host = {}
+    for name, call in (("process_complex128", lambda: sp.process(x128, float(foffs[0]))), ("process_cu8", lambda: sp.process_cu8(u8, float(foffs[0])))):
+        for _ in range(5):
+            out = call()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            out = call()
+        host[name + "_ms_per_call"] = (time.perf_counter() - t0) / 30 * 1e3
+        host[name + "_symbols"] = int(len(out))
     return {"workload": f"{carriers} carrier x 262144 cu8 samples @2.4 MS/s", "ms_per_step": ms, "value": nsym / (ms * 1e-3) / 1e6,
+            "host_call": host,
             "unit": "Msym/s", "x_realtime": (262144 / SAMPLE_RATE) / (ms * 1e-3), "plan_create_ms": create_ms,
             "plan_resize_ms": {"new_length": resize_new_ms, "seen_length": resize_seen_ms},
             "ms_per_step_staged": ms_staged, "stage_ms_per_launch": st,
