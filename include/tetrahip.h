@@ -118,7 +118,8 @@ TDM_API int tdm_debug_get(const char *key, int64_t *value);
  * (processor.py:78, :254).  n_carriers independent streams are processed per call.
  * in_fmt: reference mode takes all four wire formats; the TETRA modes take TDM_CF32 (the channeliser's output) or
  * TDM_CU8 / TDM_CS8 straight off the wire (converted where the kernels stage their window: cu8 as u / 127.5 - 1, cs8 as s / 128;
- * TDM_MODE_TETRA_GARDNER then runs as three launches, whole chunks).                        */
+ * TDM_MODE_TETRA_GARDNER's fused kernel takes bytes at 33 and 35 taps -- 72 and 80 kS/s --, other rates run as three launches,
+ * whole chunks).                                                                            */
 TDM_API int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, int32_t in_fmt,
                     int32_t mode, int32_t device, tdm_plan **out);
 TDM_API int tdm_plan_destroy(tdm_plan *plan);

@@ -653,16 +653,27 @@ def test_gpu_tetra_int8_input_matches_definition_on_the_dequantised_samples():
         ref_hard, _, info = tetra_np.demod(xqs[r], fs)
         assert ns[r] == info["n_sym"]
         np.testing.assert_array_equal(hard[r, :ns[r] - 1], ref_hard)
-    # the Gardner mode on bytes: three launches (whole chunks), decisions as the definition's loop
-    fs, n, rows = 72000.0, 12000, 4
-    sig = [make_signal(n, fs, 950 + r, 0.07 * r - 0.1, 30.0, 22.0) for r in range(rows)]
-    raws, xqs = zip(*[_quantise8(s[0].astype(np.complex128), "cu8") for s in sig])
-    bd = BatchDemodulator(fs, n, rows, "cu8", mode=MODE_TETRA_GARDNER)
-    assert bd.info.gardner_segments == 1
-    hards, softs, timing, margin = bd.process(np.concatenate(raws))
-    bd.close()
-    for r in range(rows):
-        ref_hard, _, info = tetra_np.demod_gardner(xqs[r], fs)
-        assert abs(len(softs[r]) - len(info["t"])) <= 1
-        m = min(len(hards[r]), len(ref_hard))
-        assert np.mean(hards[r][:m] != ref_hard[:m]) <= 1e-3, r
+    # the Gardner mode on bytes: 33 taps -> the fused kernel (its producers convert), chunks in pieces as for cf32; 65 taps -> the
+    # three launches (the stand-alone matched filter converts), whole chunks; decisions as the definition's loop evaluated the
+    # same way
+    for fs, n, want_pieces in ((72000.0, 12000, 4), (144000.0, 12000, 1)):
+        rows = 4
+        sig = [make_signal(n, fs, 950 + r, 0.07 * r - 0.1, 30.0, 22.0) for r in range(rows)]
+        raws, xqs = zip(*[_quantise8(s[0].astype(np.complex128), "cu8") for s in sig])
+        bd = BatchDemodulator(fs, n, rows, "cu8", mode=MODE_TETRA_GARDNER)
+        K = int(bd.info.gardner_segments)
+        assert K == want_pieces, (fs, K)
+        hards, softs, timing, margin = bd.process(np.concatenate(raws))
+        bd.close()
+        bf = BatchDemodulator(fs, n, rows, "cf32", mode=MODE_TETRA_GARDNER)
+        assert int(bf.info.gardner_segments) == K
+        hf, sf, tf, mf = bf.process(np.concatenate([q.astype(np.complex64) for q in xqs]))
+        bf.close()
+        for r in range(rows):
+            ref_hard, _, info = tetra_np.demod_gardner(xqs[r], fs, segments=K)
+            assert abs(len(softs[r]) - len(info["t"])) <= 1
+            m = min(len(hards[r]), len(ref_hard))
+            assert np.mean(hards[r][:m] != ref_hard[:m]) <= 1e-3, (fs, r)
+            # the same samples as cf32 through the same kernels: the same decisions, soft symbols within fp32 rounding
+            assert len(hf[r]) == len(hards[r]) and np.array_equal(hf[r], hards[r]), (fs, r)
+            assert np.max(np.abs(sf[r] - softs[r])) <= 2e-5 * np.max(np.abs(sf[r])), (fs, r)

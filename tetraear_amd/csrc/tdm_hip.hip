@@ -695,7 +695,7 @@ static int gardner_choose_pieces(tdm_plan *p, long long allow)
             const double cost = (double)g.n_v * (wgs > cus ? 1.18 : 1.0);
             if (cost < 0.9 * best_cost) { best_cost = cost; best_k = K; best = g; }
         }
-    } else if (allow != 0 && per_cu >= 2 && p->gardner_fused_ok == 1 && debug_value("gardner_fused") != 0) {   // (fused_ok: cf32 input; with per_cu >= 2 it does not depend on the row count)
+    } else if (allow != 0 && per_cu >= 2 && p->gardner_fused_ok == 1 && debug_value("gardner_fused") != 0) {   // (fused_ok: with per_cu >= 2 it depends on the tap count and the wire format, not on the row count)
         for (int K = 2; K <= 8 && (allow == 1 || K <= allow); K *= 2) {
             GardnerGeom g;
             if (!gardner_geometry(tp.n, tp.sps, p->gardner_ntaps_design, K, &g)) break;
@@ -877,8 +877,9 @@ int tdm_plan_create(double sample_rate, int64_t n_samples, int32_t n_carriers, i
         if (mode == TDM_MODE_TETRA_GARDNER) {
             p->rows = n_carriers;
             p->device = device;
-            // (the fused Gardner kernel's producers read cf32; 8-bit input takes the three launches, whose matched filter converts)
-            p->gardner_fused_ok = (in_fmt == TDM_CF32 && debug_value("gardner_fused") != 0 && tetra_gardner_fused_available(tp.ntaps, n_carriers)) ? 1 : 0;
+            // (8-bit input: the fused kernel is instantiated for 33 and 35 taps; other tap counts take the three launches, whose
+            //  matched filter converts)
+            p->gardner_fused_ok = (debug_value("gardner_fused") != 0 && tetra_gardner_fused_available(tp.ntaps, n_carriers, tetra_fmt8(in_fmt))) ? 1 : 0;
             p->gardner_ntaps_design = ntaps_design;
             {
                 // (no memory for the pieces' temporaries: the plan is made all the same and walks whole chunks)
@@ -1041,7 +1042,7 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
                 S.ff_first = plan->gardner_ff_first;
                 {
                     HipBackend::Scope s(be, ST_TETRA_LOOP);
-                    fused_done = tetra_gardner_fused_launch(plan->gtp, K * R, (const float2 *)iq, carrier_stride_samples, plan->d_gsoft,
+                    fused_done = tetra_gardner_fused_launch(plan->gtp, K * R, iq, tetra_fmt8(plan->fmt), carrier_stride_samples, plan->d_gsoft,
                                                             plan->d_gint, plan->d_gint + (size_t)K * R, be.stream, &S);
                 }
                 if (fused_done) {
@@ -1061,7 +1062,7 @@ static int process_device_impl(tdm_plan *plan, const void *iq, int64_t carrier_s
                 HipBackend::Scope s(be, ST_TETRA_LOOP);
                 GardnerSeg S{};
                 S.ff_first = plan->gardner_ff_first;
-                fused_done = tetra_gardner_fused_launch(tp, plan->rows, (const float2 *)iq, carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream,
+                fused_done = tetra_gardner_fused_launch(tp, plan->rows, iq, tetra_fmt8(plan->fmt), carrier_stride_samples, (float2 *)soft, n_soft, best_phase, be.stream,
                                                         S.ff_first ? &S : nullptr);
             }
             if (plan->gardner_ff_first && !fused_done)

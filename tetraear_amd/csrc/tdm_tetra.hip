@@ -74,10 +74,11 @@ static const void *gardner_fused_kernel(int ntaps)
 // With two per unit it stays ahead of the three launches at any size (4096 / 8192 / 16 384 carriers at 4 samples per
 // symbol: 1.35 / 1.86 / 3.51 ms against 1.85 / 2.4 / 3.57); with one per unit only while the launch is a single round (the
 // loop on its own needs 33 KB and runs four workgroups per unit: 8192 carriers at 8 samples per symbol 1.96 ms).
-bool tetra_gardner_fused_available(int ntaps, int rows)
+bool tetra_gardner_fused_available(int ntaps, int rows, int fmt8)
 {
     const void *fn = gardner_fused_kernel(ntaps);
     if (!fn) return false;
+    if (fmt8 && ntaps != 33 && ntaps != 35) return false;   // (tetra_gardner_fused_launch: the 8-bit instantiations)
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return true;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kGWaves, 0) != hipSuccess || per_cu < 1) return true;
@@ -92,12 +93,24 @@ int tetra_gardner_fused_per_cu(int ntaps)
     return per_cu;
 }
 
-bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
+bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const void *x_, int fmt8, int64_t in_stride, float2 *soft, int32_t *n_soft,
                                 int32_t *timing_milli, hipStream_t stream, const GardnerSeg *seg)
 {
     const GardnerSeg S = seg ? *seg : GardnerSeg{};
     const GardnerConsts G = gardner_gains();
     const dim3 grid((unsigned)((rows + kGQuads - 1) / kGQuads)), block(64 * kGWaves);
+    const float2 *x = (const float2 *)x_;
+    if (fmt8) {   // 8-bit input: the tap counts of 4 and 4.44 samples per symbol (72 / 80 kS/s) -- the others take the three launches
+        switch (tp.ntaps) {
+#define TDM_GF8_CASE(NT) case NT:                                                                                                                  \
+            if (fmt8 == 1) hipLaunchKernelGGL((k_tetra_gardner<NT, 1>), grid, block, 0, stream, x, in_stride, tp, G, rows, soft, n_soft, timing_milli, S); \
+            else hipLaunchKernelGGL((k_tetra_gardner<NT, 2>), grid, block, 0, stream, x, in_stride, tp, G, rows, soft, n_soft, timing_milli, S);           \
+            return true;
+            TDM_GF8_CASE(33) TDM_GF8_CASE(35)
+#undef TDM_GF8_CASE
+        default: return false;
+        }
+    }
     switch (tp.ntaps) {
 #define TDM_GF_CASE(NT) case NT: hipLaunchKernelGGL((k_tetra_gardner<NT>), grid, block, 0, stream, x, in_stride, tp, G, rows, soft, n_soft, timing_milli, S); return true;
         TDM_GF_CASE(17) TDM_GF_CASE(25) TDM_GF_CASE(33) TDM_GF_CASE(35) TDM_GF_CASE(41) TDM_GF_CASE(49) TDM_GF_CASE(57) TDM_GF_CASE(65)

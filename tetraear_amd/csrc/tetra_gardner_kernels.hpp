@@ -266,17 +266,25 @@ constexpr int kQuadOtherPair = 0x4E;         // [2, 3, 0, 1]
 // the producers' ~350 instructions per chunk (33 taps) fit there many times over.  Hand-over at the loop's block boundaries through
 // ONE workgroup barrier per block (no polling): the producers publish how many chunks are complete, the loop how far it has
 // moved on; every wavefront passes the same barriers and leaves after the one at which `done` was set.
-template <int NT>
+// FMT8 (fused form only; round 6): 0 = cf32 input, 1 = cu8, 2 = cs8 -- the producers fetch 2-byte samples and convert them where
+// they write their window (mf_convert8); everything behind the window is the cf32 kernel.
+template <int NT, int FMT8 = 0>
 __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(const float2 *__restrict__ y, int64_t y_pitch, const TetraParams P,
                                                       const GardnerConsts G, int rows, float2 *__restrict__ soft,
                                                       int32_t *__restrict__ n_soft, int32_t *__restrict__ timing_milli, const GardnerSeg S)
 {
     constexpr bool FUSED = NT > 0;
+    static_assert(FUSED || FMT8 == 0, "the loop alone reads the matched filter's cf32 output");
     // input row of (virtual) carrier v: second halves start seg_off samples into their carrier's row
     auto row_in = [&](int v) {
         v = min(v, rows - 1);
         const int h = S.pieces > 0 ? v / S.rows_phys : 0;     // the piece
         return y + (int64_t)(v - h * S.rows_phys) * y_pitch + (int64_t)h * S.seg_step;
+    };
+    auto row_in8 = [&](int v) {                               // (FMT8: the same row as 2-byte samples)
+        v = min(v, rows - 1);
+        const int h = S.pieces > 0 ? v / S.rows_phys : 0;
+        return (const uint16_t *)y + (int64_t)(v - h * S.rows_phys) * y_pitch + (int64_t)h * S.seg_step;
     };
     constexpr int kGRing = GardnerRing<FUSED>::slots, kGPitch = GardnerRing<FUSED>::pitch;
     __shared__ float2 ring[kGQuads * kGPitch];      // sample g of a carrier in slot g mod kGRing of its row (33 KB; fused: 66 KB)
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
             const int n = P.n, j = lane >> 3, gI = lane & 7, car0 = 8 * (wave - 1);
             float2 *xw = xwin + (wave - 1) * 8 * GW::pitch;
             const float2 *xrow[GW::loads];              // this lane's pair of every load, in chunk 0's window
+            const uint16_t *xrow8[GW::loads];           // (FMT8) the carrier's sample 0
             int xcar[GW::loads], xpr[GW::loads];
 #pragma unroll
             for (int k = 0; k < GW::loads; ++k) {
@@ -316,13 +325,25 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
                 xcar[k] = f / GW::pairs;
                 xpr[k] = f - xcar[k] * GW::pairs;
                 xrow[k] = row_in((int)blockIdx.x * kGQuads + car0 + xcar[k]) + 2 * xpr[k] - GW::H;
+                xrow8[k] = row_in8((int)blockIdx.x * kGQuads + car0 + xcar[k]);
             }
             float2 *myring = ring + (car0 + j) * kGPitch;
             // the window of the NEXT chunk is requested while this chunk's arithmetic runs (a chunk's 2 us of load latency
             // would otherwise be paid 512 times in a row: the producers, not the loop, set the pace above 4 samples per symbol)
             f32x4 pf[GW::loads];
+            uint32_t pf8[GW::loads];   // (FMT8) a pair of samples as it arrives
             auto inside = [&](int cn) { return kGChunk * cn - GW::H >= 0 && kGChunk * cn - GW::H + GW::W <= n; };
             auto issue = [&](int cn) {
+                if (FMT8) {
+                    // two 2-byte loads per pair from clamped positions, every chunk alike (masked where they are written)
+#pragma unroll
+                    for (int k = 0; k < GW::loads; ++k) {
+                        const int ga = kGChunk * cn - GW::H + 2 * xpr[k];
+                        const uint32_t a = xrow8[k][min(max(ga, 0), n - 1)], b = xrow8[k][min(max(ga + 1, 0), n - 1)];
+                        pf8[k] = a | (b << 16);
+                    }
+                    return;
+                }
                 if (inside(cn)) {
 #pragma unroll
                     for (int k = 0; k < GW::loads; ++k) pf[k] = __builtin_nontemporal_load((const f32x4_a8 *)(xrow[k] + kGChunk * cn));
@@ -336,7 +357,17 @@ __global__ __launch_bounds__(NT > 0 ? 64 * kGWaves : 64) void k_tetra_gardner(co
                     for (int o = 0; o < 8; ++o) myring[((kGChunk * cn + 8 * gI) & (kGRing - 1)) + o] = make_float2(0.f, 0.f);
                 } else {
                     // window: HBM -> registers -> this wavefront's LDS rows (nobody else reads them: no barrier, only the wait)
-                    if (inside(cn)) {
+                    if (FMT8) {
+#pragma unroll
+                        for (int k = 0; k < GW::loads; ++k) {
+                            const int ga = g0 + 2 * xpr[k];
+                            if (k < GW::loads - 1 || lane + 64 * k < 8 * GW::pairs) {
+                                float2 *d = xw + xcar[k] * GW::pitch + GW::slot(2 * xpr[k]);
+                                d[0] = (ga >= 0 && ga < n) ? mf_convert8<FMT8 ? FMT8 : 1>(pf8[k]) : make_float2(0.f, 0.f);
+                                d[1] = (ga + 1 >= 0 && ga + 1 < n) ? mf_convert8<FMT8 ? FMT8 : 1>(pf8[k] >> 16) : make_float2(0.f, 0.f);
+                            }
+                        }
+                    } else if (inside(cn)) {
 #pragma unroll
                         for (int k = 0; k < GW::loads; ++k)
                             if (k < GW::loads - 1 || lane + 64 * k < 8 * GW::pairs) *(f32x4 *)(xw + xcar[k] * GW::pitch + GW::slot(2 * xpr[k])) = pf[k];

@@ -61,7 +61,7 @@ void tetra_gardner_loop_launch(const TetraParams &tp, int rows, const float2 *y,
 // the matched filter and the loop in ONE kernel (the filter output stays in LDS); false when not instantiated for tp.ntaps
 // (the caller then makes the three launches)
 int tetra_gardner_fused_per_cu(int ntaps);                 // workgroups of the fused kernel a compute unit holds (0: not instantiated)
-bool tetra_gardner_fused_available(int ntaps, int rows);   // instantiated for the tap count, and not slower than the three launches at this size
+bool tetra_gardner_fused_available(int ntaps, int rows, int fmt8 = 0);   // fmt8: tetra_launch's   // instantiated for the tap count, and not slower than the three launches at this size
 // seg (tetra_gardner_kernels.hpp GardnerSeg, or null): the carriers as two virtual carriers each (tp.n = a half's length,
 // rows = 2 x the physical carriers, outputs into the caller's temporaries); tetra_decide_launch joins them afterwards
 // Two segments per carrier (rounds of 4096 carriers or fewer: one loop wavefront per compute unit leaves seven eighths of the
@@ -91,7 +91,7 @@ struct GardnerSeg {
     int32_t ff_first;
 };
 
-bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const float2 *x, int64_t in_stride, float2 *soft, int32_t *n_soft,
+bool tetra_gardner_fused_launch(const TetraParams &tp, int rows, const void *x, int fmt8, int64_t in_stride, float2 *soft, int32_t *n_soft,
                                 int32_t *timing_milli, hipStream_t stream, const GardnerSeg *seg = nullptr);
 // seg != null: the carriers' pieces are joined first (k_tetra_gardner_join): soft_b [(pieces - 1) rows][cap_b] the symbols of
 // pieces 1.., n_v / timing_v [pieces rows] the pieces' counts and timing; soft / n_soft / timing_milli receive the joined carrier
