@@ -248,7 +248,9 @@ TDM_API int tdm_demodulate_dqpsk(const double *x, int64_t n, uint8_t *out, int64
 /* scipy.signal.decimate(x, q) as called at processor.py:254 (y has room for ceil(n/q));
  * returns TDM_ERR_INVALID when n <= 27 (scipy raises there). */
 TDM_API int tdm_decimate(const double *x, int64_t n, int32_t q, double *y, int64_t *n_out, int32_t device);
-/* resample (processor.py:35-49): scipy.signal.resample (FFT method) to `num` points */
+/* resample (processor.py:35-49): scipy.signal.resample (FFT method) to `num` points.  Short inputs as direct sums with exact
+ * twiddles; from 2^24 terms on as fast transforms of arbitrary length (radix-2 passes for powers of two, Bluestein's chirp-z form
+ * otherwise), both in fp64: 1e-15 from scipy on 131 072-sample arrays. */
 TDM_API int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t device);
 
 /* ---- spectrum / AFC / signal gate in front of process() -----------------------

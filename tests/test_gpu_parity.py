@@ -492,6 +492,39 @@ def test_decimate_entry_vs_goldens(gold_stages):
     assert np.max(np.abs(dec(23) - ref)) <= 1e-12 * np.max(np.abs(ref))
 
 
+def test_resample_long_inputs_vs_scipy(SP):
+    """SignalProcessor.resample (processor.py:35-49 -> scipy.signal.resample, FFT method) on capture-sized arrays: from 2^24
+    terms on the transforms run as fast transforms (fft_kernels.hpp: Stockham radix-2 passes for powers of two, Bluestein's
+    chirp-z form for every other length) instead of direct sums.  Against scipy itself (present on the GPU box as in the build
+    container; the short goldens of test_stage_methods stay the pinned ones): powers of two, composite and PRIME lengths, down- and
+    up-sampling, the folded / split Nyquist bin (even kept-bin counts), within 1e-11 of the largest output; a NaN input gives an
+    all-NaN output as in the reference; and the time of one 131 072-sample call."""
+    import time
+    import scipy.signal as sg
+    from tetraear_amd import synth
+    p = SP(2.4e6)
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for n, target in ((131072, 1.2e6), (262144, 240000.0), (100000, 1.0e6), (30011, 2.0e6), (65536, 3.1e6), (50000, 2.4e6 * 49999 / 50000),
+                      (4100, 1.0e6), (4099, 2.4e6 * 5000 / 4099)):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        y = p.resample(x, target)
+        ref = sg.resample(x, int(n * target / 2.4e6))
+        assert y.shape == ref.shape and y.dtype == np.complex128, (n, target)
+        err = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
+        worst = max(worst, err)
+        assert err <= 1e-11, (n, target, err)
+    x = synth.cu8_to_c128(synth.noise_cu8(131072, 5))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        y = p.resample(x, 1.2e6)
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    x[7] = np.nan
+    assert np.isnan(p.resample(x, 1.2e6)).all()
+    print(f"resample on long inputs: worst error against scipy {worst:.2e} of the largest output; 131072 -> 65536 samples in {ms:.1f} ms per call (host arrays in and out)")
+    p.close()
+
+
 def test_one_plan_serves_ragged_lengths():
     """tdm_plan_resize: one 3-carrier plan walks through 48 chunk lengths (more than it keeps variants for), shorter and
     longer than the length it was made for (work buffers grow), revisits lengths, and every call equals the C oracle;

@@ -22,6 +22,7 @@
 #include "dev_comm.hpp"
 #include "launch.hpp"
 #include "resample_plan.hpp"
+#include "fft_kernels.hpp"
 #include "sync_kernels.hpp"
 #include "tetra_params.hpp"
 #include "pfb_kernels.hpp"
@@ -1829,6 +1830,79 @@ int tdm_demodulate_dqpsk(const double *x, int64_t n, uint8_t *out, int64_t *n_ou
     return rc;
 }
 
+// out = DFT_L(in) with kernel exp(sign 2 pi i nk / L), times scale; in / out: L complex doubles in device memory (may be the
+// same buffer); w0, w1, w2: work buffers of fft_work_len(L) complex doubles each.  Launches on the null stream.
+static int64_t fft_work_len(int64_t L)
+{
+    if ((L & (L - 1)) == 0) return L;
+    int64_t M = 1;
+    while (M < 2 * L - 1) M <<= 1;
+    return M;
+}
+static int fft_pow2(f64c *&a, f64c *&tmp, int64_t M, double sign)   // result in `a` (the pointers are swapped as the passes go)
+{
+    const int64_t half = M / 2;
+    for (int64_t p = 1; p < M; p <<= 1) {
+        hipLaunchKernelGGL(k_fft2_pass, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, 0, a, tmp, half, p, sign);
+        std::swap(a, tmp);
+    }
+    HIP_TRY(hipGetLastError());
+    return TDM_OK;
+}
+static int dft_any(const f64c *in, f64c *out, int64_t L, double sign, double scale, f64c *w0, f64c *w1, f64c *w2)
+{
+    int rc;
+    const int64_t M = fft_work_len(L);
+    const unsigned gm = (unsigned)((M + 255) / 256), gl = (unsigned)((L + 255) / 256);
+    if (M == L) {   // a power of two: the passes themselves
+        if (L == 1) { hipLaunchKernelGGL(k_fft_scale_copy, dim3(1), dim3(256), 0, 0, in, out, L, scale); return TDM_OK; }
+        HIP_TRY(hipMemcpyAsync(w0, in, (size_t)L * 16, hipMemcpyDeviceToDevice, 0));
+        f64c *a = w0, *t = w1;
+        if ((rc = fft_pow2(a, t, M, sign))) return rc;
+        hipLaunchKernelGGL(k_fft_scale_copy, dim3(gl), dim3(256), 0, 0, a, out, L, scale);
+        return TDM_OK;
+    }
+    hipLaunchKernelGGL(k_bluestein_pre, dim3(gm), dim3(256), 0, 0, in, w0, w1, L, M, sign);
+    f64c *a = w0, *b = w1, *t = w2;
+    if ((rc = fft_pow2(a, t, M, -1.0))) return rc;       // (a, t) now name two of the three buffers; b is the third
+    f64c *t2 = t;
+    if ((rc = fft_pow2(b, t2, M, -1.0))) return rc;
+    hipLaunchKernelGGL(k_fft_cmul, dim3(gm), dim3(256), 0, 0, a, b, M);
+    f64c *t3 = t2;
+    if ((rc = fft_pow2(a, t3, M, 1.0))) return rc;
+    hipLaunchKernelGGL(k_bluestein_post, dim3(gl), dim3(256), 0, 0, a, out, L, sign, scale / (double)M);
+    HIP_TRY(hipGetLastError());
+    return TDM_OK;
+}
+
+// scipy.signal.resample (FFT method) on long inputs: X = fft(x), the spectrum bookkeeping of resample_plan.hpp, y = ifft(Y) num / n
+static int resample_fft(const double *x, int64_t n, int64_t num, double *y, const ResamplePlan &rp)
+{
+    const int64_t nb = (int64_t)rp.src_bins.size(), nt = (int64_t)rp.term_src.size();
+    const int64_t W = std::max(fft_work_len(n), fft_work_len(num));
+    DevBuf dx, dX, dY, dy, w0, w1, w2, dbins, dsrc, ddst, dw;
+    int rc;
+    if ((rc = dx.alloc((size_t)n * 16)) || (rc = dX.alloc((size_t)n * 16)) || (rc = dY.alloc((size_t)num * 16)) || (rc = dy.alloc((size_t)num * 16)) ||
+        (rc = w0.alloc((size_t)W * 16)) || (rc = w1.alloc((size_t)W * 16)) || (rc = w2.alloc((size_t)W * 16)) ||
+        (rc = dbins.alloc((size_t)nb * 8)) || (rc = dsrc.alloc((size_t)nt * 8)) || (rc = ddst.alloc((size_t)nt * 8)) || (rc = dw.alloc((size_t)nt * 8)))
+        return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dbins.p, rp.src_bins.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dsrc.p, rp.term_src.data(), (size_t)nt * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ddst.p, rp.term_dst.data(), (size_t)nt * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dw.p, rp.term_w.data(), (size_t)nt * 8, hipMemcpyHostToDevice));
+    if ((rc = dft_any(dx.as<f64c>(), dX.as<f64c>(), n, -1.0, 1.0, w0.as<f64c>(), w1.as<f64c>(), w2.as<f64c>()))) return rc;
+    HIP_TRY(hipMemsetAsync(dY.p, 0, (size_t)num * 16, 0));
+    hipLaunchKernelGGL(k_resample_terms, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, dX.as<f64c>(), dY.as<f64c>(), dbins.as<int64_t>(),
+                       dsrc.as<int64_t>(), ddst.as<int64_t>(), dw.as<double>(), nt);
+    // ifft's 1 / num times resample's num / n
+    if ((rc = dft_any(dY.as<f64c>(), dy.as<f64c>(), num, 1.0, 1.0 / (double)n, w0.as<f64c>(), w1.as<f64c>(), w2.as<f64c>()))) return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(y, dy.p, (size_t)num * 16, hipMemcpyDeviceToHost));
+    return TDM_OK;
+}
+
 int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t device)
 {
     if (n < 0 || num < 0 || (n > 0 && !x) || (num > 0 && !y)) return fail(TDM_ERR_INVALID, "bad argument");
@@ -1839,6 +1913,8 @@ int tdm_resample(const double *x, int64_t n, int64_t num, double *y, int32_t dev
     if (n == 0) { std::memset(y, 0, (size_t)num * 16); return TDM_OK; }
     ResamplePlan rp = build_resample_plan(n, num);
     const int64_t nb = (int64_t)rp.src_bins.size(), nt = (int64_t)rp.term_src.size();
+    if ((double)n * (double)nb + (double)nt * (double)num >= 16777216.0 && n <= (int64_t(1) << 24) && num <= (int64_t(1) << 24))
+        return resample_fft(x, n, num, y, rp);   // long inputs: fast transforms (fft_kernels.hpp) instead of direct sums
     DevBuf dx, dX, dy, dbins, dsrc, ddst, dw;
     if ((rc = dx.alloc((size_t)n * 16)) || (rc = dX.alloc((size_t)nb * 16)) || (rc = dy.alloc((size_t)num * 16)) ||
         (rc = dbins.alloc((size_t)nb * 8)) || (rc = dsrc.alloc((size_t)nt * 8)) || (rc = ddst.alloc((size_t)nt * 8)) ||
