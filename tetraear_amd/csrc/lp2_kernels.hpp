@@ -23,11 +23,7 @@
 #include "lp2_tables.hpp"
 #include "pz_kernels.hpp"
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TDM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define TDM_SCHED_FENCE() do { } while (0)
-#endif
+// (TDM_SCHED_FENCE: pz_kernels.hpp)
 
 namespace tdm {
 

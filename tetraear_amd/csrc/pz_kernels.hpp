@@ -427,9 +427,8 @@ TDM_HD void pz_block_finish(const ZpParams &P, Comm &cm, int lane, int blk, int 
 template <int Q, int S, int EDGE, class Loader, class Comm>
 TDM_HD void pz_block_body(const ZpParams &P, const Loader &ld, Comm &cm, int lane, int blk, int row)
 {
-    constexpr int NP = PzLayout::kMaxPairs, D = 2 * NP;
+    constexpr int NP = PzLayout::kMaxPairs;
     constexpr int L = Q * S;
-    constexpr int Bn = kWave * L;
     typedef PzEdgeGeom<L, EDGE> G;
     double xr[L], xi[L];
     ld.template load<L, EDGE>(cm, row, blk, lane, P, xr, xi);
