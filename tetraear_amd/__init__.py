@@ -2,6 +2,7 @@
 
     from tetraear_amd.signal import SignalProcessor      # drop-in for tetraear.signal.SignalProcessor
     from tetraear_amd.batch import BatchDemodulator      # many carriers per call, device-resident
+    from tetraear_amd.batch import batch_demodulator     # ... with three steps in flight (PipelinedBatchDemodulator)
 
 All arithmetic runs in hand-written HIP kernels behind the C-ABI of include/tetrahip.h
 (libtetrahip.so, loaded with ctypes).  There is no CPU compute path.
@@ -12,11 +13,11 @@ def __getattr__(name):
     if name == "SignalProcessor":
         from tetraear_amd.signal.processor import SignalProcessor
         return SignalProcessor
-    if name == "BatchDemodulator":
-        from tetraear_amd.batch import BatchDemodulator
-        return BatchDemodulator
+    if name in ("BatchDemodulator", "PipelinedBatchDemodulator", "batch_demodulator"):
+        from tetraear_amd import batch
+        return getattr(batch, name)
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
-__all__ = ["SignalProcessor", "BatchDemodulator"]
-__version__ = "0.1.0"
+__all__ = ["SignalProcessor", "BatchDemodulator", "PipelinedBatchDemodulator", "batch_demodulator"]
+__version__ = "0.1.2"
