@@ -480,10 +480,17 @@ def main():
         except RcclUnavailable as e:
             import torch
             import torch.distributed as dist
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            group = TorchGroup(dist, "cuda")
-            collective = f"torch.distributed nccl (librccl through ctypes not usable on every rank: {e})"
+            if os.environ.get("TDM_DIST_BACKEND") == "gloo":
+                # dry run of the N > 1 logic where the ranks cannot have a device each (several ranks on ONE GPU: RCCL refuses
+                # duplicate devices): host-side reductions; the line says so, its timing means nothing
+                dist.init_process_group("gloo")
+                group = TorchGroup(dist, None)
+                collective = "torch.distributed gloo (TDM_DIST_BACKEND=gloo: a dry run of the multi-rank logic, NOT a measurement)"
+            else:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                group = TorchGroup(dist, "cuda")
+                collective = f"torch.distributed nccl (librccl through ctypes not usable on every rank: {e})"
 
     from tetraear_amd import batch as batch_mod
     from tetraear_amd.shard import carrier_range, reduce_job
