@@ -100,3 +100,52 @@ def test_plan_wait_for_orders_two_plans_on_the_device():
     with pytest.raises(_lib.TetraHipError):
         _lib.check(_lib.load().tdm_plan_wait_for(None, a.handle))
     a.close(); b.close()
+
+
+def test_pipelined_host_logic_with_stand_in_plans(monkeypatch):
+    """CPU tier: the turn-taking logic of PipelinedBatchDemodulator on stand-in plans (no device): step k goes to plan k % depth,
+    `upload(slot=k)` feeds that plan only, `download` returns the last step's plan, per-stage timing orders every step behind the
+    previous one (wait_for) and plain timing does not."""
+    import tetraear_amd.batch as batch
+    log = []
+
+    class Plan:
+        count = 0
+
+        def __init__(self, *a, **k):
+            self.idx = Plan.count
+            Plan.count += 1
+            self.info, self.soft_dtype, self.data = "info", np.complex128, None
+
+        def alloc_device_io(self, shared_input=False): log.append(("alloc", self.idx, shared_input))
+        def upload(self, iq, fo=None, ps=None): self.data = iq
+        def enqueue(self): log.append(("enqueue", self.idx))
+        def wait_for(self, other): log.append(("wait", self.idx, other.idx))
+        def sync(self): pass
+        def download(self): return ("out", self.idx, self.data)
+        def time_begin(self, per_stage=True): log.append(("begin", self.idx, per_stage))
+        def time_end(self): return 1.0 + self.idx
+        def stage_times(self): return {"dec_block": 0.1 * (self.idx + 1)}
+        def close(self): log.append(("close", self.idx))
+
+    monkeypatch.setattr(batch, "BatchDemodulator", Plan)
+    pl = batch.PipelinedBatchDemodulator(2.4e6, 4096, 4, "cu8", depth=3)
+    assert pl.depth == 3
+    pl.alloc_device_io()
+    pl.upload("all")
+    assert [p.data for p in pl.plans] == ["all"] * 3
+    for k in range(5):
+        pl.upload(f"chunk{k}", slot=k)
+        pl.enqueue()
+    assert [e[1] for e in log if e[0] == "enqueue"] == [0, 1, 2, 0, 1]
+    assert not [e for e in log if e[0] == "wait"]                  # steps overlap unless a per-stage pass is on
+    assert pl.download() == ("out", 1, "chunk4") and [o[2] for o in pl.download_all()] == ["chunk3", "chunk4", "chunk2"]
+    pl.time_begin(per_stage=True)
+    pl.enqueue(); pl.enqueue()
+    assert [e for e in log if e[0] == "wait"] == [("wait", 2, 1), ("wait", 0, 2)]
+    assert pl.time_end() == 3.0 and abs(pl.stage_times()["dec_block"] - 0.2) < 1e-12
+    pl.enqueue()
+    assert len([e for e in log if e[0] == "wait"]) == 2             # (back to overlapping steps after time_end)
+    pl.close()
+    assert [e[1] for e in log if e[0] == "close"] == [0, 1, 2]
+    assert isinstance(batch.batch_demodulator(2.4e6, 4096, 4, "cu8", depth=1), Plan)
