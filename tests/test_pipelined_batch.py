@@ -144,6 +144,10 @@ def test_pipelined_host_logic_with_stand_in_plans(monkeypatch):
     pl.enqueue(); pl.enqueue()
     assert [e for e in log if e[0] == "wait"] == [("wait", 2, 1), ("wait", 0, 2)]
     assert pl.time_end() == 3.0 and abs(pl.stage_times()["dec_block"] - 0.2) < 1e-12
+    keep = Plan.stage_times
+    Plan.stage_times = lambda self: {} if self.idx == 1 else keep(self)      # (a plan that took no step of a short per-stage pass)
+    assert abs(pl.stage_times()["dec_block"] - 0.2) < 1e-12
+    Plan.stage_times = keep
     pl.enqueue()
     assert len([e for e in log if e[0] == "wait"]) == 2             # (back to overlapping steps after time_end)
     pl.close()

@@ -380,8 +380,9 @@ class PipelinedBatchDemodulator:
         return max(p.time_end() for p in self.plans)
 
     def stage_times(self):
-        ts = [p.stage_times() for p in self.plans]
-        return {k: sum(t[k] for t in ts) / len(ts) for k in ts[0]}
+        ts = [t for t in (p.stage_times() for p in self.plans) if t]     # (a plan that took no step of the pass has no times)
+        keys = [k for t in ts for k in t]
+        return {k: sum(t[k] for t in ts if k in t) / sum(1 for t in ts if k in t) for k in dict.fromkeys(keys)}
 
     def close(self):
         for p in getattr(self, "plans", []):
